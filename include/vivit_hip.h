@@ -1,0 +1,149 @@
+/*
+ * vivit_hip.h -- C ABI of libvivit_hip.so, the MI355X (gfx950) kernel library behind the
+ * low-rank GGN curvature path of ViViT (Gram build V^T V  +  symmetric eigendecomposition
+ * + Gram-space -> parameter-space maps).
+ *
+ * The reference (f-dangel/vivit) is pure Python and has no FFI; each entry point below names
+ * the reference call site (path:line under /root/reference) whose tensor op it replaces.  A
+ * Python maintainer binds these with ctypes; nothing here uses torch
+ * types.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to fp32 row-major data owned by the caller, unless the
+ *     parameter is documented as a host pointer; leading dimensions are in ELEMENTS;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only enqueue
+ *     work and never synchronise, allocate or free device memory; scratch memory comes from the
+ *     caller through (workspace, workspace_bytes) sized by the matching *_workspace_bytes query;
+ *   - return value: 0 = ok; <0 = bad argument (VIVIT_E_*); a numerical failure of the
+ *     eigensolver is reported asynchronously through the device-side `info` word
+ *     (0 = converged, k>0 = k off-diagonal elements did not converge), which the host maps to
+ *     the reference's RuntimeError (vivit/utils/eig.py:37-40,103-106);
+ *   - results are deterministic: no float atomics, fixed reduction orders.
+ */
+#ifndef VIVIT_HIP_H
+#define VIVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIVIT_OK 0
+#define VIVIT_E_BADARG (-1)     /* null pointer, negative size, ld too small               */
+#define VIVIT_E_WORKSPACE (-2)  /* workspace missing or smaller than *_workspace_bytes      */
+#define VIVIT_E_LAUNCH (-3)     /* hipLaunch reported an error (hipGetLastError != success) */
+#define VIVIT_E_UNSUPPORTED (-4)
+
+/* Library/ABI version (major*1000 + minor) and the gfx target it was compiled for. */
+int vivit_hip_abi_version(void);
+const char *vivit_hip_target(void);
+const char *vivit_hip_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  Gram contraction (SYRK):  G = alpha * A A^T + beta * G
+ *   A: [n, p] (one parameter's V_t viewed as [C*N, P_param]; K-contiguous rows, lda >= p)
+ *   G: [n, n] full symmetric output (both triangles written), ldg >= n.
+ * Replaces partial_contract(V, V, (2, 2)) = einsum("cn<p>,dm<p>->cndm")
+ *   vivit/utils/gram.py:206-232 via pairwise_dot :9-35; callers
+ *   vivit/extensions/secondorder/vivit/base.py:118-124,
+ *   vivit/extensions/secondorder/sqrt_ggn/gram_sqrt_ggn.py:50-52,
+ *   vivit/optim/directional_damped_newton.py:254, and the `gram += gram_p` accumulation of
+ *   vivit/utils/gram.py:104-116 (beta = 1).
+ * Only the lower-triangular 128x128 tiles are computed on MFMA (n(n+1)p flops) and mirrored.
+ * ------------------------------------------------------------------------------------------- */
+size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p);
+int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float *G, int64_t ldg,
+                        float alpha, float beta, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2/K5/K9  C = alpha * A B^T + beta * C      A: [m, k] lda, B: [n, k] ldb, C: [m, n] ldc
+ * Replaces partial_contract(V, g, (2, 1))  vivit/optim/directional_damped_newton.py:255,
+ *   mVp  vivit/utils/gram.py:182-203, and the gamma einsum "in,id->nd" (on transposed views)
+ *   vivit/optim/directional_damped_newton.py:342.
+ * ------------------------------------------------------------------------------------------- */
+size_t vivit_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int vivit_gemm_nt_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k,
+                      int64_t lda, int64_t ldb, int64_t ldc, float alpha, float beta,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* K6/K7/K8  C = alpha * A B + beta * C        A: [m, k] lda, B: [k, n] ldb, C: [m, n] ldc
+ * Replaces Vmp  vivit/utils/ggn.py:94-115 (eigenvector back-projection, eigh.py:267-270),
+ *   the Newton-step back-projection einsum("cn,cn...->...")
+ *   vivit/optim/directional_damped_newton.py:370-373 (m = 1), and "cni,id->cnd" :348-350. */
+int vivit_gemm_nn_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k,
+                      int64_t lda, int64_t ldb, int64_t ldc, float alpha, float beta,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* C = alpha * A^T B + beta * C                A: [k, m] lda, B: [k, n] ldb, C: [m, n] ldc
+ * Replaces einsum("in,id->nd")  vivit/optim/directional_damped_newton.py:342 without a
+ * transposed copy, and Y^T Z in the Householder back-transformation of the eigensolver. */
+int vivit_gemm_tn_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k,
+                      int64_t lda, int64_t ldb, int64_t ldc, float alpha, float beta,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1'  Factorised Gram of a Linear weight:  G[c,n,d,m] = alpha * Gz[n,m] * Gs[c,n,d,m] + beta*G
+ *   Gz: [N, N] (z z^T), Gs: [C*N, C*N] (s s^T), G: [C*N, C*N], all contiguous.
+ * Replaces einsum("nm,cndm->cndm")  vivit/extensions/secondorder/vivit/linear.py:72-75.
+ * ------------------------------------------------------------------------------------------- */
+int vivit_gram_hadamard_f32(const float *Gz, const float *Gs, float *G, int64_t C, int64_t N,
+                            float alpha, float beta, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3/K4  Symmetric eigendecomposition (Householder tridiagonalisation + implicit-shift QL,
+ * divide-and-conquer merges above the single-workgroup size).
+ *   A: [n, n] symmetric, lda >= n.  DESTROYED (holds the Householder reflectors on return).
+ *      Only the lower triangle (A[i][j], i >= j) is read.
+ *   w: [n] eigenvalues, ascending.
+ *   Z: [n, n] ldz >= n or NULL.  Z[:, i] is the unit eigenvector of w[i] (column-wise, as
+ *      Tensor.symeig returned them: vivit/utils/eig.py:24-26).  NULL = values only.
+ *   info: device int32; 0 on success, >0 = number of unconverged eigenvalues.
+ * Replaces Tensor.symeig(eigenvectors=False)  vivit/linalg/eigvalsh.py:221 and
+ *   Tensor.symeig(eigenvectors=True)  vivit/linalg/eigh.py:248-250,
+ *   vivit/optim/directional_damped_newton.py:315, vivit/optim/directional_derivatives.py:291,
+ *   vivit/utils/eig.py:38,104.
+ * ------------------------------------------------------------------------------------------- */
+size_t vivit_symeig_f32_workspace_bytes(int64_t n, int want_vectors);
+int vivit_symeig_f32(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz,
+                     void *workspace, size_t workspace_bytes, int32_t *info, void *stream);
+
+/* Eigen-decomposition of a symmetric TRIDIAGONAL matrix (d: [n] diagonal, e: [n-1]
+ * off-diagonal; both destroyed).  Stage 2 of vivit_symeig_f32, exported for testing. */
+size_t vivit_stedc_f32_workspace_bytes(int64_t n, int want_vectors);
+int vivit_stedc_f32(float *d, float *e, int64_t n, float *w, float *Z, int64_t ldz,
+                    void *workspace, size_t workspace_bytes, int32_t *info, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6  Directional curvatures from the Gram eigenvectors:
+ *   lambdas[n, k] = scale * sum_c ( sum_i G[(c,n), i] E[i, k] )^2 / evals[k]
+ *   G: [C*N, C*N], E: [C*N, K] (ld = lde), evals: [K], lambdas: [N, K].
+ *   GE: [C*N, K] scratch holding G @ E (computed by vivit_gemm_nn_f32 beforehand).
+ * Replaces (V_n_T_V_e_d ** 2).sum(0) / evals
+ *   vivit/optim/directional_damped_newton.py:348-351, directional_derivatives.py:322-325.
+ * ------------------------------------------------------------------------------------------- */
+int vivit_dir_curvature_f32(const float *GE, const float *evals, float *lambdas, int64_t C,
+                            int64_t N, int64_t K, float scale, void *stream);
+
+/* K5 epilogue / K10: out[r, k] = in[r, k] * (pre) / sqrt(evals[k])   (column scaling)
+ * Replaces "/ evals.sqrt()"  vivit/optim/directional_damped_newton.py:342. */
+int vivit_scale_cols_rsqrt_f32(float *X, const float *evals, int64_t rows, int64_t K, int64_t ldx,
+                               float pre, void *stream);
+
+/* K10  Squared 2-norms of K stacked vectors: acc[k] += sum_j X[k, j]^2, X: [K, len] contiguous;
+ *      then vivit_scale_rows_f32 applies X[k, :] *= rsqrt(acc[k]).
+ * Replaces normalize  vivit/linalg/utils.py:67-76. */
+size_t vivit_row_sqnorm_workspace_bytes(int64_t K, int64_t len);
+int vivit_row_sqnorm_acc_f32(const float *X, float *acc, int64_t K, int64_t len, void *workspace,
+                             size_t workspace_bytes, void *stream);
+int vivit_scale_rows_rsqrt_f32(float *X, const float *acc, int64_t K, int64_t len, void *stream);
+
+/* Mirror the lower triangle of G into the upper triangle (G[i][j] = G[j][i], i < j). */
+int vivit_symmetrize_lower_f32(float *G, int64_t n, int64_t ldg, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIVIT_HIP_H */

@@ -1,0 +1,132 @@
+"""GPU parity of the raw kernels (through the C ABI) against fp64 references computed on the host."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize(
+    "m,n,k",
+    [(1, 1, 1), (5, 7, 3), (128, 128, 16), (130, 250, 37), (64, 300, 1000), (257, 129, 515), (10, 10, 5000), (300, 300, 70000)],
+)
+def test_gemm_variants(m, n, k):
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(m * 1000003 + n * 1009 + k)
+    A = torch.randn(m, k, generator=g)
+    B = torch.randn(n, k, generator=g)
+    C0 = torch.randn(m, n, generator=g)
+    ref = A.double() @ B.double().T
+    Ad, Bd = A.to(_dev()), B.to(_dev())
+    tol = 2e-6 * (k ** 0.5) + 1e-6
+    out = kernels.gemm_nt(Ad, Bd)
+    assert _rel(out, ref) < tol
+    out = kernels.gemm_nn(Ad, Bd.T.contiguous())
+    assert _rel(out, ref) < tol
+    out = kernels.gemm_tn(Ad.T.contiguous(), Bd.T.contiguous())
+    assert _rel(out, ref) < tol
+    # alpha / beta
+    Cd = C0.to(_dev()).clone()
+    kernels.gemm_nt(Ad, Bd, out=Cd, alpha=0.5, beta=-2.0)
+    assert _rel(Cd, 0.5 * ref - 2.0 * C0.double()) < tol
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C write (MFMA C/D layout)."""
+    from vivit_amd import kernels
+
+    n = 96
+    B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251
+    I = torch.eye(n)
+    out = kernels.gemm_nn(I.to(_dev()), B.to(_dev()))
+    assert torch.equal(out.cpu(), B)
+    out = kernels.gemm_nt(I.to(_dev()), B.to(_dev()))
+    assert torch.equal(out.cpu(), B.T)
+
+
+@pytest.mark.parametrize("n,p", [(1, 1), (3, 10), (15, 42), (128, 64), (200, 333), (640, 513), (1280, 4096), (300, 100000)])
+def test_gram_syrk(n, p):
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(n * 7919 + p)
+    A = torch.randn(n, p, generator=g)
+    ref = A.double() @ A.double().T
+    Ad = A.to(_dev())
+    G = kernels.gram_syrk(Ad)
+    tol = 2e-6 * (p ** 0.5) + 1e-6
+    assert _rel(G, ref) < tol
+    assert torch.equal(G, G.T), "Gram must be exactly symmetric"
+    # accumulate (beta = 1), the `gram += gram_p` of vivit/utils/gram.py:104-116
+    G2 = kernels.gram_syrk(Ad, out=G.clone(), alpha=1.0, beta=1.0)
+    assert _rel(G2, 2 * ref) < tol
+    assert torch.equal(G2, G2.T)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 15, 33, 64, 100, 128, 192])
+@pytest.mark.parametrize("kind", ["dense", "lowrank"])
+def test_symeig_small(n, kind):
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(n * 31 + (kind == "dense"))
+    if kind == "dense":
+        M = torch.randn(n, n, generator=g)
+        S = (M + M.T) / 2
+    else:
+        r = max(1, n // 3)
+        V = torch.randn(n, r, generator=g)
+        S = V @ V.T
+    ref_w, ref_Z = torch.linalg.eigh(S.double())
+    Sd = S.to(_dev())
+    w, _ = kernels.symeig(Sd, eigenvectors=False)
+    scale = ref_w.abs().max().item()
+    assert (w.double().cpu() - ref_w).abs().max().item() <= 2e-5 * scale + 1e-30
+    assert torch.equal(Sd.cpu(), S), "input must not be modified"
+    w2, Z = kernels.symeig(Sd, eigenvectors=True)
+    assert (w2.double().cpu() - ref_w).abs().max().item() <= 2e-5 * scale + 1e-30
+    Zc = Z.double().cpu()
+    eye = torch.eye(n, dtype=torch.float64)
+    assert (Zc.T @ Zc - eye).abs().max().item() < 2e-5
+    resid = S.double() @ Zc - Zc * w2.double().cpu()
+    assert resid.abs().max().item() <= 5e-5 * scale
+
+
+def test_symeig_rank1_denormal():
+    """Analogue of the reference's tensor_causes_symeig_error.pt (test/utils/test_stable_symeig.py:13-45):
+    128x128, effectively rank one with lambda_max ~ 6e7 on a background of denormals."""
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(0)
+    u = torch.randn(128, generator=g)
+    u = u / u.norm()
+    S = 6.2764e7 * torch.outer(u, u)
+    S = S + 1.8367e-40 * torch.ones(128, 128)
+    S = (S + S.T) / 2
+    w, Z = kernels.symeig(S.to(_dev()), eigenvectors=True)
+    assert abs(w[-1].item() - 6.2764e7) < 6.2764e7 * 1e-5
+    assert w[:-1].abs().max().item() < 6.2764e7 * 1e-5
+    Zc = Z.double().cpu()
+    assert (Zc.T @ Zc - torch.eye(128, dtype=torch.float64)).abs().max().item() < 2e-5
+
+
+def test_symeig_nan_raises():
+    from vivit_amd import kernels
+
+    S = torch.eye(8)
+    S[2, 1] = float("nan")
+    with pytest.raises(RuntimeError):
+        kernels.symeig(S.to(_dev()), eigenvectors=True)
+
+
+def test_cpu_tensor_rejected():
+    from vivit_amd import kernels
+
+    with pytest.raises(RuntimeError):
+        kernels.gram_syrk(torch.randn(4, 4))

@@ -1,0 +1,72 @@
+"""ctypes binding of libvivit_hip.so (the C ABI declared in include/vivit_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  Loading fails loudly when the
+shared object is missing, and every wrapper in :mod:`vivit_amd.kernels` raises if it is handed a
+tensor that does not live on a HIP device.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvivit_hip.so")
+
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
+_ptr = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); mirrors include/vivit_hip.h one-to-one.
+SIGNATURES = {
+    "vivit_hip_abi_version": (_int, []),
+    "vivit_hip_target": (ctypes.c_char_p, []),
+    "vivit_hip_status_string": (ctypes.c_char_p, [_int]),
+    "vivit_gram_syrk_f32_workspace_bytes": (_sz, [_i64, _i64]),
+    "vivit_gram_syrk_f32": (_int, [_ptr, _i64, _i64, _i64, _ptr, _i64, _f32, _f32, _ptr, _sz, _ptr]),
+    "vivit_gemm_f32_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "vivit_gemm_nt_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _ptr, _sz, _ptr]),
+    "vivit_gemm_nn_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _ptr, _sz, _ptr]),
+    "vivit_gemm_tn_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _ptr, _sz, _ptr]),
+    "vivit_gram_hadamard_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _ptr]),
+    "vivit_symeig_f32_workspace_bytes": (_sz, [_i64, _int]),
+    "vivit_symeig_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
+    "vivit_stedc_f32_workspace_bytes": (_sz, [_i64, _int]),
+    "vivit_stedc_f32": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
+    "vivit_dir_curvature_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr]),
+    "vivit_scale_cols_rsqrt_f32": (_int, [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr]),
+    "vivit_row_sqnorm_workspace_bytes": (_sz, [_i64, _i64]),
+    "vivit_row_sqnorm_acc_f32": (_int, [_ptr, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
+    "vivit_scale_rows_rsqrt_f32": (_int, [_ptr, _ptr, _i64, _i64, _ptr]),
+    "vivit_symmetrize_lower_f32": (_int, [_ptr, _i64, _i64, _ptr]),
+}
+
+_lib = None
+
+
+class VivitHipError(RuntimeError):
+    """A libvivit_hip.so entry point returned a non-zero status."""
+
+
+def load():
+    """Load the shared library (once) and attach the prototypes. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950). vivit_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().vivit_hip_status_string(int(status)).decode()
+        raise VivitHipError(f"{what}: status {status} ({msg})")

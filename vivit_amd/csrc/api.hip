@@ -1,0 +1,47 @@
+// C-ABI glue: version queries and the symeig dispatcher (single-workgroup vs multi-kernel path).
+#include "common.h"
+
+namespace vivit {
+constexpr int SMALL_N_MAX = 192;
+int symeig_small_launch(const float *A, int64_t lda, int n, float *w, float *Z, int64_t ldz, int32_t *info,
+                        hipStream_t stream);
+size_t symeig_large_workspace_bytes(int64_t n, bool vectors);
+int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *ws, size_t ws_bytes,
+                        int32_t *info, hipStream_t stream);
+} // namespace vivit
+
+using namespace vivit;
+
+extern "C" {
+
+int vivit_hip_abi_version(void) { return 1000; }
+const char *vivit_hip_target(void) { return "gfx950"; }
+
+const char *vivit_hip_status_string(int status) {
+  switch (status) {
+    case VIVIT_OK: return "ok";
+    case VIVIT_E_BADARG: return "bad argument (null pointer, negative size or leading dimension too small)";
+    case VIVIT_E_WORKSPACE: return "workspace missing or too small";
+    case VIVIT_E_LAUNCH: return "HIP kernel launch failed";
+    case VIVIT_E_UNSUPPORTED: return "unsupported problem size";
+    default: return "unknown status";
+  }
+}
+
+size_t vivit_symeig_f32_workspace_bytes(int64_t n, int want_vectors) {
+  if (n <= SMALL_N_MAX) return 0;
+  return symeig_large_workspace_bytes(n, want_vectors != 0);
+}
+
+int vivit_symeig_f32(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *workspace,
+                     size_t workspace_bytes, int32_t *info, void *stream) {
+  if (n < 0) return VIVIT_E_BADARG;
+  if (!info) return VIVIT_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n == 0) return hipMemsetAsync(info, 0, sizeof(int32_t), s) == hipSuccess ? VIVIT_OK : VIVIT_E_LAUNCH;
+  if (!A || !w || lda < n || (Z && ldz < n)) return VIVIT_E_BADARG;
+  if (n <= SMALL_N_MAX) return symeig_small_launch(A, lda, (int)n, w, Z, ldz, info, s);
+  return symeig_large_launch(A, n, lda, w, Z, ldz, workspace, workspace_bytes, info, s);
+}
+
+} // extern "C"

@@ -1,0 +1,212 @@
+// HBM-bound epilogue kernels of the Gram path (K1', K5/K6 epilogues, K10) for gfx950.
+// All are grid-stride, 16-byte vectorised where the layout allows, and free of float atomics.
+#include "common.h"
+
+namespace vivit {
+
+constexpr int EW_BLOCK = 256;
+static inline unsigned ew_grid(int64_t work) {
+  int64_t g = cdiv(work, EW_BLOCK);
+  if (g > 2048) g = 2048;  // ~8 blocks per CU, grid-stride the rest
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// G[c,n,d,m] = alpha * Gz[n,m] * Gs[c,n,d,m] + beta * G[c,n,d,m]   (vec4 along m when N % 4 == 0)
+template <bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void hadamard_kernel(const float *__restrict__ Gz, const float *__restrict__ Gs,
+                                                            float *__restrict__ G, int64_t C, int64_t N, float alpha,
+                                                            float beta) {
+  const int64_t n = C * N;
+  const int64_t total = VEC ? (n * n) >> 2 : n * n;
+  for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t flat = VEC ? idx << 2 : idx;
+    const int64_t row = flat / n, col = flat - row * n;  // row = c*N + nn, col = d*N + mm
+    const int64_t nn = row % N, mm = col % N;
+    if (VEC) {
+      const float4 z = *reinterpret_cast<const float4 *>(Gz + nn * N + mm);
+      const float4 s = *reinterpret_cast<const float4 *>(Gs + flat);
+      float4 o = make_float4(alpha * z.x * s.x, alpha * z.y * s.y, alpha * z.z * s.z, alpha * z.w * s.w);
+      if (beta != 0.f) {
+        const float4 g = *reinterpret_cast<const float4 *>(G + flat);
+        o.x += beta * g.x; o.y += beta * g.y; o.z += beta * g.z; o.w += beta * g.w;
+      }
+      *reinterpret_cast<float4 *>(G + flat) = o;
+    } else {
+      float o = alpha * Gz[nn * N + mm] * Gs[flat];
+      if (beta != 0.f) o += beta * G[flat];
+      G[flat] = o;
+    }
+  }
+}
+
+// lambdas[nn, k] = scale * sum_c GE[(c*N + nn), k]^2 / evals[k]
+__global__ __launch_bounds__(EW_BLOCK) void dir_curvature_kernel(const float *__restrict__ GE,
+                                                                 const float *__restrict__ evals,
+                                                                 float *__restrict__ lambdas, int64_t C, int64_t N,
+                                                                 int64_t K, float scale) {
+  const int64_t total = N * K;
+  for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t nn = idx / K, k = idx - nn * K;
+    float acc = 0.f;
+    for (int64_t c = 0; c < C; ++c) {
+      const float v = GE[(c * N + nn) * K + k];
+      acc += v * v;
+    }
+    lambdas[idx] = scale * acc / evals[k];
+  }
+}
+
+// X[r, k] *= pre / sqrt(evals[k])
+__global__ __launch_bounds__(EW_BLOCK) void scale_cols_rsqrt_kernel(float *__restrict__ X,
+                                                                    const float *__restrict__ evals, int64_t rows,
+                                                                    int64_t K, int64_t ldx, float pre) {
+  const int64_t total = rows * K;
+  for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t r = idx / K, k = idx - r * K;
+    X[r * ldx + k] *= pre / sqrtf(evals[k]);
+  }
+}
+
+// part[k][b] = sum over block b's slice of X[k, :]^2; fixed-order second pass adds into acc[k].
+constexpr int SQN_CHUNK = 8192;
+__global__ __launch_bounds__(EW_BLOCK) void row_sqnorm_part_kernel(const float *__restrict__ X, float *__restrict__ part,
+                                                                   int64_t len, int nchunk) {
+  __shared__ float red[4];
+  const int64_t k = blockIdx.y;
+  const int64_t j0 = (int64_t)blockIdx.x * SQN_CHUNK;
+  const int64_t j1 = j0 + SQN_CHUNK < len ? j0 + SQN_CHUNK : len;
+  const float *row = X + k * len;
+  float s = 0.f;
+  for (int64_t j = j0 + threadIdx.x; j < j1; j += EW_BLOCK) {
+    const float v = row[j];
+    s += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[k * nchunk + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void row_sqnorm_final_kernel(const float *__restrict__ part, float *__restrict__ acc,
+                                                                    int64_t K, int nchunk) {
+  const int64_t k = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int b = 0; b < nchunk; ++b) s += part[k * nchunk + b];
+  acc[k] += s;
+}
+
+__global__ __launch_bounds__(EW_BLOCK) void scale_rows_rsqrt_kernel(float *__restrict__ X, const float *__restrict__ acc,
+                                                                    int64_t K, int64_t len) {
+  const int64_t total = K * len;
+  for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t k = idx / len;
+    X[idx] *= 1.f / sqrtf(acc[k]);
+  }
+}
+
+// G[i][j] = G[j][i] for j > i, 32x32 tiles transposed through LDS (coalesced both ways).
+__global__ __launch_bounds__(256) void symmetrize_kernel(float *__restrict__ G, int64_t n, int64_t ldg) {
+  __shared__ float t[32][33];
+  // blockIdx.x enumerates tile pairs (bi >= bj) of the lower triangle.
+  const int64_t tb = blockIdx.x;
+  int64_t bi = (int64_t)((sqrt(8.0 * (double)tb + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= tb) ++bi;
+  while (bi * (bi + 1) / 2 > tb) --bi;
+  const int64_t bj = tb - bi * (bi + 1) / 2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = bi * 32 + r, j = bj * 32 + tx;
+    t[r][tx] = (i < n && j < n) ? G[i * ldg + j] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = bj * 32 + r, j = bi * 32 + tx;  // destination in the upper triangle
+    if (i < n && j < n && j > i) G[i * ldg + j] = t[tx][r];
+  }
+}
+
+} // namespace vivit
+
+using namespace vivit;
+
+extern "C" {
+
+int vivit_gram_hadamard_f32(const float *Gz, const float *Gs, float *G, int64_t C, int64_t N, float alpha, float beta,
+                            void *stream) {
+  if (C < 0 || N < 0) return VIVIT_E_BADARG;
+  if (C == 0 || N == 0) return VIVIT_OK;
+  if (!Gz || !Gs || !G) return VIVIT_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n = C * N;
+  const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(Gz) | reinterpret_cast<uintptr_t>(Gs) |
+                                     reinterpret_cast<uintptr_t>(G)) & 15) == 0;
+  if (vec)
+    hadamard_kernel<true><<<ew_grid((n * n) >> 2), EW_BLOCK, 0, s>>>(Gz, Gs, G, C, N, alpha, beta);
+  else
+    hadamard_kernel<false><<<ew_grid(n * n), EW_BLOCK, 0, s>>>(Gz, Gs, G, C, N, alpha, beta);
+  return launch_status();
+}
+
+int vivit_dir_curvature_f32(const float *GE, const float *evals, float *lambdas, int64_t C, int64_t N, int64_t K,
+                            float scale, void *stream) {
+  if (C < 0 || N < 0 || K < 0) return VIVIT_E_BADARG;
+  if (N == 0 || K == 0) return VIVIT_OK;
+  if (!GE || !evals || !lambdas) return VIVIT_E_BADARG;
+  dir_curvature_kernel<<<ew_grid(N * K), EW_BLOCK, 0, static_cast<hipStream_t>(stream)>>>(GE, evals, lambdas, C, N, K,
+                                                                                          scale);
+  return launch_status();
+}
+
+int vivit_scale_cols_rsqrt_f32(float *X, const float *evals, int64_t rows, int64_t K, int64_t ldx, float pre,
+                               void *stream) {
+  if (rows < 0 || K < 0 || ldx < K) return VIVIT_E_BADARG;
+  if (rows == 0 || K == 0) return VIVIT_OK;
+  if (!X || !evals) return VIVIT_E_BADARG;
+  scale_cols_rsqrt_kernel<<<ew_grid(rows * K), EW_BLOCK, 0, static_cast<hipStream_t>(stream)>>>(X, evals, rows, K, ldx,
+                                                                                                pre);
+  return launch_status();
+}
+
+// acc[k] += ||X[k, :]||^2 via per-chunk partials in `workspace` (fixed summation order).
+int vivit_row_sqnorm_acc_f32(const float *X, float *acc, int64_t K, int64_t len, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+  if (K < 0 || len < 0) return VIVIT_E_BADARG;
+  if (K == 0 || len == 0) return VIVIT_OK;
+  if (!X || !acc) return VIVIT_E_BADARG;
+  const int nchunk = (int)cdiv(len, SQN_CHUNK);
+  const size_t need = (size_t)K * nchunk * sizeof(float);
+  if (!workspace || workspace_bytes < need) return VIVIT_E_WORKSPACE;
+  if (K > 65535) return VIVIT_E_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float *part = static_cast<float *>(workspace);
+  row_sqnorm_part_kernel<<<dim3((unsigned)nchunk, (unsigned)K), EW_BLOCK, 0, s>>>(X, part, len, nchunk);
+  row_sqnorm_final_kernel<<<(unsigned)cdiv(K, EW_BLOCK), EW_BLOCK, 0, s>>>(part, acc, K, nchunk);
+  return launch_status();
+}
+
+size_t vivit_row_sqnorm_workspace_bytes(int64_t K, int64_t len) {
+  if (K <= 0 || len <= 0) return 0;
+  return (size_t)K * (size_t)cdiv(len, SQN_CHUNK) * sizeof(float);
+}
+
+int vivit_scale_rows_rsqrt_f32(float *X, const float *acc, int64_t K, int64_t len, void *stream) {
+  if (K < 0 || len < 0) return VIVIT_E_BADARG;
+  if (K == 0 || len == 0) return VIVIT_OK;
+  if (!X || !acc) return VIVIT_E_BADARG;
+  scale_rows_rsqrt_kernel<<<ew_grid(K * len), EW_BLOCK, 0, static_cast<hipStream_t>(stream)>>>(X, acc, K, len);
+  return launch_status();
+}
+
+int vivit_symmetrize_lower_f32(float *G, int64_t n, int64_t ldg, void *stream) {
+  if (n < 0 || ldg < n) return VIVIT_E_BADARG;
+  if (n == 0) return VIVIT_OK;
+  if (!G) return VIVIT_E_BADARG;
+  const int64_t nb = cdiv(n, 32);
+  symmetrize_kernel<<<(unsigned)(nb * (nb + 1) / 2), 256, 0, static_cast<hipStream_t>(stream)>>>(G, n, ldg);
+  return launch_status();
+}
+
+} // extern "C"

@@ -1,0 +1,415 @@
+// fp32 MFMA GEMM / SYRK for gfx950 (MI355X).
+//
+//   C[M,N] = alpha * op(A) op(B)^T + beta * C,   exact fp32 (v_mfma_f32_32x32x2_f32 is a
+//   k-ordered fmaf chain), accumulators flushed into a second accumulator every 2048 k so that
+//   long contractions (P up to ~4e5 for the Gram build) keep pairwise-like rounding error.
+//
+// Tile: 128x128x16 per 256-thread workgroup; 4 waves in a 2x2 grid, each wave owns a 64x64
+// block = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs + 64 for the second level).  Operands are
+// register-staged into double-buffered LDS (one barrier per K tile).  fp32 MFMA runs at the
+// vector rate (64 flop/clk/SIMD), so one wave spends 2048 cycles of matrix work per K tile and
+// the 4 global float4 loads + 8 ds_read_b128 per wave per K tile hide completely behind it.
+//
+// blockIdx -> tile mapping is XCD-aware: the grid is cut into 16x16-tile super-blocks; inside a
+// super-block the 8 workgroups that share an XCD (blockIdx % 8, round-robin dispatch) own one
+// compact 8x4-tile sub-block, so the A/B row panels they stream are shared through that XCD's
+// L2 (speed only, never correctness).
+//
+// SYRK mode (the Gram build, K1): B == A, only super-blocks/tiles with tile_i >= tile_j are
+// computed (n(n+1)p flops instead of 2n^2p) and off-diagonal tiles are stored twice, the mirror
+// image transposed through LDS so that both stores are coalesced.
+#include "common.h"
+
+namespace vivit {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int SK = BK + 4;                     // LDS row stride (floats) of a LAY_K tile [128][20]
+constexpr int SM = BM + 4;                     // LDS row stride (floats) of a LAY_M tile [16][132]
+constexpr int TILE_FLOATS = BM * SK;           // 2560 floats (>= 16*132 = 2112)
+constexpr int FLUSH_TILES = 2048 / BK;         // second-level accumulation period
+constexpr int SB = 16;                         // super-block edge in tiles
+
+__device__ __forceinline__ float4 ld4_lay_k(const float *__restrict__ P, int64_t ld, int64_t row,
+                                            int64_t nrows, int64_t k, int64_t kend, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < nrows && k < kend) {
+    const float *q = P + row * ld + k;
+    if (vec && k + 3 < kend) {
+      v = *reinterpret_cast<const float4 *>(q);
+    } else {
+      v.x = q[0];
+      if (k + 1 < kend) v.y = q[1];
+      if (k + 2 < kend) v.z = q[2];
+      if (k + 3 < kend) v.w = q[3];
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ float4 ld4_lay_m(const float *__restrict__ P, int64_t ld, int64_t row,
+                                            int64_t nrows, int64_t k, int64_t kend, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < kend && row < nrows) {
+    const float *q = P + k * ld + row;
+    if (vec && row + 3 < nrows) {
+      v = *reinterpret_cast<const float4 *>(q);
+    } else {
+      v.x = q[0];
+      if (row + 1 < nrows) v.y = q[1];
+      if (row + 2 < nrows) v.z = q[2];
+      if (row + 3 < nrows) v.w = q[3];
+    }
+  }
+  return v;
+}
+
+// Global -> registers for one 128 x 16 operand tile (2 float4 per thread).
+template <int LAY>
+__device__ __forceinline__ void tile_load(const float *__restrict__ P, int64_t ld, int64_t row0,
+                                          int64_t nrows, int64_t k0, int64_t kend, bool vec, int tid,
+                                          float4 (&st)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f = tid + 256 * q;
+    if (LAY == LAY_K) {
+      st[q] = ld4_lay_k(P, ld, row0 + (f >> 2), nrows, k0 + 4 * (f & 3), kend, vec);
+    } else {
+      st[q] = ld4_lay_m(P, ld, row0 + 4 * (f & 31), nrows, k0 + (f >> 5), kend, vec);
+    }
+  }
+}
+
+// Registers -> LDS.
+template <int LAY>
+__device__ __forceinline__ void tile_store(float *__restrict__ s, int tid, const float4 (&st)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int f = tid + 256 * q;
+    if (LAY == LAY_K) {
+      *reinterpret_cast<float4 *>(s + (f >> 2) * SK + 4 * (f & 3)) = st[q];
+    } else {
+      *reinterpret_cast<float4 *>(s + (f >> 5) * SM + 4 * (f & 31)) = st[q];
+    }
+  }
+}
+
+// MFMA operand fragments for the 8 k-pairs of one K tile.  MFMA u = 4q + t (q in 0..1,
+// t in 0..3) consumes k = 8q + 4h + t from lane half h = lane >> 5; both layouts use that same
+// assignment so any A layout pairs with any B layout.
+//   frag[q][t] for rows r0 + (lane & 31).
+template <int LAY>
+__device__ __forceinline__ void frag_load(const float *__restrict__ s, int r, int h, float (&fr)[2][4]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (LAY == LAY_K) {
+      const float4 v = *reinterpret_cast<const float4 *>(s + r * SK + 4 * (2 * q + h));
+      fr[q][0] = v.x; fr[q][1] = v.y; fr[q][2] = v.z; fr[q][3] = v.w;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fr[q][t] = s[(8 * q + 4 * h + t) * SM + r];
+    }
+  }
+}
+
+// blockIdx.x -> (tile_i, tile_j); returns false for padding slots.
+__device__ __forceinline__ bool map_tile(const GemmArgs &p, int &ti, int &tj) {
+  const int sb = blockIdx.x >> 8;
+  const int slot = blockIdx.x & 255;
+  int I, J;
+  if (p.syrk) {
+    I = (int)((sqrtf(8.f * (float)sb + 1.f) - 1.f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= sb) ++I;
+    while (I * (I + 1) / 2 > sb) --I;
+    J = sb - I * (I + 1) / 2;
+  } else {
+    const int sbn = (p.tiles_n + SB - 1) / SB;
+    I = sb / sbn;
+    J = sb - I * sbn;
+  }
+  const int xcd = slot & 7, w = slot >> 3;
+  ti = I * SB + (xcd >> 2) * 8 + (w >> 2);
+  tj = J * SB + (xcd & 3) * 4 + (w & 3);
+  if (ti >= p.tiles_m || tj >= p.tiles_n) return false;
+  if (p.syrk && tj > ti) return false;
+  return true;
+}
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+  int ti, tj;
+  if (!map_tile(p, ti, tj)) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int64_t row0 = (int64_t)ti * BM, col0 = (int64_t)tj * BN;
+  const int64_t kbeg = (int64_t)blockIdx.y * p.kchunk;
+  const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  const int nt = (int)((kend - kbeg + BK - 1) / BK);
+
+#define SA(b) (smem + (b) * TILE_FLOATS)
+#define SB_(b) (smem + (2 + (b)) * TILE_FLOATS)
+
+  f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
+
+  float4 stA[2], stB[2];
+  const bool avec = p.a_vec != 0, bvec = p.b_vec != 0;
+  if (nt > 0) {
+    tile_load<ALAY>(p.A, p.lda, row0, p.M, kbeg, kend, avec, tid, stA);
+    tile_load<BLAY>(p.B, p.ldb, col0, p.N, kbeg, kend, bvec, tid, stB);
+    tile_store<ALAY>(SA(0), tid, stA);
+    tile_store<BLAY>(SB_(0), tid, stB);
+  }
+  __syncthreads();
+
+  int since_flush = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) {
+      const int64_t k0 = kbeg + (int64_t)(t + 1) * BK;
+      tile_load<ALAY>(p.A, p.lda, row0, p.M, k0, kend, avec, tid, stA);
+      tile_load<BLAY>(p.B, p.ldb, col0, p.N, k0, kend, bvec, tid, stB);
+    }
+    float fa[2][2][4], fb[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) frag_load<ALAY>(SA(cur), wm * 64 + i * 32 + r, h, fa[i]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) frag_load<BLAY>(SB_(cur), wn * 64 + j * 32 + r, h, fb[j]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q][tt], fb[j][q][tt], acc[i][j], 0, 0, 0);
+    if (++since_flush == FLUSH_TILES) {
+      since_flush = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+    }
+    if (t + 1 < nt) {
+      tile_store<ALAY>(SA(cur ^ 1), tid, stA);
+      tile_store<BLAY>(SB_(cur ^ 1), tid, stB);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*h.
+  const bool partial = p.ksplit > 1;
+  float *__restrict__ Cout = partial ? p.slab + (int64_t)blockIdx.y * p.M * p.N : p.C;
+  const int64_t ldc = partial ? p.N : p.ldc;
+  const float alpha = partial ? 1.f : p.alpha;
+  const float beta = partial ? 0.f : p.beta;
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = col0 + wn * 64 + j * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < p.M && col < p.N) {
+          float *c = Cout + row * ldc + col;
+          float v = alpha * tot[i][j][e];
+          if (beta != 0.f) v += beta * *c;
+          *c = v;
+        }
+      }
+    }
+
+  if (p.syrk && !partial && ti != tj) {
+    // Mirror image: C[col][row] = same value, transposed through LDS (32x33 floats per wave)
+    // so that the second store is also 128-B coalesced.
+    float *ts = smem + wave * (32 * 33);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ts[r * 33 + (e & 3) + 8 * (e >> 2) + 4 * h] = tot[i][j][e];
+        __syncthreads();
+        const int64_t mrow0 = col0 + wn * 64 + j * 32;  // rows of the mirrored block
+        const int64_t mcol = row0 + wm * 64 + i * 32 + r;
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += 2) {
+          const int64_t mrow = mrow0 + rr + h;
+          if (mrow < p.N && mcol < p.M) {
+            float *c = p.C + mrow * p.ldc + mcol;
+            float v = p.alpha * ts[(rr + h) * 33 + r];
+            if (p.beta != 0.f) v += p.beta * *c;
+            *c = v;
+          }
+        }
+      }
+  }
+}
+
+// C = alpha * sum_z slab[z] + beta * C  (fixed summation order); SYRK slabs hold the lower
+// tiles only, the upper triangle is read from the transposed position.
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ slab, float *__restrict__ C,
+                                                          int64_t M, int64_t N, int64_t ldc, int ksplit,
+                                                          float alpha, float beta, int syrk) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * N) return;
+  const int64_t i = idx / N, j = idx - i * N;
+  int64_t src = idx;
+  if (syrk && (j / BN) > (i / BM)) src = j * N + i;
+  float s = 0.f;
+  for (int z = 0; z < ksplit; ++z) s += slab[(int64_t)z * M * N + src];
+  float v = alpha * s;
+  if (beta != 0.f) v += beta * C[i * ldc + j];
+  C[i * ldc + j] = v;
+}
+
+static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit, int64_t &kchunk) {
+  const int64_t tm = cdiv(M, BM), tn = cdiv(N, BN);
+  const int64_t tiles = syrk ? tm * (tm + 1) / 2 : tm * tn;
+  ksplit = 1;
+  kchunk = cdiv(K, BK) * BK;
+  if (kchunk < BK) kchunk = BK;
+  const int64_t ktiles = cdiv(K, BK);
+  // Fill at least ~2 workgroups per CU when the output has few tiles and K is deep; keep every
+  // split at least 32 K tiles long and the slab modest.
+  if (tiles < 256 && ktiles >= 64) {
+    int64_t want = cdiv(512, tiles);
+    int64_t maxs = ktiles / 32;
+    int64_t s = want < maxs ? want : maxs;
+    if (s > 64) s = 64;
+    while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ((size_t)1 << 30)) --s;
+    if (s > 1) {
+      kchunk = cdiv(ktiles, s) * BK;
+      ksplit = (int)cdiv(K, kchunk);
+    }
+  }
+}
+
+size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int ksplit;
+  int64_t kchunk;
+  choose_split(M, N, K, syrk, ksplit, kchunk);
+  return ksplit > 1 ? (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+__global__ __launch_bounds__(256) void scale_c_kernel(float *__restrict__ C, int64_t M, int64_t N, int64_t ldc, float beta) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * N) return;
+  const int64_t i = idx / N, j = idx - i * N;
+  C[i * ldc + j] = beta == 0.f ? 0.f : beta * C[i * ldc + j];
+}
+
+int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, int64_t M, int64_t N,
+                int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, float beta, bool syrk,
+                void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (M < 0 || N < 0 || K < 0) return VIVIT_E_BADARG;
+  if (M == 0 || N == 0) return VIVIT_OK;
+  if (!C || ldc < N) return VIVIT_E_BADARG;
+  if (K == 0) {  // empty contraction: C = beta * C
+    scale_c_kernel<<<(unsigned)cdiv(M * N, 256), 256, 0, stream>>>(C, M, N, ldc, beta);
+    return launch_status();
+  }
+  if (!A || !B) return VIVIT_E_BADARG;
+  if (lda < (alay == LAY_K ? K : M) || ldb < (blay == LAY_K ? K : N)) return VIVIT_E_BADARG;
+  if (syrk && (M != N || alay != blay)) return VIVIT_E_BADARG;
+
+  GemmArgs p;
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.alpha = alpha; p.beta = beta;
+  choose_split(M, N, K, syrk, p.ksplit, p.kchunk);
+  p.slab = nullptr;
+  if (p.ksplit > 1) {
+    const size_t need = (size_t)p.ksplit * (size_t)M * (size_t)N * sizeof(float);
+    if (!workspace || workspace_bytes < need) return VIVIT_E_WORKSPACE;
+    p.slab = static_cast<float *>(workspace);
+  }
+  p.tiles_m = (int)cdiv(M, BM);
+  p.tiles_n = (int)cdiv(N, BN);
+  p.syrk = syrk ? 1 : 0;
+  p.a_vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+  p.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+
+  const int64_t sbm = cdiv(p.tiles_m, SB), sbn = cdiv(p.tiles_n, SB);
+  const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
+  if (nsb * 256 > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
+  dim3 grid((unsigned)(nsb * 256), (unsigned)p.ksplit, 1);
+  dim3 block(256, 1, 1);
+  if (alay == LAY_K && blay == LAY_K)
+    gemm_kernel<LAY_K, LAY_K><<<grid, block, 0, stream>>>(p);
+  else if (alay == LAY_K && blay == LAY_M)
+    gemm_kernel<LAY_K, LAY_M><<<grid, block, 0, stream>>>(p);
+  else if (alay == LAY_M && blay == LAY_K)
+    gemm_kernel<LAY_M, LAY_K><<<grid, block, 0, stream>>>(p);
+  else
+    gemm_kernel<LAY_M, LAY_M><<<grid, block, 0, stream>>>(p);
+  int st = launch_status();
+  if (st != VIVIT_OK) return st;
+  if (p.ksplit > 1) {
+    gemm_reduce_kernel<<<(unsigned)cdiv(M * N, 256), 256, 0, stream>>>(p.slab, C, M, N, ldc, p.ksplit, alpha,
+                                                                       beta, p.syrk);
+    st = launch_status();
+  }
+  return st;
+}
+
+} // namespace vivit
+
+using namespace vivit;
+
+extern "C" {
+
+size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p) { return gemm_workspace_bytes(n, n, p, true); }
+
+int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float *G, int64_t ldg, float alpha,
+                        float beta, void *workspace, size_t workspace_bytes, void *stream) {
+  return gemm_launch(LAY_K, LAY_K, A, A, G, n, n, p, lda, lda, ldg, alpha, beta, true, workspace, workspace_bytes,
+                     static_cast<hipStream_t>(stream));
+}
+
+size_t vivit_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) { return gemm_workspace_bytes(m, n, k, false); }
+
+int vivit_gemm_nt_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k, int64_t lda,
+                      int64_t ldb, int64_t ldc, float alpha, float beta, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+  return gemm_launch(LAY_K, LAY_K, A, B, C, m, n, k, lda, ldb, ldc, alpha, beta, false, workspace, workspace_bytes,
+                     static_cast<hipStream_t>(stream));
+}
+
+int vivit_gemm_nn_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k, int64_t lda,
+                      int64_t ldb, int64_t ldc, float alpha, float beta, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+  return gemm_launch(LAY_K, LAY_M, A, B, C, m, n, k, lda, ldb, ldc, alpha, beta, false, workspace, workspace_bytes,
+                     static_cast<hipStream_t>(stream));
+}
+
+int vivit_gemm_tn_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k, int64_t lda,
+                      int64_t ldb, int64_t ldc, float alpha, float beta, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+  return gemm_launch(LAY_M, LAY_M, A, B, C, m, n, k, lda, ldb, ldc, alpha, beta, false, workspace, workspace_bytes,
+                     static_cast<hipStream_t>(stream));
+}
+
+} // extern "C"

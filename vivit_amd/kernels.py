@@ -1,0 +1,231 @@
+"""Host-side launchers: torch tensors in, HIP kernels (libvivit_hip.so) out.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens in the hand-written
+gfx950 kernels behind the C ABI of ``include/vivit_hip.h``.  Every function raises
+``RuntimeError`` for tensors that are not fp32 HIP-device tensors: there is deliberately no CPU
+path (tests inject the oracle through :func:`vivit_amd.kernels.set_backend_for_testing`).
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from vivit_amd import _lib
+
+_WORKSPACES = {}
+_TEST_BACKEND = None  # only ever set by tests/ (host-logic tests on CPU)
+
+
+def set_backend_for_testing(backend):
+    """Route the launchers below to ``backend`` (an object with the same function names).
+
+    Test infrastructure only: lets ``-m "not gpu"`` tests exercise the Python hook/scheduling
+    layer on CPU with the oracle standing in for the kernels.  Product code never calls this.
+    """
+    global _TEST_BACKEND
+    _TEST_BACKEND = backend
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "vivit_amd kernels need HIP-device tensors (got a CPU tensor); there is no CPU fallback"
+            )
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"vivit_amd kernels are fp32 only (got {t.dtype})")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _workspace(nbytes: int, like: torch.Tensor):
+    """Stream-ordered scratch buffer (grown on demand, cached per device and stream)."""
+    if nbytes == 0:
+        return None, 0
+    key = (like.device, _stream(like))
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=like.device)
+        _WORKSPACES[key] = buf
+    return buf.data_ptr(), buf.numel()
+
+
+def _as2d(t: torch.Tensor) -> torch.Tensor:
+    if t.dim() != 2:
+        raise ValueError(f"expected a matrix, got {t.dim()} dimensions")
+    if t.numel() > 0 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.numel() > 0 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return max(t.stride(0), t.shape[1], 1) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def gram_syrk(A: torch.Tensor, out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0):
+    """``out = alpha * A @ A.T + beta * out`` for ``A: [n, p]`` (K1, MFMA SYRK)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.gram_syrk(A, out, alpha, beta)
+    _require_device(A, out)
+    A = _as2d(A)
+    n, p = A.shape
+    if out is None:
+        out = torch.empty((n, n), dtype=torch.float32, device=A.device)
+        beta = 0.0
+    lib = _lib.load()
+    ws, wsb = _workspace(lib.vivit_gram_syrk_f32_workspace_bytes(n, p), A)
+    st = lib.vivit_gram_syrk_f32(A.data_ptr(), n, p, _ld(A), out.data_ptr(), _ld(out), alpha, beta, ws, wsb, _stream(A))
+    _lib.check(st, "vivit_gram_syrk_f32")
+    return out
+
+
+def _gemm(name, A, B, m, n, k, out, alpha, beta):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=A.device)
+        beta = 0.0
+    ws, wsb = _workspace(lib.vivit_gemm_f32_workspace_bytes(m, n, k), A)
+    st = getattr(lib, name)(
+        A.data_ptr(), B.data_ptr(), out.data_ptr(), m, n, k, _ld(A), _ld(B), _ld(out), alpha, beta, ws, wsb, _stream(A)
+    )
+    _lib.check(st, name)
+    return out
+
+
+def gemm_nt(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
+    """``out = alpha * A @ B.T + beta * out``; ``A: [m, k]``, ``B: [n, k]`` (K2/K9)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.gemm_nt(A, B, out, alpha, beta)
+    _require_device(A, B, out)
+    A, B = _as2d(A), _as2d(B)
+    if A.shape[1] != B.shape[1]:
+        raise ValueError("Trailing dimensions don't match.")
+    return _gemm("vivit_gemm_nt_f32", A, B, A.shape[0], B.shape[0], A.shape[1], out, alpha, beta)
+
+
+def gemm_nn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
+    """``out = alpha * A @ B + beta * out``; ``A: [m, k]``, ``B: [k, n]`` (K6/K7/K8)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.gemm_nn(A, B, out, alpha, beta)
+    _require_device(A, B, out)
+    A, B = _as2d(A), _as2d(B)
+    if A.shape[1] != B.shape[0]:
+        raise ValueError("Inner dimensions don't match.")
+    return _gemm("vivit_gemm_nn_f32", A, B, A.shape[0], B.shape[1], A.shape[1], out, alpha, beta)
+
+
+def gemm_tn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
+    """``out = alpha * A.T @ B + beta * out``; ``A: [k, m]``, ``B: [k, n]`` (K5)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.gemm_tn(A, B, out, alpha, beta)
+    _require_device(A, B, out)
+    A, B = _as2d(A), _as2d(B)
+    if A.shape[0] != B.shape[0]:
+        raise ValueError("Leading dimensions don't match.")
+    return _gemm("vivit_gemm_tn_f32", A, B, A.shape[1], B.shape[1], A.shape[0], out, alpha, beta)
+
+
+def gram_hadamard(Gz, Gs, C: int, N: int, out=None, alpha: float = 1.0, beta: float = 0.0):
+    """``out[c,n,d,m] = alpha * Gz[n,m] * Gs[c,n,d,m] + beta * out`` (K1')."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.gram_hadamard(Gz, Gs, C, N, out, alpha, beta)
+    _require_device(Gz, Gs, out)
+    Gz, Gs = Gz.contiguous(), Gs.contiguous()
+    if out is None:
+        out = torch.empty((C * N, C * N), dtype=torch.float32, device=Gz.device)
+        beta = 0.0
+    if not out.is_contiguous():
+        raise ValueError("out must be contiguous")
+    st = _lib.load().vivit_gram_hadamard_f32(Gz.data_ptr(), Gs.data_ptr(), out.data_ptr(), C, N, alpha, beta, _stream(Gz))
+    _lib.check(st, "vivit_gram_hadamard_f32")
+    return out
+
+
+def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Eigenvalues (ascending) and, optionally, column eigenvectors of symmetric ``G`` (K3/K4).
+
+    Raises ``RuntimeError`` if the solver reports unconverged eigenvalues (the reference's
+    behaviour for a failing ``Tensor.symeig``, vivit/utils/eig.py:37-40).
+    """
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.symeig(G, eigenvectors)
+    _require_device(G)
+    if G.dim() != 2 or G.shape[0] != G.shape[1]:
+        raise ValueError(f"Input must be a square matrix. Got shape {tuple(G.shape)}.")
+    n = G.shape[0]
+    A = _as2d(G)
+    if A.data_ptr() == G.data_ptr() and not overwrite:
+        A = A.clone()  # the solver destroys its input (reflectors are stored in it)
+    w = torch.empty(n, dtype=torch.float32, device=G.device)
+    Z = torch.empty((n, n), dtype=torch.float32, device=G.device) if eigenvectors else None
+    info = torch.zeros(1, dtype=torch.int32, device=G.device)
+    lib = _lib.load()
+    ws, wsb = _workspace(lib.vivit_symeig_f32_workspace_bytes(n, 1 if eigenvectors else 0), G)
+    st = lib.vivit_symeig_f32(
+        A.data_ptr(), n, _ld(A), w.data_ptr(), Z.data_ptr() if eigenvectors else None, n, ws, wsb, info.data_ptr(), _stream(G)
+    )
+    _lib.check(st, "vivit_symeig_f32")
+    nfail = int(info.item())  # device->host sync; the reference syncs here too (criterion callback)
+    if nfail != 0:
+        raise RuntimeError(f"symeig: {nfail} eigenvalues did not converge")
+    return w, Z
+
+
+def dir_curvature(GE, evals, C: int, N: int, scale: float):
+    """``lambdas[n,k] = scale * sum_c GE[(c,n),k]^2 / evals[k]`` (K6 epilogue)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.dir_curvature(GE, evals, C, N, scale)
+    _require_device(GE, evals)
+    GE, evals = GE.contiguous(), evals.contiguous()
+    K = evals.numel()
+    out = torch.empty((N, K), dtype=torch.float32, device=GE.device)
+    st = _lib.load().vivit_dir_curvature_f32(GE.data_ptr(), evals.data_ptr(), out.data_ptr(), C, N, K, scale, _stream(GE))
+    _lib.check(st, "vivit_dir_curvature_f32")
+    return out
+
+
+def scale_cols_rsqrt_(X, evals, pre: float = 1.0):
+    """In place ``X[:, k] *= pre / sqrt(evals[k])`` (K5 epilogue)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.scale_cols_rsqrt_(X, evals, pre)
+    _require_device(X, evals)
+    if X.stride(1) != 1:
+        raise ValueError("X must have unit column stride")
+    rows, K = X.shape
+    st = _lib.load().vivit_scale_cols_rsqrt_f32(X.data_ptr(), evals.contiguous().data_ptr(), rows, K, _ld(X), pre, _stream(X))
+    _lib.check(st, "vivit_scale_cols_rsqrt_f32")
+    return X
+
+
+def normalize_rows_(tensors):
+    """Normalise ``K`` stacked vectors given in parameter-list format, in place (K10).
+
+    ``tensors``: list of ``[K, *param.shape]`` contiguous tensors; afterwards, for each ``k``,
+    ``sum_t ||tensors[t][k]||^2 == 1``.  Replaces vivit/linalg/utils.py:67-76.
+    """
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.normalize_rows_(tensors)
+    if len(tensors) == 0:
+        return tensors
+    _require_device(*tensors)
+    K = tensors[0].shape[0]
+    lib = _lib.load()
+    acc = torch.zeros(K, dtype=torch.float32, device=tensors[0].device)
+    flat = []
+    for t in tensors:
+        if not t.is_contiguous():
+            raise ValueError("normalize_rows_ needs contiguous tensors")
+        length = t.numel() // max(K, 1)
+        flat.append((t, length))
+        ws, wsb = _workspace(lib.vivit_row_sqnorm_workspace_bytes(K, length), t)
+        st = lib.vivit_row_sqnorm_acc_f32(t.data_ptr(), acc.data_ptr(), K, length, ws, wsb, _stream(t))
+        _lib.check(st, "vivit_row_sqnorm_acc_f32")
+    for t, length in flat:
+        st = lib.vivit_scale_rows_rsqrt_f32(t.data_ptr(), acc.data_ptr(), K, length, _stream(t))
+        _lib.check(st, "vivit_scale_rows_rsqrt_f32")
+    return tensors

@@ -1,0 +1,110 @@
+"""Shared test helpers: golden-vector loading, fake BackPACK modules, an oracle-backed kernel
+backend for host-logic tests on CPU (TEST INFRASTRUCTURE -- the product never imports this)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CASES = ["mlp_small", "conv_like", "subsampled", "mc1", "wide"]
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, f"{name}.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def golden_factors(gold, device="cpu"):
+    V, G = [], []
+    i = 0
+    while f"V{i}" in gold:
+        V.append(torch.from_numpy(gold[f"V{i}"]).to(device))
+        G.append(torch.from_numpy(gold[f"g{i}"]).to(device))
+        i += 1
+    return V, G
+
+
+class FakeModule(torch.nn.Module):
+    """Leaf module holding parameters + the ``input0`` BackPACK stores (vivit/linalg/utils.py:54)."""
+
+    def __init__(self, params, batch_size):
+        super().__init__()
+        for i, p in enumerate(params):
+            self.register_parameter(f"p{i}", p)
+        self.input0 = torch.zeros(batch_size, 1)
+
+
+def top_k_criterion(k, must_exceed=1e-5):
+    """Rule of the reference tests' make_criterion (test/optim/settings.py:21-47)."""
+
+    def criterion(evals):
+        n = len(evals)
+        shift = max(n - k, 0)
+        return [i + shift for i, ev in enumerate(evals[shift:]) if ev > must_exceed]
+
+    return criterion
+
+
+def keep_all(evals):
+    return list(range(evals.numel()))
+
+
+def constant_damping(d):
+    def damping(evals, evecs, gammas, lambdas):
+        return d * torch.ones_like(evals)
+
+    return damping
+
+
+class OracleBackend:
+    """Same function names as ``vivit_amd.kernels``, computed with torch on CPU (oracle ops).
+    Injected with ``kernels.set_backend_for_testing`` to test the Python hook layer without a GPU."""
+
+    @staticmethod
+    def _acc(res, out, alpha, beta):
+        res = alpha * res
+        if out is None:
+            return res
+        out.copy_(res + beta * out if beta != 0.0 else res)
+        return out
+
+    def gram_syrk(self, A, out=None, alpha=1.0, beta=0.0):
+        return self._acc(A @ A.T, out, alpha, beta)
+
+    def gemm_nt(self, A, B, out=None, alpha=1.0, beta=0.0):
+        return self._acc(A @ B.T, out, alpha, beta)
+
+    def gemm_nn(self, A, B, out=None, alpha=1.0, beta=0.0):
+        return self._acc(A @ B, out, alpha, beta)
+
+    def gemm_tn(self, A, B, out=None, alpha=1.0, beta=0.0):
+        return self._acc(A.T @ B, out, alpha, beta)
+
+    def gram_hadamard(self, Gz, Gs, C, N, out=None, alpha=1.0, beta=0.0):
+        res = (Gz.view(1, N, 1, N) * Gs.view(C, N, C, N)).reshape(C * N, C * N)
+        return self._acc(res, out, alpha, beta)
+
+    def symeig(self, G, eigenvectors=False, overwrite=False):
+        from oracle import vivit_oracle as oracle
+
+        w, Z = oracle.tensor_symeig(G, eigenvectors=eigenvectors, upper=False)
+        return w, (Z if eigenvectors else None)
+
+    def dir_curvature(self, GE, evals, C, N, scale):
+        K = evals.numel()
+        return scale * (GE.view(C, N, K) ** 2).sum(0) / evals
+
+    def scale_cols_rsqrt_(self, X, evals, pre=1.0):
+        X.mul_(pre / evals.sqrt())
+        return X
+
+    def normalize_rows_(self, tensors):
+        K = tensors[0].shape[0]
+        sq = sum((t.reshape(K, -1) ** 2).sum(1) for t in tensors)
+        for t in tensors:
+            t.mul_((1 / sq.sqrt()).view(K, *([1] * (t.dim() - 1))))
+        return tensors

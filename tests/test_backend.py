@@ -1,0 +1,222 @@
+"""The stand-in BackPACK backend (factor provider) against the brute-force autograd oracle, and
+the Computation classes end to end through ``with backpack(...)`` -- the reference's own test
+method (differential testing against autograd), host and hip flavours."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import vivit_amd
+from helpers import OracleBackend, constant_damping, keep_all, top_k_criterion
+from oracle import vivit_oracle as oracle
+from vivit_amd import kernels
+from vivit_amd.backend import BatchGrad, SqrtGGNExact, SqrtGGNMC, ViViTGGNExact, backpack, extend
+
+FLAVOURS = [pytest.param("host", id="host"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=FLAVOURS)
+def device(request):
+    if request.param == "host":
+        kernels.set_backend_for_testing(OracleBackend())
+        yield torch.device("cpu")
+        kernels.set_backend_for_testing(None)
+    else:
+        kernels.set_backend_for_testing(None)
+        yield torch.device("cuda:0")
+
+
+def make_problem(name):
+    torch.manual_seed(0)
+    if name == "mlp_ce":  # test/settings.py:30-40 analogue
+        model = nn.Sequential(nn.Linear(7, 6), nn.ReLU(), nn.Linear(6, 5))
+        X, y, lossf, loss = torch.rand(3, 7), torch.randint(0, 5, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "mlp_mse":
+        model = nn.Sequential(nn.Linear(7, 6), nn.Sigmoid(), nn.Linear(6, 5))
+        X, y, lossf, loss = torch.rand(3, 7), torch.rand(3, 5), nn.MSELoss(), "mse"
+    elif name == "cnn_ce":  # test/settings.py:42-55 analogue
+        model = nn.Sequential(
+            nn.Conv2d(3, 2, 2), nn.MaxPool2d(3, stride=2), nn.Flatten(), nn.Tanh(), nn.Linear(18, 4)
+        )
+        X, y, lossf, loss = torch.rand(4, 3, 8, 8), torch.randint(0, 4, (4,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "bn_ce":  # test/settings.py:118-155 analogue (BatchNorm in eval mode)
+        bn = nn.BatchNorm1d(6)
+        bn.running_mean.uniform_(-0.5, 0.5)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.uniform_(-0.5, 0.5)
+        model = nn.Sequential(nn.Linear(7, 6), bn, nn.ReLU(), nn.Linear(6, 3)).eval()
+        X, y, lossf, loss = torch.rand(5, 7), torch.randint(0, 3, (5,)), nn.CrossEntropyLoss(), "ce"
+    return model, X, y, lossf, loss
+
+
+PROBLEMS = ["mlp_ce", "mlp_mse", "cnn_ce", "bn_ce"]
+
+
+def run_backward(model, X, y, lossf, extensions, hook=None):
+    model, lossf = extend(model), extend(lossf)
+    model.zero_grad()
+    loss = lossf(model(X), y)
+    with backpack(*extensions, extension_hook=hook):
+        loss.backward()
+    return loss
+
+
+def close(a, b, rtol=1e-4, atol=1e-6):
+    np.testing.assert_allclose(a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("subsampling", [None, [1, 0], [0, 0, 1, 0, 1]], ids=["full", "sub", "repeated"])
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_sqrt_ggn_and_batch_grad_factors(problem, subsampling, device):
+    model, X, y, lossf, loss = make_problem(problem)
+    ref_model, _, _, ref_lossf, _ = make_problem(problem)
+    S = oracle.loss_hessian_sqrt_exact(ref_model(X).detach(), loss)
+    V_ref = oracle.sqrt_ggn_factors(ref_model, X, S, subsampling)
+    g_ref = oracle.batch_grads(ref_model, X, y, ref_lossf, subsampling)
+
+    model, X, y = model.to(device), X.to(device), y.to(device)
+    run_backward(model, X, y, lossf, [SqrtGGNExact(subsampling=subsampling), BatchGrad(subsampling=subsampling)])
+    for p, v, g in zip(model.parameters(), V_ref, g_ref):
+        close(p.sqrt_ggn_exact, v, rtol=1e-4, atol=1e-6)
+        close(p.grad_batch, g, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_mc_factors_with_supplied_samples(problem, device):
+    model, X, y, lossf, loss = make_problem(problem)
+    if loss != "ce":
+        pytest.skip("MC factor oracle is stated for cross-entropy")
+    ref_model = make_problem(problem)[0]
+    out = ref_model(X).detach()
+    N, C = out.shape
+    gen = torch.Generator().manual_seed(1)
+    idx = torch.multinomial(out.softmax(1), 3, replacement=True, generator=gen)  # [N, M]
+    onehots = torch.nn.functional.one_hot(idx.t(), C).float()
+    V_ref = oracle.sqrt_ggn_factors(ref_model, X, oracle.loss_hessian_sqrt_mc(out, onehots))
+    model, X, y = model.to(device), X.to(device), y.to(device)
+    run_backward(model, X, y, lossf, [SqrtGGNMC(mc_samples=3, samples=onehots)])
+    for p, v in zip(model.parameters(), V_ref):
+        close(p.sqrt_ggn_mc, v, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_vivit_closures(problem, device):
+    """V V^T v == G v, Gram closure == Gram of the materialised factor
+    (test/extensions/secondorder/vivit/test_vivit_ggn.py:22-52)."""
+    model, X, y, lossf, loss = make_problem(problem)
+    ref_model = make_problem(problem)[0]
+    ggn = oracle.dense_ggn(ref_model.double(), X.double(), loss)
+    model, X, y = model.to(device), X.to(device), y.to(device)
+    run_backward(model, X, y, lossf, [ViViTGGNExact(), SqrtGGNExact()])
+    params = list(model.parameters())
+    gen = torch.Generator().manual_seed(3)
+    vecs = [torch.randn(2, *p.shape, generator=gen).to(device) for p in params]
+    # V^T v summed over params, then V applied
+    Vt_v = sum(p.vivit_ggn_exact["V_t_mat_prod"](v) for p, v in zip(params, vecs))  # [2, C, N]
+    VVt_v = [p.vivit_ggn_exact["V_mat_prod"](Vt_v) for p in params]
+    flat_v = torch.cat([v.flatten(1) for v in vecs], 1).cpu().double()
+    ref = flat_v @ ggn
+    got = torch.cat([r.flatten(1) for r in VVt_v], 1)
+    close(got, ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item())
+    for p in params:
+        close(p.vivit_ggn_exact["gram_mat"](), oracle.pairwise_dot(p.sqrt_ggn_exact.cpu(), 2, False), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("groups_kind", ["one", "weights_and_biases"])
+@pytest.mark.parametrize("subsampling", [None, [1, 0]], ids=["full", "sub"])
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_eigvalsh_and_eigh_end_to_end(problem, subsampling, groups_kind, device):
+    """Gram eigenvalues == dense-GGN eigenvalues on the top min(n, P); G e = lambda e; orthonormal
+    (test/linalg/test_eigvalsh.py:27-63, test/linalg/test_eigh.py:28-155)."""
+    model, X, y, lossf, loss = make_problem(problem)
+    ref_model = make_problem(problem)[0].double()
+    Xs = X if subsampling is None else X[subsampling]
+    named = list(ref_model.named_parameters())
+    model, X, y = model.to(device), X.to(device), y.to(device)
+    params = list(model.parameters())
+    if groups_kind == "one":
+        index_groups = [list(range(len(params)))]
+    else:
+        index_groups = [[i for i, (n, _) in enumerate(named) if "bias" in n],
+                        [i for i, (n, _) in enumerate(named) if "bias" not in n]]
+
+    # dense GGN blocks on the (sub-sampled) batch; mean over the sub-sample (eigvalsh.py:217-219)
+    ggn = oracle.dense_ggn(ref_model, Xs.double(), loss)
+    sizes = [p.numel() for _, p in named]
+    offs = np.cumsum([0] + sizes)
+
+    def block(idx):
+        sel = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in idx])
+        return ggn[sel][:, sel]
+
+    comp = vivit_amd.EigvalshComputation(subsampling=subsampling)
+    groups = [{"params": [params[i] for i in idx]} for idx in index_groups]
+    run_backward(model, X, y, lossf, [comp.get_extension()], comp.get_extension_hook(groups))
+    for idx, grp in zip(index_groups, groups):
+        ref_w = torch.linalg.eigvalsh(block(idx))
+        w = comp.get_result(grp).cpu().double()
+        k = min(len(w), len(ref_w))
+        np.testing.assert_allclose(w[-k:].numpy(), ref_w[-k:].numpy(), rtol=1e-4, atol=5e-6)
+
+    comp = vivit_amd.EighComputation(subsampling=subsampling, warn_small_eigvals=0.0)
+    crit = lambda evals: [i for i in range(evals.numel()) if evals[i].abs() >= 1e-4]  # keep_nonzero
+    groups = [{"params": [params[i] for i in idx], "criterion": crit} for idx in index_groups]
+    run_backward(model, X, y, lossf, [comp.get_extension()], comp.get_extension_hook(groups))
+    for idx, grp in zip(index_groups, groups):
+        evals, evecs = comp.get_result(grp)
+        E = torch.cat([e.flatten(1) for e in evecs], 1).cpu().double()  # [K, P_block]
+        B = block(idx)
+        np.testing.assert_allclose((E @ E.T).numpy(), np.eye(E.shape[0]), atol=2e-4)  # 1e-3/2e-4
+        np.testing.assert_allclose((E @ B).numpy(), (evals.cpu().double()[:, None] * E).numpy(), rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("mc", [0, 1])
+@pytest.mark.parametrize("sub_ggn", [None, [0, 1]], ids=["ggn_full", "ggn_sub"])
+@pytest.mark.parametrize("sub_grad", [None, [0, 1]], ids=["grad_full", "grad_sub"])
+@pytest.mark.parametrize("problem", ["mlp_ce", "cnn_ce"])
+def test_damped_newton_end_to_end(problem, sub_grad, sub_ggn, mc, device):
+    """Newton step == oracle restatement on autograd factors
+    (test/optim/test_directional_damped_newton.py:33-74; rtol/atol 1e-5 there, fp32 here)."""
+    model, X, y, lossf, loss = make_problem(problem)
+    ref_model, _, _, ref_lossf, _ = make_problem(problem)
+    out = ref_model(X).detach()
+    N, C = out.shape
+    samples = None
+    if mc:
+        gen = torch.Generator().manual_seed(5)
+        idx = torch.multinomial(out.softmax(1), 1, replacement=True, generator=gen)
+        samples = torch.nn.functional.one_hot(idx.t(), C).float()
+        S = oracle.loss_hessian_sqrt_mc(out, samples)
+    else:
+        S = oracle.loss_hessian_sqrt_exact(out, loss)
+    V_ref = oracle.sqrt_ggn_factors(ref_model, X, S, sub_ggn)
+    g_ref = oracle.batch_grads(ref_model, X, y, ref_lossf, sub_grad)
+    crit = top_k_criterion(3, must_exceed=1e-4)
+    ref_steps = oracle.damped_newton_group(V_ref, g_ref, crit, constant_damping(1.0), N)
+    ref_gam, ref_lam = oracle.directional_derivatives_group(V_ref, g_ref, crit, N)
+
+    model, X, y = model.to(device), X.to(device), y.to(device)
+    comp = vivit_amd.DirectionalDampedNewtonComputation(
+        subsampling_grad=sub_grad, subsampling_ggn=sub_ggn, mc_samples_ggn=mc, warn_small_eigvals=0.0
+    )
+    exts = comp.get_extensions()
+    if mc:
+        exts[1]._samples = samples  # identical MC samples (parity needs them)
+    groups = [{"params": list(model.parameters()), "criterion": crit, "damping": constant_damping(1.0)}]
+    run_backward(model, X, y, lossf, exts, comp.get_extension_hook(groups))
+    for s, r in zip(comp.get_result(groups[0]), ref_steps):
+        close(s, r, rtol=1e-3, atol=2e-5 * max(r.abs().max().item(), 1e-2))
+
+    comp = vivit_amd.DirectionalDerivativesComputation(
+        subsampling_grad=sub_grad, subsampling_ggn=sub_ggn, mc_samples_ggn=mc, warn_small_eigvals=0.0
+    )
+    exts = comp.get_extensions()
+    if mc:
+        exts[1]._samples = samples
+    groups = [{"params": list(model.parameters()), "criterion": crit}]
+    run_backward(model, X, y, lossf, exts, comp.get_extension_hook(groups))
+    gam, lam = comp.get_result(groups[0])
+    close(gam.abs(), ref_gam.abs(), rtol=1e-3, atol=1e-4 * ref_gam.abs().max().item())
+    close(lam, ref_lam, rtol=1e-3, atol=1e-5 * ref_lam.abs().max().item())
+    # lambdas.mean(0) == evals (docs/examples/basic_usage/example_directional_derivatives.py:192-199)

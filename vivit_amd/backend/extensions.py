@@ -1,0 +1,274 @@
+"""Extensions of the stand-in backend: BatchGrad, SqrtGGN{Exact,MC}, ViViTGGN{Exact,MC}.
+
+Data contract (identical to BackPACK's):
+  ``param.grad_batch``       [N_grad, *param.shape]      carries 1/N for ``reduction='mean'``
+  ``param.sqrt_ggn_exact``   [C, N_ggn, *param.shape]    carries 1/sqrt(N)
+  ``param.sqrt_ggn_mc``      [M, N_ggn, *param.shape]    carries 1/sqrt(M N)
+  ``param.vivit_ggn_exact|mc``  dict with closures ``gram_mat() -> [C,N,C,N]``,
+      ``V_mat_prod(mat[F,C,N]) -> [F,*param]``, ``V_t_mat_prod(mat[F,*param]) -> [F,C,N]``
+      (vivit/extensions/secondorder/vivit/base.py:126-130); Linear weights keep the factorised
+      form ``s=[C,N,out], z=[N,in]`` (vivit/extensions/secondorder/vivit/linear.py:41-81).
+"""
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from vivit_amd import kernels
+from vivit_amd.utils.ggn import Vmp
+from vivit_amd.utils.gram import mVp, pairwise_dot
+
+_LOSSES = (nn.CrossEntropyLoss, nn.MSELoss)
+_BATCHNORM = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
+
+
+def subsample(tensor: Tensor, dim: int = 0, subsampling: Optional[List[int]] = None) -> Tensor:
+    """``backpack.utils.subsampling.subsample`` (used at linear.py:42)."""
+    if subsampling is None:
+        return tensor
+    idx = torch.as_tensor(subsampling, device=tensor.device, dtype=torch.long)
+    return tensor.index_select(dim, idx)
+
+
+class _Extension:
+    savefield = None
+
+    def __init__(self, subsampling: Optional[List[int]] = None):
+        self._subsampling = subsampling
+
+    def get_subsampling(self):
+        return self._subsampling
+
+    def apply(self, ctx, module, g_out):
+        raise NotImplementedError
+
+
+def _own_params(module):
+    return [(name, p) for name, p in module._parameters.items() if p is not None and p.requires_grad]
+
+
+def _spatial_sum(t: Tensor, keep: int) -> Tensor:
+    """Sum all dims after the first ``keep`` ones."""
+    return t.flatten(start_dim=keep).sum(keep) if t.dim() > keep else t
+
+
+def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
+    """``param_mjp(..., sum_batch=False)``: ``M`` [V, N, *out] -> [V, N, *param.shape]."""
+    if isinstance(module, nn.Linear):
+        if name == "bias":
+            return M if M.dim() == 3 else M.flatten(2, -2).sum(2)
+        if M.dim() == 3:
+            return torch.einsum("vno,ni->vnoi", M, x)
+        return torch.einsum("vnao,nai->vnoi", M.flatten(2, -2), x.flatten(1, -2))
+    if isinstance(module, nn.Conv2d):
+        if name == "bias":
+            return M.flatten(3).sum(3)
+        if module.groups != 1:
+            raise NotImplementedError("grouped convolutions are not supported by the stand-in backend")
+        xu = F.unfold(x, module.kernel_size, dilation=module.dilation, padding=module.padding, stride=module.stride)
+        out = torch.einsum("vnol,nkl->vnok", M.flatten(3), xu)
+        return out.reshape(*M.shape[:2], *module.weight.shape)
+    if isinstance(module, _BATCHNORM):
+        if module.training:
+            raise NotImplementedError("BatchNorm must be in eval mode (as in the reference tests)")
+        if name == "bias":
+            return _spatial_sum(M, 3)
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        xhat = (x - module.running_mean.view(shape)) / torch.sqrt(module.running_var.view(shape) + module.eps)
+        return _spatial_sum(M * xhat.unsqueeze(0), 3)
+    raise NotImplementedError(f"no parameter rule for {type(module).__name__}")
+
+
+def _jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Tensor:
+    """Apply the transposed input-Jacobian of ``module`` to ``M`` [V, N, *out] -> [V, N, *in]."""
+    if isinstance(module, nn.Linear) and M.dim() == 3:
+        V, N, O = M.shape
+        if M.is_cuda:
+            return kernels.gemm_nn(M.reshape(V * N, O), module.weight.detach()).view(V, N, -1)
+        return M @ module.weight.detach()
+    if isinstance(module, nn.Dropout) and module.training and module.p > 0:
+        raise NotImplementedError("Dropout must be in eval mode")
+    if isinstance(module, _BATCHNORM) and module.training:
+        raise NotImplementedError("BatchNorm must be in eval mode")
+    # generic rule: batched vector-Jacobian product through a recomputed forward (bypasses hooks)
+    with torch.enable_grad():
+        xi = x.detach().requires_grad_(True)
+        y = module.forward(xi)
+        (g,) = torch.autograd.grad(y, xi, grad_outputs=M.reshape(M.shape[0], *y.shape), is_grads_batched=True)
+    return g
+
+
+# ---------------------------------------------------------------------------------------------
+class BatchGrad(_Extension):
+    """Per-sample gradients of the mini-batch loss (BackPACK ``BatchGrad``)."""
+
+    savefield = "grad_batch"
+
+    def apply(self, ctx, module, g_out):
+        params = _own_params(module)
+        if not params or isinstance(module, _LOSSES):
+            return
+        sub = self.get_subsampling()
+        g = subsample(g_out.detach(), 0, sub).unsqueeze(0)  # [1, N, *out]
+        x = subsample(module.input0.detach(), 0, sub)
+        for name, p in params:
+            setattr(p, self.savefield, _param_factor(module, name, g, x)[0])
+
+
+# ---------------------------------------------------------------------------------------------
+def _loss_hessian_sqrt(module, strategy: str, mc_samples: int, samples: Optional[Tensor]) -> Tensor:
+    """Symmetric factor S [V, N, C] of the loss Hessian w.r.t. the model output."""
+    out = module.input0.detach()
+    if out.dim() != 2:
+        raise NotImplementedError("loss input must be [N, C]")
+    N, C = out.shape
+    red = module.reduction
+    if red not in ("mean", "sum"):
+        raise NotImplementedError(f"reduction={red}")
+    if isinstance(module, nn.CrossEntropyLoss):
+        p = out.softmax(dim=1)
+        norm = N if red == "mean" else 1
+        if strategy == "exact":
+            sq = p.sqrt()
+            # H_n = diag(p_n) - p_n p_n^T = sum_v S[v,n,:] S[v,n,:]^T,  S[v,n,c] = sqrt(p_nv)(delta_vc - p_nc)
+            S = torch.einsum("nv,vc->vnc", sq, torch.eye(C, dtype=out.dtype, device=out.device)) - torch.einsum(
+                "nv,nc->vnc", sq, p
+            )
+            return S / math.sqrt(norm)
+        if samples is None:
+            idx = torch.multinomial(p, mc_samples, replacement=True)  # [N, M]
+            samples = F.one_hot(idx.t(), C).to(out.dtype)  # [M, N, C]
+        return (p.unsqueeze(0) - samples.to(out.device, out.dtype)) / math.sqrt(samples.shape[0] * norm)
+    if isinstance(module, nn.MSELoss):
+        norm = N * C if red == "mean" else 1
+        if strategy == "exact":
+            S = torch.eye(C, dtype=out.dtype, device=out.device).unsqueeze(1).expand(C, N, C)
+            return S * math.sqrt(2.0 / norm)
+        if samples is None:
+            samples = torch.randn(mc_samples, N, C, dtype=out.dtype, device=out.device)
+        return samples.to(out.device, out.dtype) * math.sqrt(2.0 / (samples.shape[0] * norm))
+    raise NotImplementedError(type(module).__name__)
+
+
+class _SqrtGGN(_Extension):
+    strategy = "exact"
+
+    def __init__(self, subsampling=None, mc_samples: int = 1, samples: Optional[Tensor] = None):
+        super().__init__(subsampling)
+        self._mc_samples = mc_samples
+        self._samples = samples  # externally supplied MC one-hots [M, N, C] (parity needs them)
+
+    def get_num_mc_samples(self) -> int:
+        return self._mc_samples
+
+    def _store(self, module, name, param, M, x):
+        setattr(param, self.savefield, _param_factor(module, name, M, x))
+
+    def apply(self, ctx, module, g_out):
+        sub = self.get_subsampling()
+        if isinstance(module, _LOSSES):
+            S = _loss_hessian_sqrt(module, self.strategy, self._mc_samples, self._samples)
+            ctx.put(self, module.input0, subsample(S, 1, sub))
+            return
+        M = ctx.pop(self, module.output)
+        if M is None:
+            return
+        x = subsample(module.input0.detach(), 0, sub)
+        for name, p in _own_params(module):
+            self._store(module, name, p, M, x)
+        if module.input0.requires_grad:
+            ctx.put(self, module.input0, _jac_t_mat_prod(module, M, x))
+
+
+class SqrtGGNExact(_SqrtGGN):
+    """Materialised ``V_t`` with the exact loss Hessian (BackPACK ``SqrtGGNExact``)."""
+
+    savefield = "sqrt_ggn_exact"
+    strategy = "exact"
+
+    def __init__(self, subsampling=None):
+        super().__init__(subsampling)
+
+
+class SqrtGGNMC(_SqrtGGN):
+    """Materialised ``V_t`` with an MC-sampled loss Hessian (BackPACK ``SqrtGGNMC``)."""
+
+    savefield = "sqrt_ggn_mc"
+    strategy = "sampling"
+
+    def __init__(self, mc_samples: int = 1, subsampling=None, samples: Optional[Tensor] = None):
+        super().__init__(subsampling, mc_samples, samples)
+
+
+# ---------------------------------------------------------------------------------------------
+def _materialised_closures(V_t: Tensor):
+    """Closures over a materialised ``V_t`` (vivit/extensions/secondorder/vivit/base.py:96-130)."""
+
+    def gram_mat(out=None, beta=0.0):
+        return pairwise_dot(V_t, start_dim=2, flatten=False, out=out, beta=beta)
+
+    return {
+        "V_mat_prod": lambda mat: Vmp(V_t, mat, 2),
+        "V_t_mat_prod": lambda mat: mVp(V_t, mat, 2),
+        "gram_mat": gram_mat,
+    }
+
+
+def _linear_weight_closures(s: Tensor, z: Tensor):
+    """Factorised closures for a Linear weight: ``V_t[c,n,o,i] = s[c,n,o] z[n,i]`` never exists.
+
+    vivit/extensions/secondorder/vivit/linear.py:44-75.  Gram: two small SYRKs plus the fused
+    Hadamard kernel (K1'); products: one tall GEMM with ``z`` plus a length-C contraction.
+    """
+    C, N, O = s.shape
+    s = s.contiguous()
+    z = z.contiguous()
+
+    def gram_mat(out=None, beta=0.0):
+        Gz = kernels.gram_syrk(z)                      # [N, N]
+        Gs = kernels.gram_syrk(s.reshape(C * N, O))    # [CN, CN]
+        out2d = None if out is None else out.view(C * N, C * N)
+        G = kernels.gram_hadamard(Gz, Gs, C, N, out=out2d, alpha=1.0, beta=beta)
+        return G.view(C, N, C, N)
+
+    def V_mat_prod(mat):  # [F, C, N] -> [F, O, I]     "cno,vcn,ni->voi"
+        Fdim = mat.shape[0]
+        T = torch.einsum("vcn,cno->von", mat, s).reshape(Fdim * O, N)
+        return kernels.gemm_nn(T, z).view(Fdim, O, z.shape[1])
+
+    def V_t_mat_prod(mat):  # [F, O, I] -> [F, C, N]   "cno,voi,ni->vcn"
+        Fdim = mat.shape[0]
+        U = kernels.gemm_nt(mat.reshape(Fdim * O, -1), z).view(Fdim, O, N)
+        return torch.einsum("cno,von->vcn", s, U)
+
+    return {"V_mat_prod": V_mat_prod, "V_t_mat_prod": V_t_mat_prod, "gram_mat": gram_mat}
+
+
+class _ViViTGGN(_SqrtGGN):
+    """Functional access to ``V``, ``V^T`` and the Gram matrix
+    (vivit/extensions/secondorder/vivit/__init__.py:63-133)."""
+
+    def _store(self, module, name, param, M, x):
+        if isinstance(module, nn.Linear) and name == "weight" and M.dim() == 3:
+            closures = _linear_weight_closures(M, x)
+        else:
+            closures = _materialised_closures(_param_factor(module, name, M, x))
+        setattr(param, self.savefield, closures)
+
+
+class ViViTGGNExact(_ViViTGGN):
+    savefield = "vivit_ggn_exact"
+    strategy = "exact"
+
+    def __init__(self, subsampling=None):
+        super().__init__(subsampling)
+
+
+class ViViTGGNMC(_ViViTGGN):
+    savefield = "vivit_ggn_mc"
+    strategy = "sampling"
+
+    def __init__(self, mc_samples: int = 1, subsampling=None, samples: Optional[Tensor] = None):
+        super().__init__(subsampling, mc_samples, samples)

@@ -47,8 +47,17 @@ __device__ __forceinline__ float block_max(float v, float *red, int tid) {
 
 // Implicit-shift QL on a private (d, e) copy; all lanes of the calling wave run it in lockstep.
 // z: this lane's row of Z (nullptr = no vectors).  Returns the number of unconverged values.
+//
+// Deflation test: |e[m]| <= eps * (|d[m]| + |d[m+1]|)  OR  |e[m]| <= eps/2 * ||T||.  The second
+// (EISPACK tql2-style, norm-relative) clause is what makes rank-deficient Gram matrices converge:
+// their null-space block is rounding noise of size eps * ||G|| on which a purely relative test
+// can stagnate in fp32, while the Householder stage has already committed a backward error of
+// that size, so nothing is lost.
 __device__ int ql_implicit(float *d, float *e, int n, float *z) {
   int nfail = 0;
+  float tn = 0.f;
+  for (int i = 0; i < n; ++i) tn = fmaxf(tn, fabsf(d[i]) + (i + 1 < n ? fabsf(e[i]) : 0.f));
+  const float abs_tol = 0.5f * EPS32 * tn;
   for (int l = 0; l < n; ++l) {
     int iter = 0;
     while (true) {
@@ -56,7 +65,7 @@ __device__ int ql_implicit(float *d, float *e, int n, float *z) {
       for (; m < n - 1; ++m) {
         const float dd = fabsf(d[m]) + fabsf(d[m + 1]);
         const float ae = fabsf(e[m]);
-        if (ae <= EPS32 * dd || ae < 1e-37f) break;
+        if (ae <= EPS32 * dd || ae <= abs_tol) break;
       }
       if (m == l) break;
       if (iter++ >= 60) { ++nfail; break; }

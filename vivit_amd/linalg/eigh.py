@@ -1,0 +1,134 @@
+"""GGN eigenpairs during backpropagation (API of ``vivit.linalg.eigh``)."""
+from typing import Any, Callable, Dict, List, Tuple
+from warnings import warn
+
+from torch import Tensor
+from torch.nn import Module, Parameter
+
+from vivit_amd import kernels
+from vivit_amd.linalg.utils import get_closures, get_hook_store_batch_size, get_vivit_extension, normalize
+from vivit_amd.utils import delete_savefield
+from vivit_amd.utils.checks import check_key_exists, check_subsampling_unique, check_unique_params
+from vivit_amd.utils.gram import reshape_as_square
+from vivit_amd.utils.hooks import ParameterGroupsHook
+
+
+class EighComputation:
+    """Provide the extension and the extension hook that compute GGN eigenpairs.
+
+    Same surface as vivit/linalg/eigh.py:21-292: groups need ``'params'`` and ``'criterion'``
+    (``Callable[[Tensor], List[int]]`` on the ascending eigenvalues); the result is
+    ``(evals[K], [Tensor[K, *p.shape] for p in group['params']])`` with unit-norm eigenvectors.
+    """
+
+    def __init__(
+        self,
+        subsampling: List[int] = None,
+        mc_samples: int = 0,
+        verbose: bool = False,
+        warn_small_eigvals: float = 1e-4,
+    ):
+        check_subsampling_unique(subsampling)
+        self._subsampling = subsampling
+        self._mc_samples = mc_samples
+        self._verbose = verbose
+        self._savefield = self.get_extension().savefield
+        self._warn_small_eigvals = warn_small_eigvals
+        self._batch_size: Dict[int, int] = {}
+        self._evals: Dict[int, Tensor] = {}
+        self._evecs: Dict[int, List[Tensor]] = {}
+
+    def get_result(self, group: Dict) -> Tuple[Tensor, List[Tensor]]:
+        """``(evals, evecs)`` of the group's GGN block; KeyError if unavailable."""
+        try:
+            return self._evals[id(group)], self._evecs[id(group)]
+        except KeyError as e:
+            raise KeyError("No results available for this group") from e
+
+    def get_extension(self):
+        return get_vivit_extension(self._subsampling, self._mc_samples)
+
+    def get_extension_hook(self, param_groups: List[Dict]) -> Callable[[Module], None]:
+        self._check_param_groups(param_groups)
+        store_batch_size = get_hook_store_batch_size(param_groups, self._batch_size, verbose=self._verbose)
+        hook = ParameterGroupsHook.from_functions(
+            param_groups, self.get_param_computation(), self.get_group_hook(), self.get_accumulate()
+        )
+
+        def extension_hook(module: Module):
+            if self._verbose:
+                print(f"Extension hook on module {id(module)} {module}")
+            store_batch_size(module)
+            hook(module)
+
+        if self._verbose:
+            print("ID map groups → params")
+            for group in param_groups:
+                print(f"{id(group)} → {[id(p) for p in group['params']]}")
+        return extension_hook
+
+    def get_param_computation(self) -> Callable[[ParameterGroupsHook, Parameter], None]:
+        def param_computation(self: ParameterGroupsHook, param: Parameter):
+            """Nothing per parameter: the closures must stay alive until the group is complete."""
+            return None
+
+        return param_computation
+
+    def get_accumulate(self) -> Callable[[ParameterGroupsHook, None, None], None]:
+        def accumulate(self: ParameterGroupsHook, existing: None, update: None) -> None:
+            return None
+
+        return accumulate
+
+    def get_group_hook(self) -> Callable[[ParameterGroupsHook, None, Dict[str, Any]], None]:
+        batch_sizes, subsampling, savefield = self._batch_size, self._subsampling, self._savefield
+        evals, evecs, verbose = self._evals, self._evecs, self._verbose
+        warn_small_eigvals = self._warn_small_eigvals
+
+        def group_hook(self: ParameterGroupsHook, accumulation: None, group: Dict[str, Any]) -> None:
+            group_id = id(group)
+            if verbose:
+                print(f"Group {group_id}: Delete 'batch_size'")
+            batch_size = batch_sizes.pop(group_id)
+
+            # Gram matrix, accumulated over the group's parameters inside the kernel (eigh.py:239-242)
+            gram_mat = None
+            for param in group["params"]:
+                gram_fn = get_closures(param, savefield)["gram_mat"]
+                gram_mat = gram_fn() if gram_mat is None else gram_fn(out=gram_mat, beta=1.0)
+            C, N = gram_mat.shape[:2]
+
+            gram_evals, gram_evecs = kernels.symeig(reshape_as_square(gram_mat), eigenvectors=True, overwrite=True)
+            if subsampling is not None:  # eigh.py:245-246; eigenvectors are scale invariant
+                gram_evals *= batch_size / len(subsampling)
+
+            keep = group["criterion"](gram_evals)
+            gram_evals, gram_evecs = gram_evals[keep], gram_evecs[:, keep]
+
+            if (gram_evals.abs() < warn_small_eigvals).any():
+                warn(
+                    "Some eigenvectors have small eigenvalues."
+                    + " Their parameter space transformation is numerically unstable."
+                    + " This can spoil orthogonality of eigenvectors."
+                    + " Maybe use a more restrictive eigenvalue filter criterion."
+                )
+
+            # eigenvectors selectable via the first axis: [K, C, N] (eigh.py:265)
+            gram_evecs = gram_evecs.transpose(0, 1).reshape(-1, C, N)
+
+            group_evecs = []
+            for param in group["params"]:
+                group_evecs.append(get_closures(param, savefield)["V_mat_prod"](gram_evecs))
+                delete_savefield(param, savefield, verbose=verbose)
+            normalize(group_evecs)
+
+            evals[group_id] = gram_evals
+            evecs[group_id] = group_evecs
+
+        return group_hook
+
+    @staticmethod
+    def _check_param_groups(param_groups: List[Dict]):
+        check_key_exists(param_groups, "params")
+        check_key_exists(param_groups, "criterion")
+        check_unique_params(param_groups)

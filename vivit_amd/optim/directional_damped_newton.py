@@ -1,0 +1,136 @@
+"""Directionally damped Newton steps from the low-rank GGN (API of
+``vivit.optim.directional_damped_newton``, vivit/optim/directional_damped_newton.py:24-419)."""
+from typing import Callable, Dict, List, Optional, Tuple
+
+from torch import Tensor
+from torch.nn import Module
+
+from vivit_amd import kernels
+from vivit_amd.linalg.utils import get_hook_store_batch_size
+from vivit_amd.optim.directional_derivatives import (
+    accumulate_dot_products,
+    dot_products,
+    gram_space_directions,
+)
+from vivit_amd.optim.utils import get_batch_grad_extension, get_sqrt_ggn_extension
+from vivit_amd.utils import delete_savefield
+from vivit_amd.utils.checks import check_key_exists, check_subsampling_unique, check_unique_params
+from vivit_amd.utils.hooks import ParameterGroupsHook
+
+_SMALL_EVALS_NEWTON = (
+    "Some eigenvalues are small. This can lead to numerical instabilities"
+    + " in the directional gradients and the transformation into parameter"
+    + " space because they require division by the eigenvalue square root."
+    + " Maybe use a more restrictive eigenvalue filter criterion."
+)
+
+
+class DirectionalDampedNewtonComputation:
+    r"""Provide extensions and the hook for directionally damped Newton steps
+
+    .. math:: s = \sum_{k=1}^K \frac{-\gamma_k}{\lambda_k + \delta_k} e_k
+
+    along the GGN eigenvectors :math:`e_k` selected by the group's ``'criterion'``, with
+    directional damping :math:`\delta_k` from the group's ``'damping'`` callback
+    ``(evals[K], evecs[n,K], gammas[N,K], lambdas[N,K]) -> [K]``.  ``get_result(group)`` returns
+    the step in the format of ``group['params']``.  The loss must use ``reduction='mean'``.
+    """
+
+    def __init__(
+        self,
+        subsampling_grad: Optional[List[int]] = None,
+        subsampling_ggn: Optional[List[int]] = None,
+        mc_samples_ggn: Optional[int] = 0,
+        verbose: Optional[bool] = False,
+        warn_small_eigvals: float = 1e-4,
+    ):
+        check_subsampling_unique(subsampling_grad)
+        check_subsampling_unique(subsampling_ggn)
+        self._mc_samples_ggn = mc_samples_ggn
+        if self._mc_samples_ggn != 0:
+            assert mc_samples_ggn == 1
+        self._subsampling_grad = subsampling_grad
+        self._subsampling_ggn = subsampling_ggn
+        self._savefield_grad = get_batch_grad_extension(None).savefield
+        self._savefield_ggn = get_sqrt_ggn_extension(None, mc_samples_ggn).savefield
+        self._verbose = verbose
+        self._warn_small_eigvals = warn_small_eigvals
+        self._batch_size: Dict[int, int] = {}
+        self._newton_steps: Dict[int, Tuple[Tensor]] = {}
+
+    def get_result(self, group: Dict) -> Tuple[Tensor]:
+        try:
+            return self._newton_steps[id(group)]
+        except KeyError as e:
+            raise KeyError("No results available for this group") from e
+
+    def get_extensions(self) -> List:
+        return [
+            get_batch_grad_extension(self._subsampling_grad),
+            get_sqrt_ggn_extension(subsampling=self._subsampling_ggn, mc_samples=self._mc_samples_ggn),
+        ]
+
+    def get_extension_hook(self, param_groups: List[Dict]) -> Callable[[Module], None]:
+        self._check_param_groups(param_groups)
+        store_batch_size = get_hook_store_batch_size(param_groups, self._batch_size, verbose=self._verbose)
+        hook = ParameterGroupsHook.from_functions(
+            param_groups,
+            lambda hook, param: self._param_computation(
+                hook, param, self._savefield_ggn, self._savefield_grad, self._verbose
+            ),
+            lambda hook, accumulation, group: self._group_hook(
+                hook, accumulation, group, self._batch_size, self._savefield_ggn, self._newton_steps,
+                self._verbose, self._warn_small_eigvals,
+            ),
+            lambda hook, existing, update: accumulate_dot_products(existing, update, self._verbose),
+        )
+
+        def extension_hook(module: Module):
+            if self._verbose:
+                print(f"Extension hook on module {id(module)} {module}")
+            store_batch_size(module)
+            hook(module)
+
+        if self._verbose:
+            print("ID map groups → params")
+            for group in param_groups:
+                print(f"{id(group)} → {[id(p) for p in group['params']]}")
+        return extension_hook
+
+    @staticmethod
+    def _param_computation(hook, param, savefield_ggn, savefield_grad, verbose):
+        result = dot_products(hook, param, savefield_ggn, savefield_grad, verbose)
+        # V is kept for the back-projection of the step (directional_damped_newton.py:258)
+        delete_savefield(param, savefield_grad, verbose=verbose)
+        return result
+
+    @staticmethod
+    def _group_hook(hook, accumulation, group, batch_size, savefield_ggn, newton_steps, verbose,
+                    warn_small_eigvals):
+        N = batch_size.pop(id(group))
+        evals, evecs, gammas, lambdas, V_correction, C, N_ggn = gram_space_directions(
+            accumulation, group, N, verbose, warn_small_eigvals, _SMALL_EVALS_NEWTON
+        )
+        # coefficients along the directions (directional_damped_newton.py:353-359): O(K) glue
+        damping = group["damping"]
+        coefficients = (
+            -gammas.mean(0) / (lambdas.mean(0) + damping(evals, evecs, gammas, lambdas)) / evals.sqrt()
+        )
+        # weight in Gram space (:362-366), then apply V (K7, :370-373): step_p = v^T V_p
+        v = kernels.gemm_nn(evecs, coefficients.reshape(-1, 1).contiguous(), alpha=V_correction)  # [n, 1]
+        v_row = v.reshape(1, C * N_ggn)
+        params = group["params"]
+        steps = []
+        for param in params:
+            V = getattr(param, savefield_ggn).detach()
+            steps.append(kernels.gemm_nn(v_row, V.reshape(C * N_ggn, -1)).view(param.shape))
+        for param in params:
+            delete_savefield(param, savefield_ggn, verbose=verbose)
+        newton_steps[id(group)] = steps
+
+    @staticmethod
+    def _check_param_groups(param_groups: List[Dict]):
+        check_key_exists(param_groups, "params")
+        check_key_exists(param_groups, "criterion")
+        check_key_exists(param_groups, "damping")
+        check_unique_params(param_groups)

@@ -110,6 +110,14 @@ size_t vivit_symeig_f32_workspace_bytes(int64_t n, int want_vectors);
 int vivit_symeig_f32(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz,
                      void *workspace, size_t workspace_bytes, int32_t *info, void *stream);
 
+/* Stage 1 of vivit_symeig_f32, exported for testing: Householder tridiagonalisation
+ * A = Q T Q^T (lower triangle read).  d: [n], e: [n-1], tau: [n]; on return row j of A's upper
+ * triangle, A[j][j+1:], holds reflector v_j (v_j[j+1] = 1), Q = H_0 ... H_{n-3},
+ * H_j = I - tau[j] v_j v_j^T.  n >= 3. */
+size_t vivit_sytrd_f32_workspace_bytes(int64_t n);
+int vivit_sytrd_f32(float *A, int64_t n, int64_t lda, float *d, float *e, float *tau,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 /* Eigen-decomposition of a symmetric TRIDIAGONAL matrix (d: [n] diagonal, e: [n-1]
  * off-diagonal; both destroyed).  Stage 2 of vivit_symeig_f32, exported for testing. */
 size_t vivit_stedc_f32_workspace_bytes(int64_t n, int want_vectors);

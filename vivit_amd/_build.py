@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvivit_hip.so")
-SOURCES = ["gemm_f32.hip", "symeig_small.hip", "symeig_large.hip", "elementwise.hip", "api.hip"]
+SOURCES = ["gemm_f32.hip", "symeig_small.hip", "sytrd.hip", "stedc.hip", "symeig_large.hip", "elementwise.hip", "api.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,7 +24,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     """Compile every HIP source to an object, link the shared library. Returns the library path."""
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "vivit_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "device_utils.h", "eig_internal.h")] + [
+        os.path.join(HERE, "..", "include", "vivit_hip.h")]
     objdir = os.path.join(CSRC, "obj")
     os.makedirs(objdir, exist_ok=True)
     objs = []

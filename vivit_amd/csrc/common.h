@@ -23,6 +23,16 @@ static inline int launch_status() {
 //   LAY_M: X[k * ld + row]   (row contiguous)
 enum { LAY_K = 0, LAY_M = 1 };
 
+// Per-problem descriptor for the batched mode: lives in DEVICE memory and is written by
+// device-side planning kernels (sizes such as the number of non-deflated eigenvalues of a
+// divide-and-conquer merge are only known on the device), so batched launches need no host sync.
+struct GemmDesc {
+  const float *A;
+  const float *B;
+  float *C;
+  int64_t M, N, K, lda, ldb, ldc;
+};
+
 struct GemmArgs {
   const float *A;
   const float *B;
@@ -33,8 +43,9 @@ struct GemmArgs {
   int64_t kchunk;   // K range per split (multiple of the K tile)
   float *slab;      // [ksplit][M][N]
   int tiles_m, tiles_n;
-  int syrk;         // 1: B == A, lower-triangular tiles only, mirrored store
+  int syrk;         // 1: lower-triangular tiles only + mirrored store; 2: lower tiles, no mirror
   int a_vec, b_vec; // 16-byte loads legal for the operand
+  const GemmDesc *desc;  // non-null: batched mode, problem blockIdx.z is desc[blockIdx.z]
 };
 
 // Generic launcher (gemm_f32.hip).  alay/blay in {LAY_K, LAY_M}.
@@ -42,5 +53,14 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
                 int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, float beta, bool syrk,
                 void *workspace, size_t workspace_bytes, hipStream_t stream);
 size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk);
+// SYR2K-style update: C(lower tiles) = alpha * A B^T + beta * C with A, B in LAY_M ([k][row]);
+// the result must be symmetric (A B^T + B A^T form); the strict upper triangle outside the
+// diagonal tiles is NOT touched.
+int gemm_lower_launch(const float *A, const float *B, float *C, int64_t n, int64_t K, int64_t lda, int64_t ldb,
+                      int64_t ldc, float alpha, float beta, hipStream_t stream);
+// Batched C_b = alpha * op(A_b) op(B_b)^T + beta * C_b over `batch` device-resident descriptors;
+// the grid is sized for (maxM, maxN), problems may be smaller (or empty).
+int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int64_t maxM, int64_t maxN, float alpha,
+                        float beta, hipStream_t stream);
 
 } // namespace vivit

@@ -1,0 +1,38 @@
+// Internal interfaces between the eigensolver translation units (host-side launch wrappers only:
+// kernels are launched from the file that defines them).
+#pragma once
+#include "common.h"
+
+namespace vivit {
+
+struct SytrdWs {
+  float *vw;        // [3*PB][n]: V (PB rows) | W (PB rows) | V again  (so [V;W] and [W;V] are both contiguous)
+  float *xbuf;      // [n]
+  float *rowpart;   // [nct][n]
+  float *colpart;   // [nrt][n]
+  float *dotpart;   // [nct][2*PB]
+  float *cvw;       // [2*PB]   c_v = V^T v | c_w = W^T v
+  float *ssqpart;   // [nwg]
+  float *wdotpart;  // [nwg]
+  float *scal;      // [16]  0: alpha  1: sigma  2: bad-input flag  3: amax
+  float *d, *e, *tau;
+};
+
+// sytrd.hip
+size_t sytrd_workspace_floats(int64_t n);
+int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, hipStream_t stream);
+
+// stedc.hip
+size_t stedc_workspace_bytes(int64_t n, bool vectors);
+int stedc_dc_launch(const float *d, const float *e, int64_t n, void *wsbase, float **Qt_out, float **d_out,
+                    int **order_scratch, int32_t *info, hipStream_t stream);
+// w[m] = m-th smallest eigenvalue of (d, e) by bisection, divided by scal[1] when scal != nullptr
+int stebz_launch(const float *d, const float *e, int64_t n, float *w, const float *scal, hipStream_t stream);
+// w = sorted(dcur) / sigma;  Z[i][p] = Qt[order[p]][i];  info = n if the input was non-finite
+int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *w, float *Z,
+                     int64_t ldz, const float *scal, int32_t *info, hipStream_t stream);
+
+// info = n when the scan flagged non-finite input (scal[2] != 0)
+int info_finalize_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream);
+
+} // namespace vivit

@@ -112,33 +112,43 @@ __device__ __forceinline__ void frag_load(const float *__restrict__ s, int r, in
 }
 
 // blockIdx.x -> (tile_i, tile_j); returns false for padding slots.
-__device__ __forceinline__ bool map_tile(const GemmArgs &p, int &ti, int &tj) {
+__device__ __forceinline__ bool map_tile(int syrk, int tiles_m, int tiles_n, int &ti, int &tj) {
   const int sb = blockIdx.x >> 8;
   const int slot = blockIdx.x & 255;
   int I, J;
-  if (p.syrk) {
+  if (syrk) {
     I = (int)((sqrtf(8.f * (float)sb + 1.f) - 1.f) * 0.5f);
     while ((I + 1) * (I + 2) / 2 <= sb) ++I;
     while (I * (I + 1) / 2 > sb) --I;
     J = sb - I * (I + 1) / 2;
   } else {
-    const int sbn = (p.tiles_n + SB - 1) / SB;
+    const int sbn = (tiles_n + SB - 1) / SB;
     I = sb / sbn;
     J = sb - I * sbn;
   }
   const int xcd = slot & 7, w = slot >> 3;
   ti = I * SB + (xcd >> 2) * 8 + (w >> 2);
   tj = J * SB + (xcd & 3) * 4 + (w & 3);
-  if (ti >= p.tiles_m || tj >= p.tiles_n) return false;
-  if (p.syrk && tj > ti) return false;
+  if (ti >= tiles_m || tj >= tiles_n) return false;
+  if (syrk && tj > ti) return false;
   return true;
 }
 
 template <int ALAY, int BLAY>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+  if (p.desc) {  // batched mode: this problem's pointers and sizes come from device memory
+    const GemmDesc ds = p.desc[blockIdx.z];
+    p.A = ds.A; p.B = ds.B; p.C = ds.C;
+    p.M = ds.M; p.N = ds.N; p.K = ds.K; p.lda = ds.lda; p.ldb = ds.ldb; p.ldc = ds.ldc;
+    p.tiles_m = (int)((ds.M + BM - 1) / BM);
+    p.tiles_n = (int)((ds.N + BN - 1) / BN);
+    p.kchunk = ((ds.K + BK - 1) / BK) * BK;
+    p.a_vec = ((reinterpret_cast<uintptr_t>(ds.A) & 15) == 0 && (ds.lda & 3) == 0) ? 1 : 0;
+    p.b_vec = ((reinterpret_cast<uintptr_t>(ds.B) & 15) == 0 && (ds.ldb & 3) == 0) ? 1 : 0;
+  }
   int ti, tj;
-  if (!map_tile(p, ti, tj)) return;
+  if (!map_tile(p.syrk, p.tiles_m, p.tiles_n, ti, tj)) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
       }
     }
 
-  if (p.syrk && !partial && ti != tj) {
+  if (p.syrk == 1 && !partial && ti != tj) {
     // Mirror image: C[col][row] = same value, transposed through LDS (32x33 floats per wave)
     // so that the second store is also 128-B coalesced.
     float *ts = smem + wave * (32 * 33);
@@ -351,6 +361,7 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
   p.syrk = syrk ? 1 : 0;
   p.a_vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   p.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  p.desc = nullptr;
 
   const int64_t sbm = cdiv(p.tiles_m, SB), sbn = cdiv(p.tiles_n, SB);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
@@ -373,6 +384,58 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
     st = launch_status();
   }
   return st;
+}
+
+int gemm_lower_launch(const float *A, const float *B, float *C, int64_t n, int64_t K, int64_t lda, int64_t ldb,
+                      int64_t ldc, float alpha, float beta, hipStream_t stream) {
+  if (n <= 0) return VIVIT_OK;
+  if (!A || !B || !C || K <= 0 || lda < n || ldb < n || ldc < n) return VIVIT_E_BADARG;
+  GemmArgs p;
+  p.A = A; p.B = B; p.C = C;
+  p.M = n; p.N = n; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.alpha = alpha; p.beta = beta;
+  p.ksplit = 1;
+  p.kchunk = cdiv(K, BK) * BK;
+  p.slab = nullptr;
+  p.tiles_m = p.tiles_n = (int)cdiv(n, BM);
+  p.syrk = 2;
+  p.a_vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+  p.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  p.desc = nullptr;
+  const int64_t sbm = cdiv(p.tiles_m, SB);
+  const int64_t nsb = sbm * (sbm + 1) / 2;
+  gemm_kernel<LAY_M, LAY_M><<<dim3((unsigned)(nsb * 256), 1, 1), 256, 0, stream>>>(p);
+  return launch_status();
+}
+
+int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int64_t maxM, int64_t maxN, float alpha,
+                        float beta, hipStream_t stream) {
+  if (batch <= 0 || maxM <= 0 || maxN <= 0) return VIVIT_OK;
+  if (!desc) return VIVIT_E_BADARG;
+  GemmArgs p;
+  p.A = nullptr; p.B = nullptr; p.C = nullptr;
+  p.M = maxM; p.N = maxN; p.K = 0; p.lda = p.ldb = p.ldc = 0;
+  p.alpha = alpha; p.beta = beta;
+  p.ksplit = 1;
+  p.kchunk = BK;
+  p.slab = nullptr;
+  p.tiles_m = (int)cdiv(maxM, BM);
+  p.tiles_n = (int)cdiv(maxN, BN);
+  p.syrk = 0;
+  p.a_vec = p.b_vec = 0;
+  p.desc = desc;
+  const int64_t nsb = cdiv(p.tiles_m, SB) * cdiv(p.tiles_n, SB);
+  if (nsb * 256 > 0x7fffffffLL || batch > 65535) return VIVIT_E_UNSUPPORTED;
+  dim3 grid((unsigned)(nsb * 256), 1, (unsigned)batch);
+  if (alay == LAY_K && blay == LAY_K)
+    gemm_kernel<LAY_K, LAY_K><<<grid, 256, 0, stream>>>(p);
+  else if (alay == LAY_K && blay == LAY_M)
+    gemm_kernel<LAY_K, LAY_M><<<grid, 256, 0, stream>>>(p);
+  else if (alay == LAY_M && blay == LAY_K)
+    gemm_kernel<LAY_M, LAY_K><<<grid, 256, 0, stream>>>(p);
+  else
+    gemm_kernel<LAY_M, LAY_M><<<grid, 256, 0, stream>>>(p);
+  return launch_status();
 }
 
 } // namespace vivit

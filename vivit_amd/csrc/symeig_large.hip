@@ -1,12 +1,165 @@
-// placeholder: multi-kernel eigensolver (filled in next)
+// Multi-kernel symmetric eigensolver for n > SMALL_N_MAX:
+//   sytrd.hip  blocked Householder tridiagonalisation          (HBM-bound symv + MFMA rank-2k)
+//   stedc.hip  tridiagonal eigenproblem                         (bisection | divide & conquer)
+//   here       Householder back-transformation  Z = Q_H Q_T     (compact-WY blocks, MFMA GEMMs)
+//
+// Eigenvectors are carried transposed (row = eigenvector) until the very end: the D&C produces
+// Qt = Q_T^T, the back-transformation applies the block reflectors from the right,
+//   Zt <- Zt (I - Y T Y^T)^T = Zt - ((Zt Y) T^T) Y^T,
+// three GEMMs per block of KB reflectors whose rows Y^T are exactly the rows sytrd left in the
+// upper triangle of A, and a final permuted transpose delivers Tensor.symeig's column layout.
 #include "common.h"
+#include "device_utils.h"
+#include "eig_internal.h"
+
 namespace vivit {
-size_t symeig_large_workspace_bytes(int64_t n, bool vectors) { return 0; }
+
+constexpr int KB = 128;  // reflectors per compact-WY block
+
+// Yt[t][i] = v_{a+t}[i] (zero for i <= a+t and for reflector indices beyond n-3)
+__global__ __launch_bounds__(256) void bt_extract_kernel(const float *__restrict__ A, int64_t lda, int n, int a,
+                                                         float *__restrict__ Yt) {
+  const int t = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int j = a + t;
+  float v = 0.f;
+  if (j <= n - 3 && i > j) v = A[(int64_t)j * lda + i];
+  Yt[(int64_t)t * n + i] = v;
+}
+
+// T (upper triangular, forward/columnwise larft) from S = Y^T Y and tau
+__global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict__ S, const float *__restrict__ tau, int n,
+                                                        int a, float *__restrict__ T) {
+  __shared__ float Ts[KB][KB + 1];
+  __shared__ float col[KB];
+  const int r = threadIdx.x;
+  for (int c = 0; c < KB; ++c) Ts[r][c] = 0.f;
+  __syncthreads();
+  for (int i = 0; i < KB; ++i) {
+    const int j = a + i;
+    const float ti = (j <= n - 3) ? tau[j] : 0.f;
+    // col[r] = -tau_i * sum_{c=r}^{i-1} T[r][c] S[c][i]   for r < i
+    float acc = 0.f;
+    if (r < i)
+      for (int c = r; c < i; ++c) acc += Ts[r][c] * S[c * KB + i];
+    col[r] = -ti * acc;
+    __syncthreads();
+    if (r < i) Ts[r][i] = col[r];
+    if (r == i) Ts[i][i] = ti;
+    __syncthreads();
+  }
+  for (int c = 0; c < KB; ++c) T[r * KB + c] = Ts[r][c];
+}
+
+static size_t bt_workspace_bytes(int64_t n) {
+  size_t b = 0;
+  b += align_up(sizeof(float) * KB * n, 256);      // Yt
+  b += align_up(sizeof(float) * n * KB, 256) * 2;  // W1, W2
+  b += align_up(sizeof(float) * KB * KB, 256) * 2; // S, T
+  b += align_up(gemm_workspace_bytes(KB, KB, n, false), 256);
+  b += align_up(gemm_workspace_bytes(n, KB, n, false), 256);
+  return b + 512;
+}
+
+size_t symeig_large_workspace_bytes(int64_t n, bool vectors) {
+  size_t b = align_up(sizeof(float) * sytrd_workspace_floats(n), 256) + 512;
+  b += stedc_workspace_bytes(n, vectors);
+  if (vectors) b += bt_workspace_bytes(n);
+  return b;
+}
+
 int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *ws, size_t ws_bytes,
-                        int32_t *info, hipStream_t stream) { return VIVIT_E_UNSUPPORTED; }
+                        int32_t *info, hipStream_t stream) {
+  const bool vectors = Z != nullptr;
+  if (n > 0x7fffffffLL / 8) return VIVIT_E_UNSUPPORTED;
+  if (!ws || ws_bytes < symeig_large_workspace_bytes(n, vectors)) return VIVIT_E_WORKSPACE;
+  if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return VIVIT_E_LAUNCH;
+  char *p = reinterpret_cast<char *>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+  auto take = [&](size_t bytes) {
+    char *r = p;
+    p += align_up(bytes, 256);
+    return r;
+  };
+  const int ni = (int)n;
+
+  // ---- stage 1: A = Q_H T Q_H^T
+  SytrdWs tw;
+  float *trd_base = (float *)take(sizeof(float) * sytrd_workspace_floats(n));
+  int st = sytrd_launch(A, n, lda, trd_base, &tw, stream);
+  if (st != VIVIT_OK) return st;
+
+  if (!vectors) {
+    // ---- stage 2 (values only): bisection, undo the scaling
+    st = stebz_launch(tw.d, tw.e, n, w, tw.scal, stream);
+    if (st != VIVIT_OK) return st;
+    return info_finalize_launch(info, n, tw.scal, stream);
+  }
+
+  // ---- stage 2: T = Q_T diag(w) Q_T^T by divide and conquer (Qt = Q_T^T, rows unsorted)
+  void *dc_base = take(stedc_workspace_bytes(n, true));
+  float *Qt, *dd;
+  int *order;
+  st = stedc_dc_launch(tw.d, tw.e, n, dc_base, &Qt, &dd, &order, info, stream);
+  if (st != VIVIT_OK) return st;
+
+  // ---- stage 3: Zt = Qt * Q_H^T, blocks of KB reflectors, last block first
+  float *Yt = (float *)take(sizeof(float) * KB * n);
+  float *W1 = (float *)take(sizeof(float) * n * KB);
+  float *W2 = (float *)take(sizeof(float) * n * KB);
+  float *S = (float *)take(sizeof(float) * KB * KB);
+  float *T = (float *)take(sizeof(float) * KB * KB);
+  const size_t gws1_bytes = gemm_workspace_bytes(KB, KB, n, false);
+  void *gws1 = take(gws1_bytes);
+  const size_t gws2_bytes = gemm_workspace_bytes(n, KB, n, false);
+  void *gws2 = take(gws2_bytes);
+  const int64_t nrefl = n - 2;  // reflectors 0 .. n-3
+  for (int64_t a = ((nrefl - 1) / KB) * KB; a >= 0; a -= KB) {
+    bt_extract_kernel<<<dim3((unsigned)cdiv(n, 256), KB), 256, 0, stream>>>(A, lda, ni, (int)a, Yt);
+    st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KB, KB, n, n, n, KB, 1.f, 0.f, false, gws1, gws1_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    bt_tfactor_kernel<<<1, KB, 0, stream>>>(S, tw.tau, ni, (int)a, T);
+    const int64_t m = n - a;  // components a+1 .. n-1 carry the block's reflectors (column a of Yt is zero:
+                              // starting at the 128-aligned offset a keeps the operands 16-byte aligned)
+    // W1[n x KB] = Zt[:, a:] * Yt[:, a:]^T
+    st = gemm_launch(LAY_K, LAY_K, Qt + a, Yt + a, W1, n, KB, m, n, n, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // W2 = W1 * T^T
+    st = gemm_launch(LAY_K, LAY_K, W1, T, W2, n, KB, KB, KB, KB, KB, 1.f, 0.f, false, nullptr, 0, stream);
+    if (st != VIVIT_OK) return st;
+    // Zt[:, a:] -= W2 * Yt[:, a:]
+    st = gemm_launch(LAY_K, LAY_M, W2, Yt + a, Qt + a, n, m, KB, KB, n, n, -1.f, 1.f, false, nullptr, 0, stream);
+    if (st != VIVIT_OK) return st;
+  }
+
+  // ---- sort ascending, undo the scaling, deliver column eigenvectors
+  return dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, tw.scal, info, stream);
 }
+
+} // namespace vivit
+
+using namespace vivit;
+
 extern "C" {
-size_t vivit_stedc_f32_workspace_bytes(int64_t n, int want_vectors) { return 0; }
-int vivit_stedc_f32(float *d, float *e, int64_t n, float *w, float *Z, int64_t ldz, void *workspace,
-                    size_t workspace_bytes, int32_t *info, void *stream) { return VIVIT_E_UNSUPPORTED; }
+
+size_t vivit_sytrd_f32_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  return align_up(sizeof(float) * sytrd_workspace_floats(n), 256) + 512;
 }
+
+int vivit_sytrd_f32(float *A, int64_t n, int64_t lda, float *d, float *e, float *tau, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+  if (n < 3 || !A || !d || !e || !tau || lda < n) return VIVIT_E_BADARG;
+  if (!workspace || workspace_bytes < vivit_sytrd_f32_workspace_bytes(n)) return VIVIT_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float *base = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  SytrdWs tw;
+  int st = sytrd_launch(A, n, lda, base, &tw, s);
+  if (st != VIVIT_OK) return st;
+  if (hipMemcpyAsync(d, tw.d, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return VIVIT_E_LAUNCH;
+  if (hipMemcpyAsync(e, tw.e, sizeof(float) * (n - 1), hipMemcpyDeviceToDevice, s) != hipSuccess) return VIVIT_E_LAUNCH;
+  if (hipMemcpyAsync(tau, tw.tau, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return VIVIT_E_LAUNCH;
+  return VIVIT_OK;
+}
+
+} // extern "C"

@@ -15,95 +15,9 @@
 // (vivit/linalg/eigvalsh.py:221, vivit/linalg/eigh.py:248-250) and serves as the accuracy anchor
 // for the multi-kernel path (symeig_large.hip).
 #include "common.h"
+#include "device_utils.h"
 
 namespace vivit {
-
-constexpr int SMALL_N_MAX = 192;
-constexpr float EPS32 = 5.9604645e-8f;  // 2^-24
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-// Sum over the 256 threads, fixed order; red needs 4 floats. Every thread must call.
-__device__ __forceinline__ float block_sum(float v, float *red, int tid) {
-  v = wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-__device__ __forceinline__ float block_max(float v, float *red, int tid) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  __syncthreads();
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-
-// Implicit-shift QL on a private (d, e) copy; all lanes of the calling wave run it in lockstep.
-// z: this lane's row of Z (nullptr = no vectors).  Returns the number of unconverged values.
-//
-// Deflation test: |e[m]| <= eps * (|d[m]| + |d[m+1]|)  OR  |e[m]| <= eps/2 * ||T||.  The second
-// (EISPACK tql2-style, norm-relative) clause is what makes rank-deficient Gram matrices converge:
-// their null-space block is rounding noise of size eps * ||G|| on which a purely relative test
-// can stagnate in fp32, while the Householder stage has already committed a backward error of
-// that size, so nothing is lost.
-__device__ int ql_implicit(float *d, float *e, int n, float *z) {
-  int nfail = 0;
-  float tn = 0.f;
-  for (int i = 0; i < n; ++i) tn = fmaxf(tn, fabsf(d[i]) + (i + 1 < n ? fabsf(e[i]) : 0.f));
-  const float abs_tol = 0.5f * EPS32 * tn;
-  for (int l = 0; l < n; ++l) {
-    int iter = 0;
-    while (true) {
-      int m = l;
-      for (; m < n - 1; ++m) {
-        const float dd = fabsf(d[m]) + fabsf(d[m + 1]);
-        const float ae = fabsf(e[m]);
-        if (ae <= EPS32 * dd || ae <= abs_tol) break;
-      }
-      if (m == l) break;
-      if (iter++ >= 60) { ++nfail; break; }
-      float g = (d[l + 1] - d[l]) / (2.f * e[l]);
-      float r = sqrtf(g * g + 1.f);
-      g = d[m] - d[l] + e[l] / (g + copysignf(r, g));
-      float s = 1.f, c = 1.f, p = 0.f;
-      int i;
-      for (i = m - 1; i >= l; --i) {
-        const float f = s * e[i], b = c * e[i];
-        r = sqrtf(f * f + g * g);
-        e[i + 1] = r;
-        if (r == 0.f) {
-          d[i + 1] -= p;
-          e[m] = 0.f;
-          break;
-        }
-        s = f / r;
-        c = g / r;
-        g = d[i + 1] - p;
-        r = (d[i] - g) * s + 2.f * c * b;
-        p = s * r;
-        d[i + 1] = g + p;
-        g = c * r - b;
-        if (z) {
-          const float zf = z[i + 1], zi = z[i];
-          z[i + 1] = s * zi + c * zf;
-          z[i] = c * zi - s * zf;
-        }
-      }
-      if (r == 0.f && i >= l) continue;
-      d[l] -= p;
-      e[l] = g;
-      e[m] = 0.f;
-    }
-  }
-  return nfail;
-}
 
 __global__ __launch_bounds__(256) void symeig_small_kernel(const float *__restrict__ Ag, int64_t lda, int n,
                                                            float *__restrict__ wout, float *__restrict__ Zg,

@@ -176,6 +176,41 @@ def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False)
     return w, Z
 
 
+def stedc(d: torch.Tensor, e: torch.Tensor, eigenvectors: bool = False):
+    """Eigen-decomposition of the symmetric tridiagonal (d, e) -- stage 2 of ``symeig`` (testing)."""
+    _require_device(d, e)
+    n = d.numel()
+    d, e = d.contiguous().clone(), e.contiguous().clone()
+    w = torch.empty(n, dtype=torch.float32, device=d.device)
+    Z = torch.empty((n, n), dtype=torch.float32, device=d.device) if eigenvectors else None
+    info = torch.zeros(1, dtype=torch.int32, device=d.device)
+    lib = _lib.load()
+    ws, wsb = _workspace(lib.vivit_stedc_f32_workspace_bytes(n, 1 if eigenvectors else 0), d)
+    st = lib.vivit_stedc_f32(
+        d.data_ptr(), e.data_ptr(), n, w.data_ptr(), Z.data_ptr() if eigenvectors else None, n, ws, wsb, info.data_ptr(), _stream(d)
+    )
+    _lib.check(st, "vivit_stedc_f32")
+    if int(info.item()) != 0:
+        raise RuntimeError(f"stedc: {int(info.item())} eigenvalues did not converge")
+    return w, Z
+
+
+def sytrd(G: torch.Tensor):
+    """Householder tridiagonalisation -- stage 1 of ``symeig`` (testing).
+    Returns ``(d, e, tau, A)`` with the reflectors in the upper triangle of ``A``."""
+    _require_device(G)
+    n = G.shape[0]
+    A = G.contiguous().clone()
+    d = torch.empty(n, dtype=torch.float32, device=G.device)
+    e = torch.empty(n - 1, dtype=torch.float32, device=G.device)
+    tau = torch.empty(n, dtype=torch.float32, device=G.device)
+    lib = _lib.load()
+    ws, wsb = _workspace(lib.vivit_sytrd_f32_workspace_bytes(n), G)
+    st = lib.vivit_sytrd_f32(A.data_ptr(), n, n, d.data_ptr(), e.data_ptr(), tau.data_ptr(), ws, wsb, _stream(G))
+    _lib.check(st, "vivit_sytrd_f32")
+    return d, e, tau, A
+
+
 def dir_curvature(GE, evals, C: int, N: int, scale: float):
     """``lambdas[n,k] = scale * sum_c GE[(c,n),k]^2 / evals[k]`` (K6 epilogue)."""
     if _TEST_BACKEND is not None:

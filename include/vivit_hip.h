@@ -148,6 +148,14 @@ int vivit_row_sqnorm_acc_f32(const float *X, float *acc, int64_t K, int64_t len,
                              size_t workspace_bytes, void *stream);
 int vivit_scale_rows_rsqrt_f32(float *X, const float *acc, int64_t K, int64_t len, void *stream);
 
+/* Optional kernel timing for roofline reports (bench.py): between begin and end, every Gram SYRK
+ * launch and every `symv_stride`-th symmetric matrix-vector launch of the tridiagonalisation is
+ * bracketed by HIP events on its stream.  vivit_profile_end synchronises on those events and
+ * fills out[6] = {syrk launches, syrk ms, syrk flops n(n+1)p,  symv launches, symv ms,
+ * symv algorithmic bytes 4*m(m+1)/2}.  Not thread-safe; leave off in production. */
+int vivit_profile_begin(int symv_stride);
+int vivit_profile_end(double *out);
+
 /* Mirror the lower triangle of G into the upper triangle (G[i][j] = G[j][i], i < j). */
 int vivit_symmetrize_lower_f32(float *G, int64_t n, int64_t ldg, void *stream);
 

@@ -39,6 +39,8 @@ SIGNATURES = {
     "vivit_row_sqnorm_workspace_bytes": (_sz, [_i64, _i64]),
     "vivit_row_sqnorm_acc_f32": (_int, [_ptr, _ptr, _i64, _i64, _ptr, _sz, _ptr]),
     "vivit_scale_rows_rsqrt_f32": (_int, [_ptr, _ptr, _i64, _i64, _ptr]),
+    "vivit_profile_begin": (_int, [_int]),
+    "vivit_profile_end": (_int, [ctypes.POINTER(ctypes.c_double)]),
     "vivit_symmetrize_lower_f32": (_int, [_ptr, _i64, _i64, _ptr]),
 }
 

@@ -63,4 +63,10 @@ int gemm_lower_launch(const float *A, const float *B, float *C, int64_t n, int64
 int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int64_t maxM, int64_t maxN, float alpha,
                         float beta, hipStream_t stream);
 
+// profile.hip: optional event timing.  kind 0 = Gram SYRK (work = flops), 1 = symv (work = bytes).
+bool prof_enabled();
+int prof_stride();
+void prof_begin(int kind, double work, hipStream_t stream);
+void prof_end(int kind, hipStream_t stream);
+
 } // namespace vivit

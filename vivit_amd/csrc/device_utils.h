@@ -7,6 +7,15 @@ namespace vivit {
 constexpr int SMALL_N_MAX = 192;
 constexpr float EPS32 = 5.9604645e-8f;  // 2^-24
 
+// Total order on floats for rank sorting: -inf < ... < -0 < +0 < ... < +inf < NaN.  With NaNs
+// mapped to the largest key the rank of n values is always a permutation of 0..n-1, so a
+// non-finite input can never turn into an out-of-range row index downstream.
+__device__ __forceinline__ unsigned sort_key(float f) {
+  const unsigned b = __float_as_uint(f);
+  if ((b & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -368,6 +368,8 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
   if (nsb * 256 > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
   dim3 grid((unsigned)(nsb * 256), (unsigned)p.ksplit, 1);
   dim3 block(256, 1, 1);
+  const bool prof = syrk && prof_enabled();
+  if (prof) prof_begin(0, (double)M * (double)(M + 1) * (double)K, stream);
   if (alay == LAY_K && blay == LAY_K)
     gemm_kernel<LAY_K, LAY_K><<<grid, block, 0, stream>>>(p);
   else if (alay == LAY_K && blay == LAY_M)
@@ -376,6 +378,7 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
     gemm_kernel<LAY_M, LAY_K><<<grid, block, 0, stream>>>(p);
   else
     gemm_kernel<LAY_M, LAY_M><<<grid, block, 0, stream>>>(p);
+  if (prof) prof_end(0, stream);
   int st = launch_status();
   if (st != VIVIT_OK) return st;
   if (p.ksplit > 1) {

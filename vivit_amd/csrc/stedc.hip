@@ -160,10 +160,11 @@ __global__ __launch_bounds__(256) void dc_rank_kernel(int n, int nl, int level, 
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= s) return;
   const float dv = dcur[lo + r];
+  const unsigned kv = sort_key(dv);
   int rk = 0;
   for (int k = 0; k < s; ++k) {
-    const float dk = dcur[lo + k];
-    rk += (dk < dv || (dk == dv && k < r)) ? 1 : 0;
+    const unsigned kk = sort_key(dcur[lo + k]);
+    rk += (kk < kv || (kk == kv && k < r)) ? 1 : 0;
   }
   ws.order[lo + rk] = r;
   ws.ds[lo + rk] = dv;
@@ -434,10 +435,11 @@ __global__ __launch_bounds__(256) void dc_final_rank_kernel(int n, const float *
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   const float dv = dcur[r];
+  const unsigned kv = sort_key(dv);
   int rk = 0;
   for (int k = 0; k < n; ++k) {
-    const float dk = dcur[k];
-    rk += (dk < dv || (dk == dv && k < r)) ? 1 : 0;
+    const unsigned kk = sort_key(dcur[k]);
+    rk += (kk < kv || (kk == kv && k < r)) ? 1 : 0;
   }
   order[rk] = r;
   const float sigma = scal ? scal[1] : 1.f;

@@ -176,10 +176,11 @@ __global__ __launch_bounds__(256) void symeig_small_kernel(const float *__restri
   const float *d0 = dw;  // wave 0's copy
   for (int t = tid; t < n; t += 256) {
     const float dt = d0[t];
+    const unsigned kt = sort_key(dt);
     int rk = 0;
     for (int k = 0; k < n; ++k) {
-      const float dk = d0[k];
-      rk += (dk < dt || (dk == dt && k < t)) ? 1 : 0;
+      const unsigned kk = sort_key(d0[k]);
+      rk += (kk < kt || (kk == kt && k < t)) ? 1 : 0;
     }
     rank[t] = rk;
     wout[rk] = dt / sigma;

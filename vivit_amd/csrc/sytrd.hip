@@ -23,7 +23,6 @@
 namespace vivit {
 
 constexpr int PB = 64;          // panel width
-constexpr int TR = 128;         // symv wave tile: rows
 constexpr int TC = 256;         // symv wave tile: cols (64 lanes x float4)
 
 
@@ -122,51 +121,57 @@ __global__ __launch_bounds__(256) void trd_col_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// K1b: Householder reflector from x: beta, tau, v (v[j+1] = 1).  Rows i >= j+1.
+// Householder scalars of column j, recomputed by every wavefront from the K1 partials (same
+// instruction stream, same inputs: bit-identical in every wave, no extra launch, no broadcast).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trd_reflector_kernel(float *__restrict__ A, int64_t lda, int n, int j, int jj,
-                                                            SytrdWs ws, int npart) {
-  __shared__ float red[4];
-  const int tid = threadIdx.x;
+struct Refl {
+  float beta, tau, sc;
+};
+
+__device__ __forceinline__ Refl wave_reflector(const SytrdWs &ws, int npart, int lane) {
   float s = 0.f;
-  for (int t = tid; t < npart; t += 256) s += ws.ssqpart[t];
-  const float ssq = block_sum(s, red, tid);
+  for (int t = lane; t < npart; t += 64) s += ws.ssqpart[t];
+  const float ssq = wave_sum(s);
   const float alpha = ws.scal[0];
-  float tauj = 0.f, beta = alpha, sc = 0.f;
+  Refl r;
+  r.beta = alpha; r.tau = 0.f; r.sc = 0.f;
   if (ssq > 0.f) {
-    beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
-    tauj = (beta - alpha) / beta;
-    sc = 1.f / (alpha - beta);
+    r.beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
+    r.tau = (r.beta - alpha) / r.beta;
+    r.sc = 1.f / (alpha - r.beta);
   }
-  const int64_t N = n;
-  const int64_t i = (int64_t)j + 1 + (int64_t)blockIdx.x * 256 + tid;
-  if (i < N) {
-    const float v = (i == j + 1) ? 1.f : ws.xbuf[i] * sc;
-    ws.vw[(int64_t)jj * N + i] = v;
-    ws.vw[(int64_t)(2 * PB + jj) * N + i] = v;
-    A[(int64_t)j * lda + i] = v;  // reflector storage: dead upper-triangle row j
-  }
-  if (blockIdx.x == 0 && tid == 0) { ws.e[j] = beta; ws.tau[j] = tauj; }
+  return r;
 }
 
-// ------------------------------------------------------------------------------------------
-// K2: symmetric matrix-vector product over the lower triangle + panel dot products.
-//     One wavefront per 128 x 256 tile; lanes span 4 columns each (16-byte loads), rows are
-//     walked 8 at a time: row sums need a cross-lane reduction (recursive halving, 10 shuffles
-//     per 8 rows), column sums accumulate in registers.  Every tile writes its 128 row partials
-//     and 256 column partials to slabs; K3 adds them in a fixed order.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float4 ld4_guard(const float *__restrict__ p, int64_t c, int64_t n, bool vec) {
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (vec && c + 3 < n) {
-    a = *reinterpret_cast<const float4 *>(p + c);
+// Guarded 4-wide load, BRANCH-FREE (out-of-range lanes read a dummy in-range address and select
+// zero): a branch per load makes hipcc drain vmcnt(0) in front of every load, which serialises
+// the stream.  VEC requires p 16-byte aligned, c % 4 == 0 and n % 4 == 0 (so c < n <=> c+3 < n).
+template <bool VEC>
+__device__ __forceinline__ float4 ld4_guard(const float *__restrict__ p, int64_t c, int64_t n) {
+  if constexpr (VEC) {
+    const bool ok = c < n;
+    const float4 a = *reinterpret_cast<const float4 *>(p + (ok ? c : 0));
+    return ok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    if (c < n) a.x = p[c];
-    if (c + 1 < n) a.y = p[c + 1];
-    if (c + 2 < n) a.z = p[c + 2];
-    if (c + 3 < n) a.w = p[c + 3];
+    float e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = c + k < n;
+      const float x = p[ok ? c + k : 0];
+      e[k] = ok ? x : 0.f;
+    }
+    return make_float4(e[0], e[1], e[2], e[3]);
   }
-  return a;
+}
+
+// v[idx] for idx = c .. c+3 from the un-scaled column x:  0 (idx <= j), 1 (idx == j+1), x * sc.
+__device__ __forceinline__ float v_of(float x, int64_t idx, int j, float sc) {
+  return idx <= j ? 0.f : (idx == j + 1 ? 1.f : x * sc);
+}
+template <bool VEC>
+__device__ __forceinline__ float4 v4_of(const float *__restrict__ xbuf, int64_t c, int64_t n, int j, float sc) {
+  const float4 x = ld4_guard<VEC>(xbuf, c, n);
+  return make_float4(v_of(x.x, c, j, sc), v_of(x.y, c + 1, j, sc), v_of(x.z, c + 2, j, sc), v_of(x.w, c + 3, j, sc));
 }
 
 // Reduce 8 per-lane values over the 64 lanes; on return every lane holds the total of row
@@ -198,46 +203,139 @@ __device__ __forceinline__ float reduce8(const float (&v)[8], int lane) {
   c += __shfl_xor(c, 1, 64);
   return c;
 }
+__device__ __forceinline__ int rho_of(int lane) {
+  return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+}
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void trd_symv_kernel(const float *__restrict__ A, int64_t lda, int n, int j, int jj,
-                                                       SytrdWs ws, int rt0, int nrt, int ct0, int nct) {
-  __shared__ float rowsum[4][TR];
+// One TRR x 256 tile: returns the lane's 4 column sums, leaves the TRR row sums in `rowsum`.
+// FAST = strictly-lower in-bounds tile: unconditional 16-byte loads, no masks.
+template <bool VEC, int TRR, bool FAST>
+__device__ __forceinline__ float4 symv_tile(const float *__restrict__ A, int64_t lda, int64_t N, int64_t R0, int64_t c,
+                                            float4 vc, const float (&vr)[(TRR + 63) / 64], int lane,
+                                            float *__restrict__ rowsum) {
+  float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_group = [&](int g, float4(&dst)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = R0 + g * 8 + u;
+      if constexpr (FAST) {
+        dst[u] = *reinterpret_cast<const float4 *>(A + i * lda + c);
+      } else {
+        const bool rowok = i < N;
+        const float4 a = ld4_guard<VEC>(A + (rowok ? i : 0) * lda, c, N);
+        dst[u] = rowok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto compute_group = [&](int g, const float4(&src)[8]) {
+    float racc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = g * 8 + u;
+      const int64_t i = R0 + r;
+      const float vsel = (TRR > 64 && r >= 64) ? vr[(TRR + 63) / 64 - 1] : vr[0];
+      const float vi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vsel), r & 63));
+      float4 x = src[u];
+      if constexpr (!FAST) {
+        // triangle mask: keep c+e <= i for the row product ...
+        x.x = (c + 0 > i) ? 0.f : x.x;
+        x.y = (c + 1 > i) ? 0.f : x.y;
+        x.z = (c + 2 > i) ? 0.f : x.z;
+        x.w = (c + 3 > i) ? 0.f : x.w;
+      }
+      racc[u] = x.x * vc.x + x.y * vc.y + x.z * vc.z + x.w * vc.w;
+      if constexpr (!FAST) {
+        // ... and c+e < i for the column product (the diagonal counts once)
+        x.x = (c + 0 == i) ? 0.f : x.x;
+        x.y = (c + 1 == i) ? 0.f : x.y;
+        x.z = (c + 2 == i) ? 0.f : x.z;
+        x.w = (c + 3 == i) ? 0.f : x.w;
+      }
+      colacc.x += x.x * vi; colacc.y += x.y * vi; colacc.z += x.z * vi; colacc.w += x.w * vi;
+    }
+    const float tot = reduce8(racc, lane);
+    if ((lane & 7) == 0) rowsum[g * 8 + rho_of(lane)] = tot;
+  };
+  constexpr int NG = TRR / 8;
+  float4 bufa[8], bufb[8];
+  load_group(0, bufa);
+#pragma unroll 1
+  for (int g = 0; g < NG; g += 2) {
+    load_group(g + 1, bufb);
+    compute_group(g, bufa);
+    if (g + 2 < NG) load_group(g + 2, bufa);
+    compute_group(g + 1, bufb);
+  }
+  return colacc;
+}
+
+constexpr int NAUX = 16;  // auxiliary wavefronts: write v / reflector row, panel dot products
+
+// ------------------------------------------------------------------------------------------
+// K2: symmetric matrix-vector product over the lower triangle (+ reflector write, panel dots).
+//     One wavefront per TRR x 256 tile (TRR = 128 for large trailing matrices: 1.2 % slab
+//     overhead; 32 for small ones: 4x more waves to hide latency); lanes span 4 columns each
+//     (16-byte loads), rows are walked 8 at a time with the next 8 rows' loads already in flight.
+//     Row sums need a cross-lane reduction (recursive halving, 10 shuffles per 8 rows), column
+//     sums accumulate in registers.  Every tile writes TRR row partials and 256 column partials
+//     to slabs; K3 adds them in a fixed order.
+// ------------------------------------------------------------------------------------------
+template <bool VEC, int TRR>
+__global__ __launch_bounds__(256) void trd_symv_kernel(float *__restrict__ A, int64_t lda, int n, int j, int jj,
+                                                       SytrdWs ws, int rt0, int nrt, int ct0, int nct, int npart) {
+  __shared__ float rowsum[4][TRR];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t N = n;
   const int ntile = nrt * nct;
   const int widx = blockIdx.x * 4 + wave;
-  const float *__restrict__ v = ws.vw + (int64_t)jj * N;
+  const Refl rf = wave_reflector(ws, npart, lane);
+  const float *__restrict__ xb = ws.xbuf;
 
   if (widx >= ntile) {
-    // ---- panel-dot wave: chunk of 256 indices, all 2*jj panel rows.
-    const int chunk = widx - ntile;
-    if (chunk >= nct || jj == 0) return;
-    const int64_t c = (int64_t)(ct0 + chunk) * TC + 4 * lane;
-    const float4 vc = ld4_guard(v, c, N, VEC);
-    float *out = ws.dotpart + (int64_t)chunk * (2 * PB);
+    // ---- auxiliary wave: materialise v for its chunks, then the panel dots V^T v, W^T v
+    const int aw = widx - ntile;
+    const int naux = nct < NAUX ? nct : NAUX;
+    if (aw >= naux) return;
+    for (int chunk = aw; chunk < nct; chunk += naux) {
+      const int64_t c = (int64_t)(ct0 + chunk) * TC + 4 * lane;
+      const float4 v4 = v4_of<VEC>(xb, c, N, j, rf.sc);
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t idx = c + e;
+        if (idx < N && idx > j) {
+          ws.vw[(int64_t)jj * N + idx] = vv[e];
+          ws.vw[(int64_t)(2 * PB + jj) * N + idx] = vv[e];
+          A[(int64_t)j * lda + idx] = vv[e];  // reflector storage: dead upper-triangle row j
+        }
+      }
+    }
+    if (aw == 0 && lane == 0) { ws.e[j] = rf.beta; ws.tau[j] = rf.tau; }
+    float *out = ws.dotpart + (int64_t)aw * (2 * PB);
     for (int t0 = 0; t0 < jj; t0 += 8) {
       float pv[8], pw[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        pv[u] = 0.f; pw[u] = 0.f;
-        const int t = t0 + u;
-        if (t < jj) {
-          const float4 a = ld4_guard(ws.vw + (int64_t)t * N, c, N, VEC);
-          const float4 b = ld4_guard(ws.vw + (int64_t)(PB + t) * N, c, N, VEC);
-          pv[u] = a.x * vc.x + a.y * vc.y + a.z * vc.z + a.w * vc.w;
-          pw[u] = b.x * vc.x + b.y * vc.y + b.z * vc.z + b.w * vc.w;
+      for (int u = 0; u < 8; ++u) { pv[u] = 0.f; pw[u] = 0.f; }
+      for (int chunk = aw; chunk < nct; chunk += naux) {
+        const int64_t c = (int64_t)(ct0 + chunk) * TC + 4 * lane;
+        const float4 vc = v4_of<VEC>(xb, c, N, j, rf.sc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = t0 + u;
+          if (t < jj) {
+            const float4 a = ld4_guard<VEC>(ws.vw + (int64_t)t * N, c, N);
+            const float4 b = ld4_guard<VEC>(ws.vw + (int64_t)(PB + t) * N, c, N);
+            pv[u] += a.x * vc.x + a.y * vc.y + a.z * vc.z + a.w * vc.w;
+            pw[u] += b.x * vc.x + b.y * vc.y + b.z * vc.z + b.w * vc.w;
+          }
         }
       }
       const float rv = reduce8(pv, lane);
       const float rw = reduce8(pw, lane);
-      if ((lane & 7) == 0) {
-        const int rho = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-        if (t0 + rho < jj) {
-          out[t0 + rho] = rv;
-          out[PB + t0 + rho] = rw;
-        }
+      if ((lane & 7) == 0 && t0 + rho_of(lane) < jj) {
+        out[t0 + rho_of(lane)] = rv;
+        out[PB + t0 + rho_of(lane)] = rw;
       }
     }
     return;
@@ -245,61 +343,28 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const float *__restrict__
 
   // ---- symv tile
   const int rt = rt0 + widx / nct, ct = ct0 + widx % nct;
-  const int64_t R0 = (int64_t)rt * TR, C0 = (int64_t)ct * TC;
-  if (C0 > R0 + TR - 1) return;  // entirely above the diagonal: no partials are ever read from it
+  const int64_t R0 = (int64_t)rt * TRR, C0 = (int64_t)ct * TC;
+  if (C0 > R0 + TRR - 1) return;  // entirely above the diagonal: no partials are ever read from it
   const int64_t c = C0 + 4 * lane;
-  const float4 vc = ld4_guard(v, c, N, VEC);           // v[c..c+3]  (zero below j+1 and beyond n)
-  float vr0 = 0.f, vr1 = 0.f;                          // v[R0 + lane], v[R0 + 64 + lane]
-  if (R0 + lane < N) vr0 = v[R0 + lane];
-  if (R0 + 64 + lane < N) vr1 = v[R0 + 64 + lane];
-  float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool interior = (C0 + TC - 1 < R0) && (R0 + TR - 1 < N);  // strictly below the diagonal, in bounds
-
-  for (int g = 0; g < TR / 8; ++g) {
-    float racc[8];
-    float4 a[8];
+  const float4 vc = v4_of<VEC>(xb, c, N, j, rf.sc);   // v[c..c+3]  (zero up to j and beyond n)
+  float vr[(TRR + 63) / 64];                          // v[R0 + 64*k + lane]
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t i = R0 + g * 8 + u;
-      a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (interior && VEC) {
-        a[u] = *reinterpret_cast<const float4 *>(A + i * lda + c);
-      } else if (i < N) {
-        a[u] = ld4_guard(A + i * lda, c, N, VEC);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = g * 8 + u;
-      const int64_t i = R0 + r;
-      const float vi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r < 64 ? vr0 : vr1), r & 63));
-      float4 x = a[u];
-      if (!interior) {
-        // triangle mask: keep c+e <= i for the row product, c+e < i for the column product
-        if (c + 0 > i) x.x = 0.f;
-        if (c + 1 > i) x.y = 0.f;
-        if (c + 2 > i) x.z = 0.f;
-        if (c + 3 > i) x.w = 0.f;
-      }
-      racc[u] = x.x * vc.x + x.y * vc.y + x.z * vc.z + x.w * vc.w;
-      if (!interior) {
-        if (c + 0 == i) x.x = 0.f;
-        if (c + 1 == i) x.y = 0.f;
-        if (c + 2 == i) x.z = 0.f;
-        if (c + 3 == i) x.w = 0.f;
-      }
-      colacc.x += x.x * vi; colacc.y += x.y * vi; colacc.z += x.z * vi; colacc.w += x.w * vi;
-    }
-    const float tot = reduce8(racc, lane);
-    if ((lane & 7) == 0) {
-      const int rho = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-      rowsum[wave][g * 8 + rho] = tot;
-    }
+  for (int k = 0; k < (TRR + 63) / 64; ++k) {
+    const int64_t i = R0 + 64 * k + lane;
+    const bool ok = i < N && 64 * k + lane < TRR;
+    const float xv = xb[ok ? i : 0];
+    vr[k] = ok ? v_of(xv, i, j, rf.sc) : 0.f;
   }
+  const bool interior = VEC && (C0 + TC - 1 < R0) && (R0 + TRR - 1 < N);  // strictly below the diagonal, in bounds
+  float4 colacc;
+  if (interior)
+    colacc = symv_tile<VEC, TRR, true>(A, lda, N, R0, c, vc, vr, lane, rowsum[wave]);
+  else
+    colacc = symv_tile<VEC, TRR, false>(A, lda, N, R0, c, vc, vr, lane, rowsum[wave]);
   // column partials: one coalesced 1 KiB store per wave
   float *cp = ws.colpart + (int64_t)(rt - rt0) * N;
-  if (c + 3 < N && VEC) {
-    *reinterpret_cast<float4 *>(cp + c) = colacc;
+  if (VEC) {
+    if (c < N) *reinterpret_cast<float4 *>(cp + c) = colacc;
   } else {
     if (c < N) cp[c] = colacc.x;
     if (c + 1 < N) cp[c + 1] = colacc.y;
@@ -309,41 +374,60 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(const float *__restrict__
   // row partials (same wave wrote rowsum: LDS ops of one wave are ordered)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   float *rp = ws.rowpart + (int64_t)(ct - ct0) * N;
-  if (R0 + lane < N) rp[R0 + lane] = rowsum[wave][lane];
-  if (R0 + 64 + lane < N) rp[R0 + 64 + lane] = rowsum[wave][64 + lane];
+#pragma unroll
+  for (int k = 0; k < (TRR + 63) / 64; ++k)
+    if (64 * k + lane < TRR && R0 + 64 * k + lane < N) rp[R0 + 64 * k + lane] = rowsum[wave][64 * k + lane];
 }
 
-// K2b: cvw[t] = sum over chunks of dotpart[chunk][t]
-__global__ __launch_bounds__(2 * PB) void trd_dotreduce_kernel(SytrdWs ws, int nchunk, int jj) {
-  const int t = threadIdx.x;
-  const int tt = t < PB ? t : t - PB;
-  float s = 0.f;
-  if (tt < jj)
-    for (int c = 0; c < nchunk; ++c) s += ws.dotpart[(int64_t)c * (2 * PB) + t];
-  ws.cvw[t] = s;
+// Deterministic strided sum with 4 independent accumulators (loads can overlap).
+__device__ __forceinline__ float sum_strided(const float *__restrict__ p, int64_t stride, int count) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < count; k += 4) {
+    s0 += p[(int64_t)k * stride];
+    s1 += p[(int64_t)(k + 1) * stride];
+    s2 += p[(int64_t)(k + 2) * stride];
+    s3 += p[(int64_t)(k + 3) * stride];
+  }
+  for (; k < count; ++k) s0 += p[(int64_t)k * stride];
+  return (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------
 // K3: y = sum of partials;  w' = tau (y - V c_w - W c_v);  partial w'.v.   Rows i >= j+1.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void trd_finish_kernel(int n, int j, int jj, SytrdWs ws, int rt0, int nrt, int ct0) {
+__global__ __launch_bounds__(256) void trd_finish_kernel(int n, int j, int jj, SytrdWs ws, int rt0, int nrt, int ct0,
+                                                         int nct, int tr) {
   __shared__ float red[4];
   __shared__ float s_c[2 * PB];
   const int tid = threadIdx.x;
-  if (tid < 2 * PB) s_c[tid] = ws.cvw[tid];
+  if (tid < 2 * PB) {
+    const int naux = nct < NAUX ? nct : NAUX;
+    const int tt = tid < PB ? tid : tid - PB;
+    float s = 0.f;
+    if (tt < jj)
+      for (int a = 0; a < naux; ++a) s += ws.dotpart[(int64_t)a * (2 * PB) + tid];
+    s_c[tid] = s;
+  }
   __syncthreads();
   const int64_t N = n;
   const int64_t i = (int64_t)j + 1 + (int64_t)blockIdx.x * 256 + tid;
   float wv = 0.f;
   if (i < N) {
-    float y = 0.f;
     const int ctl = (int)(i / TC);
-    for (int ct = ct0; ct <= ctl; ++ct) y += ws.rowpart[(int64_t)(ct - ct0) * N + i];
-    int rtf = (int)(i / TR);
+    float y = sum_strided(ws.rowpart + i, N, ctl - ct0 + 1);
+    int rtf = (int)(i / tr);
     if (rtf < rt0) rtf = rt0;
-    for (int rt = rtf; rt < rt0 + nrt; ++rt) y += ws.colpart[(int64_t)(rt - rt0) * N + i];
+    y += sum_strided(ws.colpart + (int64_t)(rtf - rt0) * N + i, N, rt0 + nrt - rtf);
     const float *V = ws.vw, *W = ws.vw + (int64_t)PB * N;
-    for (int t = 0; t < jj; ++t) y -= V[(int64_t)t * N + i] * s_c[PB + t] + W[(int64_t)t * N + i] * s_c[t];
+    float c0 = 0.f, c1 = 0.f;
+    int t = 0;
+    for (; t + 1 < jj; t += 2) {
+      c0 += V[(int64_t)t * N + i] * s_c[PB + t] + W[(int64_t)t * N + i] * s_c[t];
+      c1 += V[(int64_t)(t + 1) * N + i] * s_c[PB + t + 1] + W[(int64_t)(t + 1) * N + i] * s_c[t + 1];
+    }
+    if (t < jj) c0 += V[(int64_t)t * N + i] * s_c[PB + t] + W[(int64_t)t * N + i] * s_c[t];
+    y -= c0 + c1;
     const float w = ws.tau[j] * y;
     ws.vw[(int64_t)(PB + jj) * N + i] = w;
     wv = w * V[(int64_t)jj * N + i];
@@ -376,12 +460,12 @@ __global__ void trd_tail_kernel(const float *__restrict__ A, int64_t lda, int n,
 
 // ------------------------------------------------------------------------------------------
 size_t sytrd_workspace_floats(int64_t n) {
-  const int64_t nct = cdiv(n, TC), nrt = cdiv(n, TR), nwg = cdiv(n, 256) + 1;
+  const int64_t nct = cdiv(n, TC), nrt = cdiv(n, 32), nwg = cdiv(n, 256) + 1;
   int64_t f = 0;
   f += 3 * PB * n;                 // vw
   f += n;                          // xbuf
   f += nct * n + nrt * n;          // rowpart, colpart
-  f += nct * 2 * PB + 2 * PB;      // dotpart, cvw
+  f += NAUX * 2 * PB + 2 * PB;     // dotpart, cvw
   f += 2 * nwg + 16;               // ssqpart, wdotpart, scal
   f += 3 * n;                      // d, e, tau
   f += 2 * n;                      // scan partials
@@ -390,7 +474,7 @@ size_t sytrd_workspace_floats(int64_t n) {
 
 // Carve the workspace (all sub-buffers 16-byte aligned).
 static SytrdWs sytrd_carve(float *base, int64_t n, float **scanpart) {
-  const int64_t nct = cdiv(n, TC), nrt = cdiv(n, TR), nwg = cdiv(n, 256) + 1;
+  const int64_t nct = cdiv(n, TC), nrt = cdiv(n, 32), nwg = cdiv(n, 256) + 1;
   auto take = [&](int64_t count) {
     float *p = base;
     base += (count + 3) / 4 * 4;
@@ -401,7 +485,7 @@ static SytrdWs sytrd_carve(float *base, int64_t n, float **scanpart) {
   ws.xbuf = take(n);
   ws.rowpart = take(nct * n);
   ws.colpart = take(nrt * n);
-  ws.dotpart = take(nct * 2 * PB);
+  ws.dotpart = take(NAUX * 2 * PB);
   ws.cvw = take(2 * PB);
   ws.ssqpart = take(nwg);
   ws.wdotpart = take(nwg);
@@ -436,16 +520,24 @@ int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, 
       const int g2 = (int)cdiv(n - j - 1, 256);  // rows i >= j+1
       const int nprev = (int)cdiv(n - j, 256);   // finish-kernel grid of column j-1 (rows >= j)
       trd_col_kernel<<<g1, 256, 0, stream>>>(A, lda, ni, j, jj, 0, ws, nprev);
-      trd_reflector_kernel<<<g2, 256, 0, stream>>>(A, lda, ni, j, jj, ws, g1);
-      const int rt0 = (j + 1) / TR, nrt = (int)cdiv(n, TR) - rt0;
+      const int64_t mtrail = n - j - 1;
+      const int tr = mtrail > 16384 ? 128 : 32;
+      const int rt0 = (j + 1) / tr, nrt = (int)cdiv(n, tr) - rt0;
       const int ct0 = (j + 1) / TC, nct = (int)cdiv(n, TC) - ct0;
-      const int nwave = nrt * nct + (jj > 0 ? nct : 0);
-      if (vec)
-        trd_symv_kernel<true><<<(unsigned)cdiv(nwave, 4), 256, 0, stream>>>(A, lda, ni, j, jj, ws, rt0, nrt, ct0, nct);
+      const int nwave = nrt * nct + (nct < NAUX ? nct : NAUX);
+      const unsigned g = (unsigned)cdiv(nwave, 4);
+      const bool prof = prof_enabled() && (j % prof_stride() == 0);
+      if (prof) prof_begin(1, 2.0 * (double)(n - j - 1) * (double)(n - j), stream);  // 4 B * m(m+1)/2
+      if (vec && tr == 128)
+        trd_symv_kernel<true, 128><<<g, 256, 0, stream>>>(A, lda, ni, j, jj, ws, rt0, nrt, ct0, nct, g1);
+      else if (vec)
+        trd_symv_kernel<true, 32><<<g, 256, 0, stream>>>(A, lda, ni, j, jj, ws, rt0, nrt, ct0, nct, g1);
+      else if (tr == 128)
+        trd_symv_kernel<false, 128><<<g, 256, 0, stream>>>(A, lda, ni, j, jj, ws, rt0, nrt, ct0, nct, g1);
       else
-        trd_symv_kernel<false><<<(unsigned)cdiv(nwave, 4), 256, 0, stream>>>(A, lda, ni, j, jj, ws, rt0, nrt, ct0, nct);
-      trd_dotreduce_kernel<<<1, 2 * PB, 0, stream>>>(ws, nct, jj);
-      trd_finish_kernel<<<g2, 256, 0, stream>>>(ni, j, jj, ws, rt0, nrt, ct0);
+        trd_symv_kernel<false, 32><<<g, 256, 0, stream>>>(A, lda, ni, j, jj, ws, rt0, nrt, ct0, nct, g1);
+      if (prof) prof_end(1, stream);
+      trd_finish_kernel<<<g2, 256, 0, stream>>>(ni, j, jj, ws, rt0, nrt, ct0, nct, tr);
     }
     // finalise the last W of the panel (rows >= j0 + bb)
     {

@@ -1,0 +1,37 @@
+"""bench.py's synthetic factor generator must produce exactly what SqrtGGNExact attaches to the
+parameters (checked on CPU against the stand-in backend, which is itself checked against autograd)."""
+import torch
+from torch import nn
+
+import bench
+from helpers import OracleBackend
+from vivit_amd import kernels
+from vivit_amd.backend import SqrtGGNExact, backpack, extend
+
+
+def test_bench_factors_match_backend():
+    dims, batch = (7, 6, 5), 4
+    facs = bench.mlp_sqrt_ggn_factors(dims, batch, torch.device("cpu"), seed=3)
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(3)
+        lin1, lin2 = nn.Linear(7, 6), nn.Linear(6, 5)
+        X = torch.rand(batch, 7)
+    model = extend(nn.Sequential(lin1, nn.ReLU(), lin2))
+    lossf = extend(nn.CrossEntropyLoss())
+    kernels.set_backend_for_testing(OracleBackend())
+    try:
+        loss = lossf(model(X), torch.zeros(batch, dtype=torch.long))
+        with backpack(SqrtGGNExact()):
+            loss.backward()
+    finally:
+        kernels.set_backend_for_testing(None)
+    n = 5 * batch
+    expect = [lin2.weight, lin2.bias, lin1.weight, lin1.bias]
+    for f, p in zip(facs, expect):
+        torch.testing.assert_close(f, p.sqrt_ggn_exact.reshape(n, -1), rtol=1e-5, atol=1e-7)
+    # sharding the first-layer weight over 2 ranks partitions its columns
+    f0 = bench.mlp_sqrt_ggn_factors(dims, batch, torch.device("cpu"), shard=(0, 2), seed=3)
+    f1 = bench.mlp_sqrt_ggn_factors(dims, batch, torch.device("cpu"), shard=(1, 2), seed=3)
+    G_full = sum(f @ f.T for f in facs)
+    G_sharded = sum(f @ f.T for f in f0) + sum(f @ f.T for f in f1)
+    torch.testing.assert_close(G_full, G_sharded, rtol=1e-5, atol=1e-6)

@@ -379,28 +379,31 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(float *__restrict__ A, in
     if (64 * k + lane < TRR && R0 + 64 * k + lane < N) rp[R0 + 64 * k + lane] = rowsum[wave][64 * k + lane];
 }
 
-// Deterministic strided sum with 4 independent accumulators (loads can overlap).
-__device__ __forceinline__ float sum_strided(const float *__restrict__ p, int64_t stride, int count) {
+// Deterministic strided partial sum: terms first, first + step, ... < count, 4 accumulators.
+__device__ __forceinline__ float sum_strided(const float *__restrict__ p, int64_t stride, int first, int step,
+                                             int count) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < count; k += 4) {
+  int k = first;
+  for (; k + 3 * step < count; k += 4 * step) {
     s0 += p[(int64_t)k * stride];
-    s1 += p[(int64_t)(k + 1) * stride];
-    s2 += p[(int64_t)(k + 2) * stride];
-    s3 += p[(int64_t)(k + 3) * stride];
+    s1 += p[(int64_t)(k + step) * stride];
+    s2 += p[(int64_t)(k + 2 * step) * stride];
+    s3 += p[(int64_t)(k + 3 * step) * stride];
   }
-  for (; k < count; ++k) s0 += p[(int64_t)k * stride];
+  for (; k < count; k += step) s0 += p[(int64_t)k * stride];
   return (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------
 // K3: y = sum of partials;  w' = tau (y - V c_w - W c_v);  partial w'.v.   Rows i >= j+1.
+//     64 rows per workgroup (lane = row); the 4 waves split the partial/panel index 4 ways to
+//     shorten the dependent chains, their sums are combined through LDS in a fixed order.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void trd_finish_kernel(int n, int j, int jj, SytrdWs ws, int rt0, int nrt, int ct0,
                                                          int nct, int tr) {
-  __shared__ float red[4];
   __shared__ float s_c[2 * PB];
-  const int tid = threadIdx.x;
+  __shared__ float part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 2 * PB) {
     const int naux = nct < NAUX ? nct : NAUX;
     const int tt = tid < PB ? tid : tid - PB;
@@ -411,29 +414,37 @@ __global__ __launch_bounds__(256) void trd_finish_kernel(int n, int j, int jj, S
   }
   __syncthreads();
   const int64_t N = n;
-  const int64_t i = (int64_t)j + 1 + (int64_t)blockIdx.x * 256 + tid;
-  float wv = 0.f;
+  const int64_t i = (int64_t)j + 1 + (int64_t)blockIdx.x * 64 + lane;
+  const float *V = ws.vw, *W = ws.vw + (int64_t)PB * N;
+  float y = 0.f;
   if (i < N) {
     const int ctl = (int)(i / TC);
-    float y = sum_strided(ws.rowpart + i, N, ctl - ct0 + 1);
+    y = sum_strided(ws.rowpart + i, N, wave, 4, ctl - ct0 + 1);
     int rtf = (int)(i / tr);
     if (rtf < rt0) rtf = rt0;
-    y += sum_strided(ws.colpart + (int64_t)(rtf - rt0) * N + i, N, rt0 + nrt - rtf);
-    const float *V = ws.vw, *W = ws.vw + (int64_t)PB * N;
+    y += sum_strided(ws.colpart + (int64_t)(rtf - rt0) * N + i, N, wave, 4, rt0 + nrt - rtf);
     float c0 = 0.f, c1 = 0.f;
-    int t = 0;
-    for (; t + 1 < jj; t += 2) {
+    int t = wave;
+    for (; t + 4 < jj; t += 8) {
       c0 += V[(int64_t)t * N + i] * s_c[PB + t] + W[(int64_t)t * N + i] * s_c[t];
-      c1 += V[(int64_t)(t + 1) * N + i] * s_c[PB + t + 1] + W[(int64_t)(t + 1) * N + i] * s_c[t + 1];
+      c1 += V[(int64_t)(t + 4) * N + i] * s_c[PB + t + 4] + W[(int64_t)(t + 4) * N + i] * s_c[t + 4];
     }
     if (t < jj) c0 += V[(int64_t)t * N + i] * s_c[PB + t] + W[(int64_t)t * N + i] * s_c[t];
     y -= c0 + c1;
-    const float w = ws.tau[j] * y;
-    ws.vw[(int64_t)(PB + jj) * N + i] = w;
-    wv = w * V[(int64_t)jj * N + i];
   }
-  const float s = block_sum(wv, red, tid);
-  if (tid == 0) ws.wdotpart[blockIdx.x] = s;
+  part[wave][lane] = y;
+  __syncthreads();
+  if (wave == 0) {
+    float wv = 0.f;
+    if (i < N) {
+      const float yt = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+      const float w = ws.tau[j] * yt;
+      ws.vw[(int64_t)(PB + jj) * N + i] = w;
+      wv = w * V[(int64_t)jj * N + i];
+    }
+    const float s = wave_sum(wv);
+    if (lane == 0) ws.wdotpart[blockIdx.x] = s;
+  }
 }
 
 // Tail: d[n-2], e[n-2], d[n-1] from the last 2x2 block with the pending panel applied.
@@ -460,7 +471,7 @@ __global__ void trd_tail_kernel(const float *__restrict__ A, int64_t lda, int n,
 
 // ------------------------------------------------------------------------------------------
 size_t sytrd_workspace_floats(int64_t n) {
-  const int64_t nct = cdiv(n, TC), nrt = cdiv(n, 32), nwg = cdiv(n, 256) + 1;
+  const int64_t nct = cdiv(n, TC), nrt = cdiv(n, 32), nwg = cdiv(n, 64) + 1;
   int64_t f = 0;
   f += 3 * PB * n;                 // vw
   f += n;                          // xbuf
@@ -474,7 +485,7 @@ size_t sytrd_workspace_floats(int64_t n) {
 
 // Carve the workspace (all sub-buffers 16-byte aligned).
 static SytrdWs sytrd_carve(float *base, int64_t n, float **scanpart) {
-  const int64_t nct = cdiv(n, TC), nrt = cdiv(n, 32), nwg = cdiv(n, 256) + 1;
+  const int64_t nct = cdiv(n, TC), nrt = cdiv(n, 32), nwg = cdiv(n, 64) + 1;
   auto take = [&](int64_t count) {
     float *p = base;
     base += (count + 3) / 4 * 4;
@@ -518,7 +529,7 @@ int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, 
       const int j = (int)(j0 + jj);
       const int g1 = (int)cdiv(n - j, 256);      // rows i >= j
       const int g2 = (int)cdiv(n - j - 1, 256);  // rows i >= j+1
-      const int nprev = (int)cdiv(n - j, 256);   // finish-kernel grid of column j-1 (rows >= j)
+      const int nprev = (int)cdiv(n - j, 64);    // finish-kernel grid of column j-1 (rows >= j, 64 per block)
       trd_col_kernel<<<g1, 256, 0, stream>>>(A, lda, ni, j, jj, 0, ws, nprev);
       const int64_t mtrail = n - j - 1;
       const int tr = mtrail > 16384 ? 128 : 32;
@@ -537,13 +548,13 @@ int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, 
       else
         trd_symv_kernel<false, 32><<<g, 256, 0, stream>>>(A, lda, ni, j, jj, ws, rt0, nrt, ct0, nct, g1);
       if (prof) prof_end(1, stream);
-      trd_finish_kernel<<<g2, 256, 0, stream>>>(ni, j, jj, ws, rt0, nrt, ct0, nct, tr);
+      trd_finish_kernel<<<(unsigned)cdiv(n - j - 1, 64), 256, 0, stream>>>(ni, j, jj, ws, rt0, nrt, ct0, nct, tr);
     }
     // finalise the last W of the panel (rows >= j0 + bb)
     {
       const int j = (int)(j0 + bb);
       const int g1 = (int)cdiv(n - j, 256);
-      trd_col_kernel<<<g1, 256, 0, stream>>>(A, lda, ni, j, bb, 1, ws, g1);
+      trd_col_kernel<<<g1, 256, 0, stream>>>(A, lda, ni, j, bb, 1, ws, (int)cdiv(n - j, 64));
     }
     const int64_t off = j0 + bb;
     if (off < n - 2) {

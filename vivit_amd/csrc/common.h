@@ -46,6 +46,7 @@ struct GemmArgs {
   int syrk;         // 1: lower-triangular tiles only + mirrored store; 2: lower tiles, no mirror
   int a_vec, b_vec; // 16-byte loads legal for the operand
   const GemmDesc *desc;  // non-null: batched mode, problem blockIdx.z is desc[blockIdx.z]
+  int sbw;          // super-block width in tiles (host and kernel must agree on the tile map)
 };
 
 // Generic launcher (gemm_f32.hip).  alay/blay in {LAY_K, LAY_M}.

@@ -111,10 +111,20 @@ __device__ __forceinline__ void frag_load(const float *__restrict__ s, int r, in
   }
 }
 
+// Super-block geometry: 256 tiles per super-block, SBW tiles wide (a power of two <= 16, shrunk
+// for skinny outputs so that a one-tile-wide GEMM still spreads over all 8 XCDs), each XCD owning
+// one compact sub-block of 32 tiles (xw wide).
+__host__ __device__ inline int sb_width(int tiles_n) {
+  int w = 1;
+  while (w < 16 && w < tiles_n) w <<= 1;
+  return w;
+}
+
 // blockIdx.x -> (tile_i, tile_j); returns false for padding slots.
-__device__ __forceinline__ bool map_tile(int syrk, int tiles_m, int tiles_n, int &ti, int &tj) {
+__device__ __forceinline__ bool map_tile(int syrk, int SBW, int tiles_m, int tiles_n, int &ti, int &tj) {
   const int sb = blockIdx.x >> 8;
   const int slot = blockIdx.x & 255;
+  const int SBH = 256 / SBW;
   int I, J;
   if (syrk) {
     I = (int)((sqrtf(8.f * (float)sb + 1.f) - 1.f) * 0.5f);
@@ -122,13 +132,15 @@ __device__ __forceinline__ bool map_tile(int syrk, int tiles_m, int tiles_n, int
     while (I * (I + 1) / 2 > sb) --I;
     J = sb - I * (I + 1) / 2;
   } else {
-    const int sbn = (tiles_n + SB - 1) / SB;
+    const int sbn = (tiles_n + SBW - 1) / SBW;
     I = sb / sbn;
     J = sb - I * sbn;
   }
+  const int xw = SBW < 4 ? SBW : 4, xh = 32 / xw;   // XCD sub-block: xh x xw tiles
+  const int xcols = SBW / xw;                        // XCD sub-blocks per super-block row
   const int xcd = slot & 7, w = slot >> 3;
-  ti = I * SB + (xcd >> 2) * 8 + (w >> 2);
-  tj = J * SB + (xcd & 3) * 4 + (w & 3);
+  ti = I * SBH + (xcd / xcols) * xh + w / xw;
+  tj = J * SBW + (xcd % xcols) * xw + w % xw;
   if (ti >= tiles_m || tj >= tiles_n) return false;
   if (syrk && tj > ti) return false;
   return true;
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     p.b_vec = ((reinterpret_cast<uintptr_t>(ds.B) & 15) == 0 && (ds.ldb & 3) == 0) ? 1 : 0;
   }
   int ti, tj;
-  if (!map_tile(p.syrk, p.tiles_m, p.tiles_n, ti, tj)) return;
+  if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -363,7 +375,9 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
   p.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
   p.desc = nullptr;
 
-  const int64_t sbm = cdiv(p.tiles_m, SB), sbn = cdiv(p.tiles_n, SB);
+  const int sbw = syrk ? 16 : sb_width(p.tiles_n), sbh = 256 / sbw;
+  p.sbw = sbw;
+  const int64_t sbm = cdiv(p.tiles_m, sbh), sbn = cdiv(p.tiles_n, sbw);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
   if (nsb * 256 > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
   dim3 grid((unsigned)(nsb * 256), (unsigned)p.ksplit, 1);
@@ -405,6 +419,7 @@ int gemm_lower_launch(const float *A, const float *B, float *C, int64_t n, int64
   p.a_vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   p.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
   p.desc = nullptr;
+  p.sbw = SB;
   const int64_t sbm = cdiv(p.tiles_m, SB);
   const int64_t nsb = sbm * (sbm + 1) / 2;
   gemm_kernel<LAY_M, LAY_M><<<dim3((unsigned)(nsb * 256), 1, 1), 256, 0, stream>>>(p);
@@ -427,7 +442,9 @@ int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int
   p.syrk = 0;
   p.a_vec = p.b_vec = 0;
   p.desc = desc;
-  const int64_t nsb = cdiv(p.tiles_m, SB) * cdiv(p.tiles_n, SB);
+  const int sbw = sb_width(p.tiles_n), sbh = 256 / sbw;
+  p.sbw = sbw;
+  const int64_t nsb = cdiv(p.tiles_m, sbh) * cdiv(p.tiles_n, sbw);
   if (nsb * 256 > 0x7fffffffLL || batch > 65535) return VIVIT_E_UNSUPPORTED;
   dim3 grid((unsigned)(nsb * 256), 1, (unsigned)batch);
   if (alay == LAY_K && blay == LAY_K)

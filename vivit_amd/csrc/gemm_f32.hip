@@ -18,6 +18,8 @@
 // SYRK mode (the Gram build, K1): B == A, only super-blocks/tiles with tile_i >= tile_j are
 // computed (n(n+1)p flops instead of 2n^2p) and off-diagonal tiles are stored twice, the mirror
 // image transposed through LDS so that both stores are coalesced.
+#include <type_traits>
+
 #include "common.h"
 
 namespace vivit {
@@ -29,52 +31,53 @@ constexpr int TILE_FLOATS = BM * SK;           // 2560 floats (>= 16*132 = 2112)
 constexpr int FLUSH_TILES = 2048 / BK;         // second-level accumulation period
 constexpr int SB = 16;                         // super-block edge in tiles
 
-__device__ __forceinline__ float4 ld4_lay_k(const float *__restrict__ P, int64_t ld, int64_t row,
-                                            int64_t nrows, int64_t k, int64_t kend, bool vec) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < nrows && k < kend) {
-    const float *q = P + row * ld + k;
-    if (vec && k + 3 < kend) {
-      v = *reinterpret_cast<const float4 *>(q);
-    } else {
-      v.x = q[0];
-      if (k + 1 < kend) v.y = q[1];
-      if (k + 2 < kend) v.z = q[2];
-      if (k + 3 < kend) v.w = q[3];
-    }
-  }
-  return v;
+// Operand pointers are re-read from a device-resident descriptor in batched mode, which makes
+// hipcc lose their address space and emit flat_load (slower, and waited for with vmcnt(0) +
+// lgkmcnt(0)).  All global accesses therefore go through explicitly global-address-space pointers.
+typedef const float __attribute__((address_space(1))) *gcptr;
+typedef float __attribute__((address_space(1))) *gptr;
+typedef const f32x4 __attribute__((address_space(1))) *gcptr4;
+__device__ __forceinline__ float4 ldg4(gcptr q) {
+  const f32x4 v = *(gcptr4)q;
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
-__device__ __forceinline__ float4 ld4_lay_m(const float *__restrict__ P, int64_t ld, int64_t row,
-                                            int64_t nrows, int64_t k, int64_t kend, bool vec) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (k < kend && row < nrows) {
-    const float *q = P + k * ld + row;
-    if (vec && row + 3 < nrows) {
-      v = *reinterpret_cast<const float4 *>(q);
-    } else {
-      v.x = q[0];
-      if (row + 1 < nrows) v.y = q[1];
-      if (row + 2 < nrows) v.z = q[2];
-      if (row + 3 < nrows) v.w = q[3];
-    }
-  }
-  return v;
+// Guarded element load, BRANCH-FREE: out-of-range elements read a clamped in-range address and
+// select zero.  (A branch per load makes hipcc put s_waitcnt vmcnt(0) in front of every load and
+// in front of the MFMA block, which serialises the stream and exposes the full HBM latency.)
+__device__ __forceinline__ float ld1_sel(gcptr P, int64_t idx_major, int64_t n_major,
+                                         int64_t idx_minor, int64_t n_minor, int64_t ld) {
+  const bool ok = idx_major < n_major && idx_minor < n_minor;
+  const int64_t a = idx_major < n_major ? idx_major : n_major - 1;
+  const int64_t b = idx_minor < n_minor ? idx_minor : n_minor - 1;
+  const float x = P[a * ld + b];
+  return ok ? x : 0.f;
 }
 
 // Global -> registers for one 128 x 16 operand tile (2 float4 per thread).
-template <int LAY>
-__device__ __forceinline__ void tile_load(const float *__restrict__ P, int64_t ld, int64_t row0,
-                                          int64_t nrows, int64_t k0, int64_t kend, bool vec, int tid,
-                                          float4 (&st)[2]) {
+// FAST: the tile is completely in range and the operand is 16-byte aligned: unconditional float4.
+template <int LAY, bool FAST>
+__device__ __forceinline__ void tile_load(gcptr P, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                          int64_t kend, int tid, float4 (&st)[2]) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int f = tid + 256 * q;
     if (LAY == LAY_K) {
-      st[q] = ld4_lay_k(P, ld, row0 + (f >> 2), nrows, k0 + 4 * (f & 3), kend, vec);
+      const int64_t row = row0 + (f >> 2), k = k0 + 4 * (f & 3);
+      if constexpr (FAST) {
+        st[q] = ldg4(P + row * ld + k);
+      } else {
+        st[q] = make_float4(ld1_sel(P, row, nrows, k, kend, ld), ld1_sel(P, row, nrows, k + 1, kend, ld),
+                            ld1_sel(P, row, nrows, k + 2, kend, ld), ld1_sel(P, row, nrows, k + 3, kend, ld));
+      }
     } else {
-      st[q] = ld4_lay_m(P, ld, row0 + 4 * (f & 31), nrows, k0 + (f >> 5), kend, vec);
+      const int64_t row = row0 + 4 * (f & 31), k = k0 + (f >> 5);
+      if constexpr (FAST) {
+        st[q] = ldg4(P + k * ld + row);
+      } else {
+        st[q] = make_float4(ld1_sel(P, k, kend, row, nrows, ld), ld1_sel(P, k, kend, row + 1, nrows, ld),
+                            ld1_sel(P, k, kend, row + 2, nrows, ld), ld1_sel(P, k, kend, row + 3, nrows, ld));
+      }
     }
   }
 }
@@ -183,24 +186,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
 
-  float4 stA[2], stB[2];
-  const bool avec = p.a_vec != 0, bvec = p.b_vec != 0;
-  if (nt > 0) {
-    tile_load<ALAY>(p.A, p.lda, row0, p.M, kbeg, kend, avec, tid, stA);
-    tile_load<BLAY>(p.B, p.ldb, col0, p.N, kbeg, kend, bvec, tid, stB);
-    tile_store<ALAY>(SA(0), tid, stA);
-    tile_store<BLAY>(SB_(0), tid, stB);
-  }
-  __syncthreads();
-
-  int since_flush = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) {
-      const int64_t k0 = kbeg + (int64_t)(t + 1) * BK;
-      tile_load<ALAY>(p.A, p.lda, row0, p.M, k0, kend, avec, tid, stA);
-      tile_load<BLAY>(p.B, p.ldb, col0, p.N, k0, kend, bvec, tid, stB);
-    }
+  // One K tile of MFMA work from LDS buffer `cur`.
+  auto compute = [&](int cur) {
     float fa[2][2][4], fb[2][2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) frag_load<ALAY>(SA(cur), wm * 64 + i * 32 + r, h, fa[i]);
@@ -215,23 +202,58 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q][tt], fb[j][q][tt], acc[i][j], 0, 0, 0);
-    if (++since_flush == FLUSH_TILES) {
-      since_flush = 0;
+  };
+  auto flush = [&]() {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          tot[i][j] += acc[i][j];
+      for (int j = 0; j < 2; ++j) {
+        tot[i][j] += acc[i][j];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        }
-    }
-    if (t + 1 < nt) {
-      tile_store<ALAY>(SA(cur ^ 1), tid, stA);
-      tile_store<BLAY>(SB_(cur ^ 1), tid, stB);
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      }
+  };
+
+  // Register-staged double buffering: the loads of tile t+1 are issued BEFORE the MFMAs of tile t
+  // and written to the other LDS buffer after them; one barrier per K tile.
+  auto mainloop = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    // with FAST only the full K tiles go through the unguarded loader; a ragged last tile is
+    // loaded by the guarded one.
+    const int nt_fast = FAST ? (int)((kend - kbeg) / BK) : 0;
+    float4 stA[2], stB[2];
+    auto load = [&](int t) {
+      const int64_t k0 = kbeg + (int64_t)t * BK;
+      if (FAST && t < nt_fast) {
+        tile_load<ALAY, FAST>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
+        tile_load<BLAY, FAST>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
+      } else {
+        tile_load<ALAY, false>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
+        tile_load<BLAY, false>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
+      }
+    };
+    if (nt > 0) {
+      load(0);
+      tile_store<ALAY>(SA(0), tid, stA);
+      tile_store<BLAY>(SB_(0), tid, stB);
     }
     __syncthreads();
-  }
+    int since_flush = 0;
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < nt) load(t + 1);
+      compute(cur);
+      if (++since_flush == FLUSH_TILES) { since_flush = 0; flush(); }
+      if (t + 1 < nt) {
+        tile_store<ALAY>(SA(cur ^ 1), tid, stA);
+        tile_store<BLAY>(SB_(cur ^ 1), tid, stB);
+      }
+      __syncthreads();
+    }
+  };
+  const bool fast = p.a_vec && p.b_vec && row0 + BM <= p.M && col0 + BN <= p.N;
+  if (fast) mainloop(std::true_type{});
+  else mainloop(std::false_type{});
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -239,27 +261,49 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*h.
   const bool partial = p.ksplit > 1;
-  float *__restrict__ Cout = partial ? p.slab + (int64_t)blockIdx.y * p.M * p.N : p.C;
+  gptr Cout = (gptr)(partial ? p.slab + (int64_t)blockIdx.y * p.M * p.N : p.C);
   const int64_t ldc = partial ? p.N : p.ldc;
   const float alpha = partial ? 1.f : p.alpha;
   const float beta = partial ? 0.f : p.beta;
 
+  const bool full_tile = row0 + BM <= p.M && col0 + BN <= p.N;
+  if (full_tile) {
+    // unguarded epilogue: all loads (beta != 0) are issued before the first use
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = col0 + wn * 64 + j * 32 + r;
+      for (int j = 0; j < 2; ++j) {
+        gptr cbase = Cout + (row0 + wm * 64 + i * 32 + 4 * h) * ldc + col0 + wn * 64 + j * 32 + r;
+        float old[16];
+        if (beta != 0.f) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < p.M && col < p.N) {
-          float *c = Cout + row * ldc + col;
+          for (int e = 0; e < 16; ++e) old[e] = cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
           float v = alpha * tot[i][j][e];
-          if (beta != 0.f) v += beta * *c;
-          *c = v;
+          if (beta != 0.f) v += beta * old[e];
+          cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc] = v;
         }
       }
-    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = col0 + wn * 64 + j * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < p.M && col < p.N) {
+            gptr c = Cout + row * ldc + col;
+            float v = alpha * tot[i][j][e];
+            if (beta != 0.f) v += beta * *c;
+            *c = v;
+          }
+        }
+      }
+  }
 
   if (p.syrk == 1 && !partial && ti != tj) {
     // Mirror image: C[col][row] = same value, transposed through LDS (32x33 floats per wave)
@@ -279,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         for (int rr = 0; rr < 32; rr += 2) {
           const int64_t mrow = mrow0 + rr + h;
           if (mrow < p.N && mcol < p.M) {
-            float *c = p.C + mrow * p.ldc + mcol;
+            gptr c = (gptr)p.C + mrow * p.ldc + mcol;
             float v = p.alpha * ts[(rr + h) * 33 + r];
             if (p.beta != 0.f) v += p.beta * *c;
             *c = v;
@@ -316,7 +360,7 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
   // Fill at least ~2 workgroups per CU when the output has few tiles and K is deep; keep every
   // split at least 32 K tiles long and the slab modest.
   if (tiles < 256 && ktiles >= 64) {
-    int64_t want = cdiv(512, tiles);
+    int64_t want = 512 / tiles;  // one resident round: 2 workgroups per CU x 256 CUs
     int64_t maxs = ktiles / 32;
     int64_t s = want < maxs ? want : maxs;
     if (s > 64) s = 64;

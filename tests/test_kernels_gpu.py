@@ -130,3 +130,23 @@ def test_cpu_tensor_rejected():
 
     with pytest.raises(RuntimeError):
         kernels.gram_syrk(torch.randn(4, 4))
+
+
+@pytest.mark.parametrize("K,n,P", [(1, 40, 10), (1, 3000, 5000), (3, 1025, 1027), (8, 2048, 4096), (16, 777, 333), (10, 1280, 7840)])
+def test_backproject_skinny(K, n, P):
+    """K7/K8 with few directions (streaming kernel behind gemm_nn for m <= 16)."""
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(K * 131 + n + P)
+    E = torch.randn(K, n, generator=g)
+    V = torch.randn(n, P, generator=g)
+    C0 = torch.randn(K, P, generator=g)
+    ref = E.double() @ V.double()
+    out = kernels.gemm_nn(E.to(_dev()), V.to(_dev()))
+    tol = 2e-6 * (n ** 0.5) + 1e-6
+    assert _rel(out, ref) < tol
+    Cd = C0.to(_dev()).clone()
+    kernels.gemm_nn(E.to(_dev()), V.to(_dev()), out=Cd, alpha=-0.5, beta=2.0)
+    assert _rel(Cd, -0.5 * ref + 2.0 * C0.double()) < tol
+    out2 = kernels.gemm_nn(E.to(_dev()), V.to(_dev()))
+    assert torch.equal(out, out2), "fixed-order slab reduction must be bit-reproducible"

@@ -64,6 +64,12 @@ int gemm_lower_launch(const float *A, const float *B, float *C, int64_t n, int64
 int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int64_t maxM, int64_t maxN, float alpha,
                         float beta, hipStream_t stream);
 
+// skinny.hip: out[K x P] = alpha * coef[K x n] @ V[n x P] + beta * out for K <= 16 (HBM-bound streaming)
+bool skinny_applicable(int64_t M, int64_t N, int64_t K);
+size_t skinny_workspace_bytes(int64_t K, int64_t n, int64_t P);
+int skinny_nn_launch(const float *coef, int64_t ldc_, const float *V, int64_t ldv, float *out, int64_t ldo, int64_t K,
+                     int64_t n, int64_t P, float alpha, float beta, void *ws, size_t ws_bytes, hipStream_t stream);
+
 // profile.hip: optional event timing.  kind 0 = Gram SYRK (work = flops), 1 = symv (work = bytes).
 bool prof_enabled();
 int prof_stride();

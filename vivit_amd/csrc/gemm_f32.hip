@@ -516,7 +516,14 @@ int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float
                      static_cast<hipStream_t>(stream));
 }
 
-size_t vivit_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) { return gemm_workspace_bytes(m, n, k, false); }
+size_t vivit_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  size_t b = gemm_workspace_bytes(m, n, k, false);
+  if (skinny_applicable(m, n, k)) {
+    const size_t sb = skinny_workspace_bytes(m, k, n);
+    if (sb > b) b = sb;
+  }
+  return b;
+}
 
 int vivit_gemm_nt_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k, int64_t lda,
                       int64_t ldb, int64_t ldc, float alpha, float beta, void *workspace, size_t workspace_bytes,
@@ -528,6 +535,11 @@ int vivit_gemm_nt_f32(const float *A, const float *B, float *C, int64_t m, int64
 int vivit_gemm_nn_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k, int64_t lda,
                       int64_t ldb, int64_t ldc, float alpha, float beta, void *workspace, size_t workspace_bytes,
                       void *stream) {
+  // few output rows: HBM-bound streaming kernel instead of a mostly idle MFMA tile (K7/K8)
+  if (skinny_applicable(m, n, k) && A && B && C && lda >= k && ldb >= n && ldc >= n &&
+      workspace_bytes >= skinny_workspace_bytes(m, k, n) && workspace)
+    return skinny_nn_launch(A, lda, B, ldb, C, ldc, m, k, n, alpha, beta, workspace, workspace_bytes,
+                            static_cast<hipStream_t>(stream));
   return gemm_launch(LAY_K, LAY_M, A, B, C, m, n, k, lda, ldb, ldc, alpha, beta, false, workspace, workspace_bytes,
                      static_cast<hipStream_t>(stream));
 }

@@ -16,6 +16,8 @@
 //
 // Storage: A is n x n row-major; only A[i][j], i >= j is read.  Reflector j (v_j, v_j[j+1] = 1)
 // is written to the dead upper-triangle row j: A[j][j+1 .. n-1]; tau, d, e go to vectors.
+#include <cstdlib>
+
 #include "common.h"
 #include "device_utils.h"
 #include "eig_internal.h"
@@ -522,7 +524,12 @@ int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, 
   trd_sigma_kernel<<<1, 256, 0, stream>>>(scanpart, ni, ws.scal);
   trd_scale_kernel<<<ni, 256, 0, stream>>>(A, lda, ni, ws.scal);
 
+  // Debug knob for counter collection (rocprofv3 --pmc dies on >10^4 dispatches): stop after this
+  // many columns.  The factorisation is then incomplete and its outputs meaningless.
+  const char *stop_env = getenv("VIVIT_SYTRD_STOP_AFTER");
+  const int64_t stop_after = stop_env ? atoll(stop_env) : -1;
   for (int64_t j0 = 0; j0 < n - 2; j0 += PB) {
+    if (stop_after >= 0 && j0 >= stop_after) break;
     const int bb = (int)((n - 2 - j0) < PB ? (n - 2 - j0) : PB);
     if (hipMemsetAsync(ws.vw, 0, sizeof(float) * 3 * PB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
     for (int jj = 0; jj < bb; ++jj) {

@@ -14,11 +14,15 @@ constexpr int SK_MAXK = 16;
 constexpr int SK_COLS = 1024;   // columns per workgroup (256 threads x float4)
 constexpr int SK_ROWS = 1024;   // rows per chunk
 
+constexpr int SK_SUB = 256;  // rows whose coefficients are staged in LDS at a time
+
 template <int KK, bool VEC>
 __global__ __launch_bounds__(256) void skinny_nn_kernel(const float *__restrict__ coef, int64_t ldc_,
                                                         const float *__restrict__ V, int64_t ldv, int64_t n, int64_t P,
                                                         float *__restrict__ part, int Kact) {
-  const int64_t c = (int64_t)blockIdx.x * SK_COLS + 4 * threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float sc[SK_SUB * KK];  // [row][k]: one broadcast read per row
+  const int tid = threadIdx.x;
+  const int64_t c = (int64_t)blockIdx.x * SK_COLS + 4 * tid;
   const int64_t r0 = (int64_t)blockIdx.y * SK_ROWS;
   const int64_t r1 = r0 + SK_ROWS < n ? r0 + SK_ROWS : n;
   float4 acc[KK];
@@ -26,41 +30,56 @@ __global__ __launch_bounds__(256) void skinny_nn_kernel(const float *__restrict_
   for (int k = 0; k < KK; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool colok = c < P;
   const int64_t cc = colok ? c : 0;
-  for (int64_t i = r0; i < r1; i += 8) {
-    float4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t row = (i + u < r1) ? i + u : r1 - 1;
-      if constexpr (VEC) {
-        v[u] = *reinterpret_cast<const float4 *>(V + row * ldv + cc);
-      } else {
-        const float *q = V + row * ldv;
-        v[u] = make_float4(q[cc], q[cc + 1 < P ? cc + 1 : cc], q[cc + 2 < P ? cc + 2 : cc], q[cc + 3 < P ? cc + 3 : cc]);
-      }
+  for (int64_t s0 = r0; s0 < r1; s0 += SK_SUB) {
+    __syncthreads();
+    // stage coef[k][s0 + rr] -> sc[rr][k] (zero beyond the chunk / beyond Kact)
+    for (int idx = tid; idx < SK_SUB * KK; idx += 256) {
+      const int k = idx / SK_SUB, rr = idx - k * SK_SUB;
+      const int64_t row = s0 + rr;
+      const bool ok = k < Kact && row < r1;
+      const float a = coef[(int64_t)(ok ? k : 0) * ldc_ + (ok ? row : r0)];
+      sc[rr * KK + k] = ok ? a : 0.f;
     }
+    __syncthreads();
+    const int64_t send = s0 + SK_SUB < r1 ? s0 + SK_SUB : r1;
+    for (int64_t i = s0; i < send; i += 8) {
+      float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool rowok = i + u < r1;
-      const int64_t row = rowok ? i + u : r1 - 1;
+      for (int u = 0; u < 8; ++u) {
+        const int64_t row = (i + u < send) ? i + u : send - 1;   // clamped duplicate, its coefficients are zero
+        if constexpr (VEC) {
+          v[u] = *reinterpret_cast<const float4 *>(V + row * ldv + cc);
+        } else {
+          const float *q = V + row * ldv;
+          v[u] = make_float4(q[cc], q[cc + 1 < P ? cc + 1 : cc], q[cc + 2 < P ? cc + 2 : cc], q[cc + 3 < P ? cc + 3 : cc]);
+        }
+      }
 #pragma unroll
-      for (int k = 0; k < KK; ++k) {
-        const float a = (rowok && k < Kact) ? coef[(int64_t)(k < Kact ? k : 0) * ldc_ + row] : 0.f;
-        acc[k].x += a * v[u].x; acc[k].y += a * v[u].y; acc[k].z += a * v[u].z; acc[k].w += a * v[u].w;
+      for (int u = 0; u < 8; ++u) {
+        const int rr = (int)(i - s0) + u;   // < SK_SUB + 8; rows past `send` hold zeros or are clamped below
+        const float *crow = sc + (rr < SK_SUB ? rr : SK_SUB - 1) * KK;
+        const float live = (i + u < send) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+          const float a = crow[k] * live;
+          acc[k].x += a * v[u].x; acc[k].y += a * v[u].y; acc[k].z += a * v[u].z; acc[k].w += a * v[u].w;
+        }
       }
     }
   }
   if (!colok) return;
 #pragma unroll
   for (int k = 0; k < KK; ++k) {
-    if (k >= Kact) break;
-    float *o = part + ((int64_t)blockIdx.y * Kact + k) * P + c;
-    if (VEC) {
-      *reinterpret_cast<float4 *>(o) = acc[k];
-    } else {
-      o[0] = acc[k].x;
-      if (c + 1 < P) o[1] = acc[k].y;
-      if (c + 2 < P) o[2] = acc[k].z;
-      if (c + 3 < P) o[3] = acc[k].w;
+    if (k < Kact) {
+      float *o = part + ((int64_t)blockIdx.y * Kact + k) * P + c;
+      if (VEC) {
+        *reinterpret_cast<float4 *>(o) = acc[k];
+      } else {
+        o[0] = acc[k].x;
+        if (c + 1 < P) o[1] = acc[k].y;
+        if (c + 2 < P) o[2] = acc[k].z;
+        if (c + 3 < P) o[3] = acc[k].w;
+      }
     }
   }
 }

@@ -118,6 +118,16 @@ size_t vivit_sytrd_f32_workspace_bytes(int64_t n);
 int vivit_sytrd_f32(float *A, int64_t n, int64_t lda, float *d, float *e, float *tau,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Stage 1b of the two-stage path, exported for testing: symmetric BAND -> tridiagonal by bulge
+ * chasing.  Half bandwidth NB = vivit_sb2st_half_bandwidth() (64).  AB: [n][2*NB+1] row-band
+ * layout, AB[i][j - i + 2*NB] = A[i][j] for i - 2*NB <= j <= i (entries with i - j > NB must be
+ * zero on entry: bulge room); destroyed.  d: [n], e: [n].  R2: [n][n], row s receives the
+ * Householder vectors of sweep s (for the back-transformation). */
+int vivit_sb2st_half_bandwidth(void);
+size_t vivit_sb2st_f32_workspace_bytes(int64_t n);
+int vivit_sb2st_f32(float *AB, int64_t n, float *d, float *e, float *R2, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
 /* Eigen-decomposition of a symmetric TRIDIAGONAL matrix (d: [n] diagonal, e: [n-1]
  * off-diagonal; both destroyed).  Stage 2 of vivit_symeig_f32, exported for testing. */
 size_t vivit_stedc_f32_workspace_bytes(int64_t n, int want_vectors);

@@ -211,6 +211,28 @@ def sytrd(G: torch.Tensor):
     return d, e, tau, A
 
 
+def sb2st(AB: torch.Tensor):
+    """Band -> tridiagonal by bulge chasing (testing). ``AB``: [n, 2*NB+1] row-band layout.
+    Returns ``(d, e, R2, tau2)``."""
+    _require_device(AB)
+    lib = _lib.load()
+    n = AB.shape[0]
+    nb = lib.vivit_sb2st_half_bandwidth()
+    assert AB.shape[1] == 2 * nb + 1 and AB.is_contiguous()
+    AB = AB.clone()
+    d = torch.empty(n, dtype=torch.float32, device=AB.device)
+    e = torch.empty(n, dtype=torch.float32, device=AB.device)
+    R2 = torch.zeros((n, n), dtype=torch.float32, device=AB.device)
+    nbytes = lib.vivit_sb2st_f32_workspace_bytes(n)
+    ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=AB.device)
+    st = lib.vivit_sb2st_f32(AB.data_ptr(), n, d.data_ptr(), e.data_ptr(), R2.data_ptr(), ws.data_ptr(), ws.numel(), _stream(AB))
+    _lib.check(st, "vivit_sb2st_f32")
+    off = (-ws.data_ptr()) % 256
+    nk = -(-n // nb) + 1
+    tau2 = ws[off : off + 4 * n * nk].view(torch.float32).view(n, nk).clone()
+    return d, e[: n - 1], R2, tau2
+
+
 def dir_curvature(GE, evals, C: int, N: int, scale: float):
     """``lambdas[n,k] = scale * sum_c GE[(c,n),k]^2 / evals[k]`` (K6 epilogue)."""
     if _TEST_BACKEND is not None:

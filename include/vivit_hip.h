@@ -118,6 +118,15 @@ size_t vivit_sytrd_f32_workspace_bytes(int64_t n);
 int vivit_sytrd_f32(float *A, int64_t n, int64_t lda, float *d, float *e, float *tau,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Stage 1a of the two-stage path, exported for testing: full symmetric A (BOTH triangles valid,
+ * lda >= n) -> symmetric band with half bandwidth vivit_sb2st_half_bandwidth() by blocked
+ * Householder QR of the sub-band panels and two-sided MFMA updates.  On return the band is in A
+ * (A[i][j], 0 <= i-j <= NB) and, copied, in AB ([n][2*NB+1] row-band layout); reflector c of
+ * panel p sits in A[p*NB + c][(p+1)*NB + c ..]; tau1: [n]. */
+size_t vivit_sy2sb_f32_workspace_bytes(int64_t n);
+int vivit_sy2sb_f32(float *A, int64_t n, int64_t lda, float *AB, float *tau1, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
 /* Stage 1b of the two-stage path, exported for testing: symmetric BAND -> tridiagonal by bulge
  * chasing.  Half bandwidth NB = vivit_sb2st_half_bandwidth() (64).  AB: [n][2*NB+1] row-band
  * layout, AB[i][j - i + 2*NB] = A[i][j] for i - 2*NB <= j <= i (entries with i - j > NB must be

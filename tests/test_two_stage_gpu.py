@@ -49,3 +49,54 @@ def test_sb2st_eigenvalues_and_q2(n):
         T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
         assert np.abs(Q @ T @ Q.T - band).max() <= 2e-5 * scale
         assert np.abs(Q.T @ Q - np.eye(n)).max() <= 1e-5
+
+
+def from_rowband(AB):
+    n = AB.shape[0]
+    band = np.zeros((n, n))
+    for i in range(n):
+        lo = max(0, i - NB)
+        band[i, lo : i + 1] = AB[i, lo - i + 2 * NB : 2 * NB + 1]
+    return band + np.tril(band, -1).T
+
+
+@pytest.mark.parametrize("n", [65, 66, 100, 128, 129, 200, 300, 1000, 2048])
+def test_sy2sb_preserves_spectrum(n):
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(n)
+    M = torch.randn(n, n, generator=g, dtype=torch.float64)
+    S = ((M + M.T) / 2).float()
+    AB, tau1, A = kernels.sy2sb(S.to(DEV))
+    ABh = AB.cpu().double().numpy()
+    assert np.abs(ABh[:, :NB]).max() == 0.0  # bulge room is zero
+    band = from_rowband(ABh)
+    ref = np.linalg.eigvalsh(S.double().numpy())
+    w = np.linalg.eigvalsh(band)
+    scale = np.abs(ref).max()
+    assert np.abs(w - ref).max() <= 5e-6 * scale, np.abs(w - ref).max() / scale
+    if n <= 300:
+        # S = Q1 B Q1^T with Q1 from the stored reflector rows
+        Ah, t1 = A.cpu().double().numpy(), tau1.cpu().double().numpy()
+        Q = np.eye(n)
+        for j0 in range(0, n - NB, NB):
+            mp = n - j0 - NB
+            for c in range(min(NB, mp)):
+                v = np.zeros(n)
+                v[j0 + NB + c :] = Ah[j0 + c, j0 + NB + c :]
+                assert abs(v[j0 + NB + c] - 1.0) < 1e-12
+                Q = Q - t1[j0 + c] * np.outer(Q @ v, v)
+        assert np.abs(Q @ band @ Q.T - S.double().numpy()).max() <= 3e-5 * scale
+
+
+@pytest.mark.parametrize("n", [2048, 3000])
+@pytest.mark.parametrize("kind", ["dense", "lowrank", "decay"])
+def test_two_stage_eigenvalues(kind, n):
+    """values-only symeig takes the two-stage path for n >= 2048."""
+    from test_symeig_large_gpu import make_matrix
+    from vivit_amd import kernels
+
+    S = make_matrix(kind, n)
+    ref = np.linalg.eigvalsh(S.double().numpy())
+    w, _ = kernels.symeig(S.to(DEV), eigenvectors=False)
+    assert np.abs(w.cpu().double().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()

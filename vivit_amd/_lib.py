@@ -32,6 +32,8 @@ SIGNATURES = {
     "vivit_symeig_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
     "vivit_sytrd_f32_workspace_bytes": (_sz, [_i64]),
     "vivit_sytrd_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
+    "vivit_sy2sb_f32_workspace_bytes": (_sz, [_i64]),
+    "vivit_sy2sb_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _sz, _ptr]),
     "vivit_sb2st_half_bandwidth": (_int, []),
     "vivit_sb2st_f32_workspace_bytes": (_sz, [_i64]),
     "vivit_sb2st_f32": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),

@@ -32,6 +32,19 @@ int stebz_launch(const float *d, const float *e, int64_t n, float *w, const floa
 int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *w, float *Z,
                      int64_t ldz, const float *scal, int32_t *info, hipStream_t stream);
 
+// sy2sb.hip / sb2st.hip (two-stage tridiagonalisation)
+size_t sy2sb_workspace_bytes(int64_t n);
+int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_out, hipStream_t stream);
+int sy2sb_extract_band_launch(const float *A, int64_t lda, int64_t n, float *AB, hipStream_t stream);
+int sb2st_num_levels(int64_t n);
+int64_t sb2st_ring_rows(int64_t n);
+int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ldr, int64_t r2rows, float *tau2,
+                 hipStream_t stream);
+// sytrd.hip: scan (amax, non-finite flag) + LAPACK-style scaling of the lower triangle; scal: [16], part: [2n]
+int prescale_launch(float *A, int64_t n, int64_t lda, float *scal, float *part, hipStream_t stream);
+// elementwise.hip
+int symmetrize_launch(float *G, int64_t n, int64_t ldg, hipStream_t stream);
+
 // info = n when the scan flagged non-finite input (scal[2] != 0)
 int info_finalize_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream);
 

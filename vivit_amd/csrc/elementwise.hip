@@ -1,6 +1,7 @@
 // HBM-bound epilogue kernels of the Gram path (K1', K5/K6 epilogues, K10) for gfx950.
 // All are grid-stride, 16-byte vectorised where the layout allows, and free of float atomics.
 #include "common.h"
+#include "eig_internal.h"
 
 namespace vivit {
 
@@ -128,6 +129,12 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(float *__restrict__ G, 
   }
 }
 
+int symmetrize_launch(float *G, int64_t n, int64_t ldg, hipStream_t stream) {
+  const int64_t nb = cdiv(n, 32);
+  symmetrize_kernel<<<(unsigned)(nb * (nb + 1) / 2), 256, 0, stream>>>(G, n, ldg);
+  return launch_status();
+}
+
 } // namespace vivit
 
 using namespace vivit;
@@ -204,9 +211,7 @@ int vivit_symmetrize_lower_f32(float *G, int64_t n, int64_t ldg, void *stream) {
   if (n < 0 || ldg < n) return VIVIT_E_BADARG;
   if (n == 0) return VIVIT_OK;
   if (!G) return VIVIT_E_BADARG;
-  const int64_t nb = cdiv(n, 32);
-  symmetrize_kernel<<<(unsigned)(nb * (nb + 1) / 2), 256, 0, static_cast<hipStream_t>(stream)>>>(G, n, ldg);
-  return launch_status();
+  return symmetrize_launch(G, n, ldg, static_cast<hipStream_t>(stream));
 }
 
 } // extern "C"

@@ -426,7 +426,7 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
   if (nsb * 256 > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
   dim3 grid((unsigned)(nsb * 256), (unsigned)p.ksplit, 1);
   dim3 block(256, 1, 1);
-  const bool prof = syrk && prof_enabled();
+  const bool prof = syrk && A == B && prof_enabled();  // only the Gram SYRK is profiled as such
   if (prof) prof_begin(0, (double)M * (double)(M + 1) * (double)K, stream);
   if (alay == LAY_K && blay == LAY_K)
     gemm_kernel<LAY_K, LAY_K><<<grid, block, 0, stream>>>(p);

@@ -31,7 +31,7 @@ __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of
 
 __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB, int n, int t, int s_lo,
                                                          float *__restrict__ R2, int64_t ldr, float *__restrict__ tau2,
-                                                         int nk) {
+                                                         int nk, int rmod) {
   __shared__ float E[NB][NB + 1];
   __shared__ float D[NB][NB + 1];
   __shared__ float v[NB], pv[NB], z[NB], pw[NB];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
     E[r][c] = ev;
   }
   if (tid < NB) {
-    pv[tid] = (k > 0) ? R2[(int64_t)s * ldr + (c0 - NB + tid)] : 0.f;
+    pv[tid] = (k > 0) ? R2[(int64_t)(s % rmod) * ldr + (c0 - NB + tid)] : 0.f;
     v[tid] = 0.f;
   }
   if (tid == 0) sc[1] = (k > 0) ? tau2[(int64_t)s * nk + (k - 1)] : 0.f;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
     if (r < L && c <= r) AB[(int64_t)(c0 + r) * LDAB + (c - r + 2 * NB)] = D[r][c];
     if (k > 0 && r < L) AB[(int64_t)(c0 + r) * LDAB + (NB + c - r)] = E[r][c];
   }
-  if (R2 && tid < L) R2[(int64_t)s * ldr + c0 + tid] = v[tid];
+  if (tid < L) R2[(int64_t)(s % rmod) * ldr + c0 + tid] = v[tid];
   if (tid == 0) tau2[(int64_t)s * nk + k] = tau;
 }
 
@@ -148,11 +148,14 @@ __global__ __launch_bounds__(256) void sb2st_extract_kernel(const float *__restr
 }
 
 int sb2st_num_levels(int64_t n) { return (int)cdiv(n, NB) + 1; }
+int64_t sb2st_ring_rows(int64_t n) { const int64_t need = n / NB + 64; return need < n ? need : n; }
 
-// Reduce the band AB (destroyed) to tridiagonal (d, e).  R2: [n][ldr] reflector storage (row s holds
-// sweep s), tau2: [n][sb2st_num_levels(n)].  R2 may be nullptr only if the reflectors are not needed,
-// in which case a scratch row buffer of the same shape is still required by the chase itself.
-int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ldr, float *tau2, hipStream_t stream) {
+// Reduce the band AB (destroyed) to tridiagonal (d, e).  R2: [r2rows][ldr] reflector storage, sweep s
+// uses row s % r2rows (r2rows = n keeps every reflector for the back-transformation; a ring of
+// SB2ST_RING rows is enough for the chase itself when only eigenvalues are wanted);
+// tau2: [n][sb2st_num_levels(n)].
+int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ldr, int64_t r2rows, float *tau2,
+                 hipStream_t stream) {
   const int ni = (int)n;
   const int nk = sb2st_num_levels(n);
   if (n >= 3) {
@@ -164,7 +167,7 @@ int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ld
       const int64_t num = t * NB + 1 - n;
       if (num >= 0) s_lo = num / (2 * NB - 1) + 1;
       if (s_lo > s_hi) continue;
-      sb2st_task_kernel<<<(unsigned)(s_hi - s_lo + 1), 256, 0, stream>>>(AB, ni, (int)t, (int)s_lo, R2, ldr, tau2, nk);
+      sb2st_task_kernel<<<(unsigned)(s_hi - s_lo + 1), 256, 0, stream>>>(AB, ni, (int)t, (int)s_lo, R2, ldr, tau2, nk, (int)r2rows);
     }
   }
   sb2st_extract_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(AB, ni, d, e);
@@ -191,7 +194,7 @@ int vivit_sb2st_f32(float *AB, int64_t n, float *d, float *e, float *R2, void *w
   if (n < 1 || !AB || !d || !e || !R2) return VIVIT_E_BADARG;
   if (!workspace || workspace_bytes < vivit_sb2st_f32_workspace_bytes(n)) return VIVIT_E_WORKSPACE;
   float *tau2 = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
-  return sb2st_launch(AB, n, d, e, R2, n, tau2, static_cast<hipStream_t>(stream));
+  return sb2st_launch(AB, n, d, e, R2, n, n, tau2, static_cast<hipStream_t>(stream));
 }
 
 } // extern "C"

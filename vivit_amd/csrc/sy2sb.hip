@@ -1,0 +1,338 @@
+// Full symmetric -> symmetric band (half bandwidth NB = 64): stage 1 of the two-stage
+// tridiagonalisation.  All O(n^3) work is MFMA GEMM; the matrix is streamed O(n / NB) times instead
+// of the O(n) times of the one-stage reduction (sytrd.hip), which is what lifts the eigensolver off
+// the HBM roofline.
+//
+// Panel p (columns j0 = p*NB .. j0+NB-1): QR-factorise the block below the band,
+//   B = A[j0+NB:, j0:j0+NB] = Q R,  Q = I - V T V^T  (Householder, compact WY),
+// then update the trailing matrix two-sidedly,  A22 <- Q^T A22 Q = A22 - V W^T - W V^T  with
+//   P = A22 V,  X = P T,  W = X - 1/2 V (T^T (V^T X)).
+// Everything after the panel QR is GEMM-shaped and runs k-major (Vt = V^T rows, Pt, Xt, Wt) so that
+// the final update is one rank-2*NB GEMM over the lower tiles with a mirrored store (A22 is kept
+// fully symmetric in memory: the P = A22 V product is then a plain GEMM).
+//
+// The panel QR is column by column with two launches per column (reflector + partial dots, then
+// rank-1 update + next column's norm), 128-row tiles staged through LDS.
+//
+// Outputs: band entries stay in A (A[i][j], 0 <= i-j <= NB), reflector c of panel p goes to the
+// dead upper-triangle row j0+c: A[j0+c][j0+NB+c ..] (v[j0+NB+c] = 1), tau1[j0+c].
+#include "common.h"
+#include "device_utils.h"
+#include "eig_internal.h"
+
+namespace vivit {
+
+constexpr int SNB = 64;     // half bandwidth = panel width (must equal sb2st.hip's NB)
+constexpr int QT = 128;     // rows per workgroup tile in the panel QR
+
+struct Sy2sbWs {
+  float *pan;      // [n][SNB]   compact copy of the current panel block
+  float *stack;    // [3*SNB][n] Vt | Wt | Vt   (k-major, ld = n)
+  float *zpart;    // [nwg][SNB]
+  float *ssqpart;  // [nwg]
+  float *S, *T, *Y3, *S2;  // [SNB*SNB] each
+  float *tau1;     // [n]
+  float *betas;    // [SNB] diagonal of R of the current panel
+  void *gws;       // split-K workspace
+  size_t gws_bytes;
+};
+
+__global__ __launch_bounds__(256) void sb_panel_load_kernel(const float *__restrict__ A, int64_t lda, int64_t j0, int64_t mp,
+                                                            float *__restrict__ pan) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= mp * SNB) return;
+  const int64_t r = idx / SNB, c = idx - r * SNB;
+  pan[idx] = A[(j0 + SNB + r) * lda + j0 + c];
+}
+
+// partial sum of squares of column c below row c (rows r > c): used for column 0 of a panel
+__global__ __launch_bounds__(256) void qr_ssq_kernel(const float *__restrict__ pan, int64_t mp, int c, float *__restrict__ ssqpart) {
+  __shared__ float red[4];
+  const int64_t r = (int64_t)blockIdx.x * QT + (threadIdx.x >> 1);
+  float s = 0.f;
+  if ((threadIdx.x & 1) == 0 && r < mp && r > c) {
+    const float x = pan[r * SNB + c];
+    s = x * x;
+  }
+  s = block_sum(s, red, threadIdx.x);
+  if (threadIdx.x == 0) ssqpart[blockIdx.x] = s;
+}
+
+// Column c, launch 1: reflector scalars (redundantly per workgroup), v for this tile's rows, partial
+// z[cc] = sum_r v_r pan[r][cc] (cc > c).
+__global__ __launch_bounds__(256) void qr_col1_kernel(float *__restrict__ pan, int64_t mp, int c, int npart,
+                                                      const float *__restrict__ ssqpart, float *__restrict__ zpart,
+                                                      float *__restrict__ stack, int64_t lds_, int64_t gi0,
+                                                      float *__restrict__ A, int64_t lda, int64_t j0,
+                                                      float *__restrict__ tau1, float *__restrict__ betas) {
+  __shared__ float tile[QT][SNB + 1];
+  __shared__ float vs[QT];
+  __shared__ float zq[4][SNB];
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float s = 0.f;
+  for (int t = tid; t < npart; t += 256) s += ssqpart[t];
+  const float ssq = block_sum(s, red, tid);
+  const float alpha = pan[(int64_t)c * SNB + c];
+  float tau = 0.f, beta = alpha, scal = 0.f;
+  if (ssq > 0.f) {
+    beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
+    tau = (beta - alpha) / beta;
+    scal = 1.f / (alpha - beta);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * QT;
+  for (int idx = tid; idx < QT * SNB; idx += 256) {
+    const int rl = idx / SNB, cc = idx - rl * SNB;
+    const int64_t r = r0 + rl;
+    tile[rl][cc] = (r < mp) ? pan[r * SNB + cc] : 0.f;
+  }
+  __syncthreads();
+  if (tid < QT) {
+    const int64_t r = r0 + tid;
+    float v = 0.f;
+    if (r < mp) {
+      if (r == c) v = 1.f;
+      else if (r > c) v = tile[tid][c] * scal;
+      // k-major copies for the GEMMs and the reflector row for the back-transformation
+      stack[(int64_t)c * lds_ + gi0 + r] = v;
+      stack[(int64_t)(2 * SNB + c) * lds_ + gi0 + r] = v;
+      if (r >= c) A[(j0 + c) * lda + gi0 + r] = v;
+    }
+    vs[tid] = v;
+  }
+  __syncthreads();
+  {
+    const int cc = tid & 63, q = tid >> 6;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int rl = q * 32; rl < q * 32 + 32; ++rl) acc += vs[rl] * tile[rl][cc];
+    zq[q][cc] = acc;
+  }
+  __syncthreads();
+  if (tid < SNB) zpart[(int64_t)blockIdx.x * SNB + tid] = (zq[0][tid] + zq[1][tid]) + (zq[2][tid] + zq[3][tid]);
+  // (pan[c][c] itself is left alone: other workgroups of this launch still read it as alpha)
+  if (blockIdx.x == 0 && tid == 0) { tau1[j0 + c] = tau; betas[c] = beta; }
+}
+
+// Column c, launch 2: z = sum of partials; pan[r][cc] -= tau v_r z[cc] (cc > c, r >= c); partial
+// sum of squares of column c+1 below row c+1.
+__global__ __launch_bounds__(256) void qr_col2_kernel(float *__restrict__ pan, int64_t mp, int c, int nwg,
+                                                      const float *__restrict__ zpart, const float *__restrict__ stack,
+                                                      int64_t lds_, int64_t gi0, const float *__restrict__ tau1, int64_t j0,
+                                                      float *__restrict__ ssqpart) {
+  __shared__ float zs[SNB];
+  __shared__ float zq[4][SNB];
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  {
+    const int cc = tid & 63, q = tid >> 6;
+    float acc = 0.f;
+    for (int w = q; w < nwg; w += 4) acc += zpart[(int64_t)w * SNB + cc];
+    zq[q][cc] = acc;
+  }
+  __syncthreads();
+  if (tid < SNB) zs[tid] = (zq[0][tid] + zq[1][tid]) + (zq[2][tid] + zq[3][tid]);
+  __syncthreads();
+  const float tau = tau1[j0 + c];
+  const int64_t r = (int64_t)blockIdx.x * QT + (tid >> 1);
+  const int half = tid & 1;
+  float sq = 0.f;
+  if (r < mp && r >= c) {
+    const float tv = tau * stack[(int64_t)c * lds_ + gi0 + r];
+    float *row = pan + r * SNB;
+    for (int cc = half * 32; cc < half * 32 + 32; ++cc) {
+      if (cc > c) {
+        const float x = row[cc] - tv * zs[cc];
+        row[cc] = x;
+        if (cc == c + 1 && r > c + 1) sq = x * x;
+      }
+    }
+  }
+  sq = block_sum(sq, red, tid);
+  if (tid == 0) ssqpart[blockIdx.x] = sq;
+}
+
+// R (upper triangular, rows 0..min(NB, mp)-1 of the factored panel) back into A; zeros below it inside
+// the band rows.
+__global__ __launch_bounds__(256) void sb_panel_store_kernel(float *__restrict__ A, int64_t lda, int64_t j0, int64_t mp,
+                                                             const float *__restrict__ pan, const float *__restrict__ betas) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= SNB * SNB) return;
+  const int r = idx / SNB, c = idx - r * SNB;
+  if (r >= mp) return;
+  A[(j0 + SNB + r) * lda + j0 + c] = (r < c) ? pan[(int64_t)r * SNB + c] : (r == c ? betas[c] : 0.f);
+}
+
+// T (nb x nb upper triangular, forward/columnwise larft) from S = V^T V and tau; nb <= 128
+__global__ __launch_bounds__(128) void larft_kernel(const float *__restrict__ S, const float *__restrict__ tau, int nb,
+                                                    int nvalid, float *__restrict__ T) {
+  __shared__ float Ts[128][129];
+  __shared__ float col[128];
+  const int r = threadIdx.x;
+  for (int c = 0; c < nb; ++c) Ts[r][c] = 0.f;
+  __syncthreads();
+  for (int i = 0; i < nb; ++i) {
+    const float ti = (i < nvalid) ? tau[i] : 0.f;
+    float acc = 0.f;
+    if (r < i)
+      for (int c = r; c < i; ++c) acc += Ts[r][c] * S[c * nb + i];
+    col[r] = -ti * acc;
+    __syncthreads();
+    if (r < i) Ts[r][i] = col[r];
+    if (r == i) Ts[i][i] = ti;
+    __syncthreads();
+  }
+  if (r < nb)
+    for (int c = 0; c < nb; ++c) T[r * nb + c] = Ts[r][c];
+}
+
+// AB[i][d] = A[i][i - 2*NB + d] for NB <= d <= 2*NB (0 <= i-j <= NB), zero bulge room for d < NB
+__global__ __launch_bounds__(256) void sb_extract_band_kernel(const float *__restrict__ A, int64_t lda, int64_t n,
+                                                              float *__restrict__ AB) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int LD = 2 * SNB + 1;
+  if (idx >= n * LD) return;
+  const int64_t i = idx / LD;
+  const int d = (int)(idx - i * LD);
+  const int64_t j = i - 2 * SNB + d;
+  AB[idx] = (d >= SNB && j >= 0) ? A[i * lda + j] : 0.f;
+}
+
+// split-K scratch: the largest need over the GEMM shapes used per panel (trailing size mp <= n)
+static size_t sy2sb_gemm_ws_bytes(int64_t n) {
+  size_t m = 0;
+  for (int64_t mp = 1; mp <= n; mp = mp < 4096 ? mp * 2 : mp + 4096) {
+    const int64_t q = mp < n ? mp : n;
+    size_t a = gemm_workspace_bytes(SNB, SNB, q, false);
+    size_t b = gemm_workspace_bytes(SNB, q, q, false);
+    size_t c = gemm_workspace_bytes(SNB, q, SNB, false);
+    m = a > m ? a : m; m = b > m ? b : m; m = c > m ? c : m;
+  }
+  size_t a = gemm_workspace_bytes(SNB, SNB, n, false), b = gemm_workspace_bytes(SNB, n, n, false);
+  m = a > m ? a : m; m = b > m ? b : m;
+  return m * 2;  // generous: shapes between the sampled mp values
+}
+
+size_t sy2sb_workspace_bytes(int64_t n) {
+  const int64_t nwg = cdiv(n, QT) + 1;
+  size_t b = 0;
+  b += align_up(sizeof(float) * n * SNB, 256);          // pan
+  b += align_up(sizeof(float) * 3 * SNB * n, 256);      // stack
+  b += align_up(sizeof(float) * nwg * SNB, 256);        // zpart
+  b += align_up(sizeof(float) * nwg, 256);              // ssqpart
+  b += align_up(sizeof(float) * SNB * SNB, 256) * 4;    // S T Y3 S2
+  b += align_up(sizeof(float) * n, 256);                // tau1
+  b += align_up(sizeof(float) * SNB, 256);              // betas
+  b += align_up(sy2sb_gemm_ws_bytes(n), 256);
+  return b + 1024;
+}
+
+// Reduce A (n x n, FULL symmetric storage, lda) to band form in place.  tau1_out receives the pointer
+// to the reflector scalars (inside the workspace).
+int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_out, hipStream_t stream) {
+  char *p = reinterpret_cast<char *>(align_up(reinterpret_cast<uintptr_t>(wsbase), 256));
+  auto take = [&](size_t bytes) {
+    char *r = p;
+    p += align_up(bytes, 256);
+    return r;
+  };
+  const int64_t nwg = cdiv(n, QT) + 1;
+  Sy2sbWs ws;
+  ws.pan = (float *)take(sizeof(float) * n * SNB);
+  ws.stack = (float *)take(sizeof(float) * 3 * SNB * n);
+  ws.zpart = (float *)take(sizeof(float) * nwg * SNB);
+  ws.ssqpart = (float *)take(sizeof(float) * nwg);
+  ws.S = (float *)take(sizeof(float) * SNB * SNB);
+  ws.T = (float *)take(sizeof(float) * SNB * SNB);
+  ws.Y3 = (float *)take(sizeof(float) * SNB * SNB);
+  ws.S2 = (float *)take(sizeof(float) * SNB * SNB);
+  ws.tau1 = (float *)take(sizeof(float) * n);
+  ws.betas = (float *)take(sizeof(float) * SNB);
+  ws.gws_bytes = sy2sb_gemm_ws_bytes(n);
+  ws.gws = take(ws.gws_bytes);
+  *tau1_out = ws.tau1;
+  if (hipMemsetAsync(ws.tau1, 0, sizeof(float) * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+
+  for (int64_t j0 = 0; j0 + SNB < n; j0 += SNB) {
+    const int64_t mp = n - j0 - SNB;      // rows of the block below the band
+    const int64_t gi0 = j0 + SNB;         // global index of block row 0
+    const int ncol = (int)(mp < SNB ? mp : SNB);
+    const int g = (int)cdiv(mp, QT);
+    if (hipMemsetAsync(ws.stack, 0, sizeof(float) * 3 * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    sb_panel_load_kernel<<<(unsigned)cdiv(mp * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan);
+    qr_ssq_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, 0, ws.ssqpart);
+    for (int c = 0; c < ncol; ++c) {
+      qr_col1_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, g, ws.ssqpart, ws.zpart, ws.stack, n, gi0, A, lda, j0, ws.tau1, ws.betas);
+      qr_col2_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, g, ws.zpart, ws.stack, n, gi0, ws.tau1, j0, ws.ssqpart);
+    }
+    sb_panel_store_kernel<<<(unsigned)cdiv(SNB * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan, ws.betas);
+
+    // ---- two-sided update of A22 = A[gi0:, gi0:]  (mp x mp), all operands k-major with ld = n
+    float *Vt = ws.stack + gi0;                    // [SNB][mp]
+    float *Wt = ws.stack + (int64_t)SNB * n + gi0; // [SNB][mp]   (receives Pt, then Xt, then Wt)
+    float *A22 = A + gi0 * lda + gi0;
+    int st;
+    // S = Vt Vt^T, T = larft(S, tau)
+    st = gemm_launch(LAY_K, LAY_K, Vt, Vt, ws.S, SNB, SNB, mp, n, n, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    larft_kernel<<<1, 128, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
+    // Pt = Vt A22                      [SNB x mp]   (A22 symmetric: B operand k-major = A22 itself)
+    st = gemm_launch(LAY_K, LAY_M, Vt, A22, Wt, SNB, mp, mp, n, lda, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // Xt = T^T Pt  (in place is not possible for a GEMM: go through the third stack block as scratch)
+    float *Xt = ws.stack + (int64_t)2 * SNB * n + gi0;
+    st = gemm_launch(LAY_M, LAY_M, ws.T, Wt, Xt, SNB, mp, SNB, SNB, n, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // S2^T = Xt Vt^T                   [SNB x SNB]
+    st = gemm_launch(LAY_K, LAY_K, Xt, Vt, ws.S2, SNB, SNB, mp, n, n, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // Y3 = S2^T T
+    st = gemm_launch(LAY_K, LAY_M, ws.S2, ws.T, ws.Y3, SNB, SNB, SNB, SNB, SNB, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // Wt = Xt - 1/2 Y3 Vt  -> second stack block
+    if (hipMemcpy2DAsync(Wt, sizeof(float) * n, Xt, sizeof(float) * n, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
+                         stream) != hipSuccess)
+      return VIVIT_E_LAUNCH;
+    st = gemm_launch(LAY_K, LAY_M, ws.Y3, Vt, Wt, SNB, mp, SNB, SNB, n, n, -0.5f, 1.f, false, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // third block back to Vt:  [Vt; Wt] and [Wt; Vt] contiguous
+    if (hipMemcpy2DAsync(Xt, sizeof(float) * n, Vt, sizeof(float) * n, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
+                         stream) != hipSuccess)
+      return VIVIT_E_LAUNCH;
+    // A22 -= [V W] [W V]^T   (lower tiles on MFMA, mirrored store keeps A22 fully symmetric)
+    st = gemm_launch(LAY_M, LAY_M, Vt, Wt, A22, mp, mp, 2 * SNB, n, n, lda, -1.f, 1.f, true, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+  }
+  return launch_status();
+}
+
+int sy2sb_extract_band_launch(const float *A, int64_t lda, int64_t n, float *AB, hipStream_t stream) {
+  sb_extract_band_kernel<<<(unsigned)cdiv(n * (2 * SNB + 1), 256), 256, 0, stream>>>(A, lda, n, AB);
+  return launch_status();
+}
+
+} // namespace vivit
+
+using namespace vivit;
+
+extern "C" {
+
+size_t vivit_sy2sb_f32_workspace_bytes(int64_t n) { return n > 0 ? sy2sb_workspace_bytes(n) : 0; }
+
+// Stage 1a of the two-stage path, exported for testing: A (FULL symmetric storage) -> band form in
+// place, band copied to AB in the row-band layout of vivit_sb2st_f32; tau1: [n] reflector scalars.
+int vivit_sy2sb_f32(float *A, int64_t n, int64_t lda, float *AB, float *tau1, void *workspace, size_t workspace_bytes,
+                    void *stream) {
+  if (n < 1 || !A || !AB || !tau1 || lda < n) return VIVIT_E_BADARG;
+  if (!workspace || workspace_bytes < sy2sb_workspace_bytes(n)) return VIVIT_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float *t1;
+  int st = sy2sb_launch(A, n, lda, workspace, &t1, s);
+  if (st != VIVIT_OK) return st;
+  st = sy2sb_extract_band_launch(A, lda, n, AB, s);
+  if (st != VIVIT_OK) return st;
+  if (hipMemcpyAsync(tau1, t1, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return VIVIT_E_LAUNCH;
+  return VIVIT_OK;
+}
+
+} // extern "C"

@@ -8,6 +8,8 @@
 //   Zt <- Zt (I - Y T Y^T)^T = Zt - ((Zt Y) T^T) Y^T,
 // three GEMMs per block of KB reflectors whose rows Y^T are exactly the rows sytrd left in the
 // upper triangle of A, and a final permuted transpose delivers Tensor.symeig's column layout.
+#include <cstdlib>
+
 #include "common.h"
 #include "device_utils.h"
 #include "eig_internal.h"
@@ -62,11 +64,73 @@ static size_t bt_workspace_bytes(int64_t n) {
   return b + 512;
 }
 
+// ---- two-stage reduction (sy2sb + sb2st) --------------------------------------------------------
+constexpr int TS_NB = 64;
+
+// 1 = use the two-stage tridiagonalisation.  Values-only solves switch at n >= 2048 (the band
+// reduction is MFMA-bound, the one-stage reduction HBM-bound); VIVIT_TWO_STAGE=0/1 overrides.
+static bool use_two_stage(int64_t n, bool vectors) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char *e = getenv("VIVIT_TWO_STAGE");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced >= 0) return forced != 0 && n > 2 * TS_NB;
+  return !vectors && n >= 2048;
+}
+
+static size_t two_stage_workspace_bytes(int64_t n, bool vectors) {
+  size_t b = 0;
+  b += align_up(sizeof(float) * 16, 256) + align_up(sizeof(float) * 2 * n, 256);       // scal, scan partials
+  b += align_up(sy2sb_workspace_bytes(n), 256);
+  b += align_up(sizeof(float) * n * (2 * TS_NB + 1), 256);                              // AB
+  b += align_up(sizeof(float) * (vectors ? n : sb2st_ring_rows(n)) * n, 256);           // R2
+  b += align_up(sizeof(float) * n * sb2st_num_levels(n), 256);                          // tau2
+  b += align_up(sizeof(float) * n, 256) * 2;                                            // d, e
+  return b + 1024;
+}
+
 size_t symeig_large_workspace_bytes(int64_t n, bool vectors) {
-  size_t b = align_up(sizeof(float) * sytrd_workspace_floats(n), 256) + 512;
+  size_t one = align_up(sizeof(float) * sytrd_workspace_floats(n), 256) + 512;
+  size_t two = two_stage_workspace_bytes(n, vectors);
+  size_t b = one > two ? one : two;   // either reduction may be selected at run time
   b += stedc_workspace_bytes(n, vectors);
   if (vectors) b += bt_workspace_bytes(n);
   return b;
+}
+
+// values only: prescale -> mirror -> band -> tridiagonal -> bisection
+static int symeig_two_stage_values(float *A, int64_t n, int64_t lda, float *w, void *ws, int32_t *info,
+                                   hipStream_t stream) {
+  char *p = reinterpret_cast<char *>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+  auto take = [&](size_t bytes) {
+    char *r = p;
+    p += align_up(bytes, 256);
+    return r;
+  };
+  float *scal = (float *)take(sizeof(float) * 16);
+  float *part = (float *)take(sizeof(float) * 2 * n);
+  void *sbws = take(sy2sb_workspace_bytes(n));
+  float *AB = (float *)take(sizeof(float) * n * (2 * TS_NB + 1));
+  const int64_t rrows = sb2st_ring_rows(n);
+  float *R2 = (float *)take(sizeof(float) * rrows * n);
+  float *tau2 = (float *)take(sizeof(float) * n * sb2st_num_levels(n));
+  float *d = (float *)take(sizeof(float) * n);
+  float *e = (float *)take(sizeof(float) * n);
+  int st = prescale_launch(A, n, lda, scal, part, stream);
+  if (st != VIVIT_OK) return st;
+  st = symmetrize_launch(A, n, lda, stream);
+  if (st != VIVIT_OK) return st;
+  float *tau1;
+  st = sy2sb_launch(A, n, lda, sbws, &tau1, stream);
+  if (st != VIVIT_OK) return st;
+  st = sy2sb_extract_band_launch(A, lda, n, AB, stream);
+  if (st != VIVIT_OK) return st;
+  st = sb2st_launch(AB, n, d, e, R2, n, rrows, tau2, stream);
+  if (st != VIVIT_OK) return st;
+  st = stebz_launch(d, e, n, w, scal, stream);
+  if (st != VIVIT_OK) return st;
+  return info_finalize_launch(info, n, scal, stream);
 }
 
 int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *ws, size_t ws_bytes,
@@ -82,6 +146,8 @@ int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, in
     return r;
   };
   const int ni = (int)n;
+
+  if (!vectors && use_two_stage(n, false)) return symeig_two_stage_values(A, n, lda, w, ws, info, stream);
 
   // ---- stage 1: A = Q_H T Q_H^T
   SytrdWs tw;

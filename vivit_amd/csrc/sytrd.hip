@@ -510,6 +510,14 @@ static SytrdWs sytrd_carve(float *base, int64_t n, float **scanpart) {
   return ws;
 }
 
+int prescale_launch(float *A, int64_t n, int64_t lda, float *scal, float *part, hipStream_t stream) {
+  const int ni = (int)n;
+  trd_scan_kernel<<<ni, 256, 0, stream>>>(A, lda, ni, part);
+  trd_sigma_kernel<<<1, 256, 0, stream>>>(part, ni, scal);
+  trd_scale_kernel<<<ni, 256, 0, stream>>>(A, lda, ni, scal);
+  return launch_status();
+}
+
 // Tridiagonalise A (n x n, lda).  On return ws.d / ws.e / ws.tau hold T and the reflector
 // scalars, A's upper-triangle rows hold the reflectors, ws.scal[1] the applied scaling sigma
 // and ws.scal[2] the non-finite-input flag.
@@ -520,9 +528,7 @@ int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, 
   const int ni = (int)n;
   const bool vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0) && (n % 4 == 0);
 
-  trd_scan_kernel<<<ni, 256, 0, stream>>>(A, lda, ni, scanpart);
-  trd_sigma_kernel<<<1, 256, 0, stream>>>(scanpart, ni, ws.scal);
-  trd_scale_kernel<<<ni, 256, 0, stream>>>(A, lda, ni, ws.scal);
+  prescale_launch(A, n, lda, ws.scal, scanpart, stream);
 
   // Debug knob for counter collection (rocprofv3 --pmc dies on >10^4 dispatches): stop after this
   // many columns.  The factorisation is then incomplete and its outputs meaningless.

@@ -211,6 +211,22 @@ def sytrd(G: torch.Tensor):
     return d, e, tau, A
 
 
+def sy2sb(G: torch.Tensor):
+    """Full symmetric -> band (testing). Returns ``(AB, tau1, A)``: band in row-band layout, reflector
+    scalars, and the overwritten matrix (band + reflector rows)."""
+    _require_device(G)
+    lib = _lib.load()
+    n = G.shape[0]
+    nb = lib.vivit_sb2st_half_bandwidth()
+    A = G.contiguous().clone()
+    AB = torch.empty((n, 2 * nb + 1), dtype=torch.float32, device=G.device)
+    tau1 = torch.empty(n, dtype=torch.float32, device=G.device)
+    ws, wsb = _workspace(lib.vivit_sy2sb_f32_workspace_bytes(n), G)
+    st = lib.vivit_sy2sb_f32(A.data_ptr(), n, n, AB.data_ptr(), tau1.data_ptr(), ws, wsb, _stream(G))
+    _lib.check(st, "vivit_sy2sb_f32")
+    return AB, tau1, A
+
+
 def sb2st(AB: torch.Tensor):
     """Band -> tridiagonal by bulge chasing (testing). ``AB``: [n, 2*NB+1] row-band layout.
     Returns ``(d, e, R2, tau2)``."""

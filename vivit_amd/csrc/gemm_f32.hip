@@ -54,9 +54,13 @@ __device__ __forceinline__ float ld1_sel(gcptr P, int64_t idx_major, int64_t n_m
   return ok ? x : 0.f;
 }
 
-// Global -> registers for one 128 x 16 operand tile (2 float4 per thread).
-// FAST: the tile is completely in range and the operand is 16-byte aligned: unconditional float4.
-template <int LAY, bool FAST>
+// Global -> registers for one 128 x 16 operand tile (2 float4 per thread).  MODE:
+//   0  tile completely in range, operand 16-byte aligned: unconditional float4
+//   1  aligned operand, ragged rows (and, for LAY_M, row count % 4 == 0): float4 from a clamped
+//      row + zero select -- still one vector load per thread and no branch
+//   2  anything else: clamped scalar loads
+// Full K tiles only for modes 0/1 (a ragged last K tile is loaded with mode 2).
+template <int LAY, int MODE>
 __device__ __forceinline__ void tile_load(gcptr P, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
                                           int64_t kend, int tid, float4 (&st)[2]) {
 #pragma unroll
@@ -64,16 +68,24 @@ __device__ __forceinline__ void tile_load(gcptr P, int64_t ld, int64_t row0, int
     const int f = tid + 256 * q;
     if (LAY == LAY_K) {
       const int64_t row = row0 + (f >> 2), k = k0 + 4 * (f & 3);
-      if constexpr (FAST) {
+      if constexpr (MODE == 0) {
         st[q] = ldg4(P + row * ld + k);
+      } else if constexpr (MODE == 1) {
+        const bool ok = row < nrows;
+        const float4 v = ldg4(P + (ok ? row : nrows - 1) * ld + k);
+        st[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         st[q] = make_float4(ld1_sel(P, row, nrows, k, kend, ld), ld1_sel(P, row, nrows, k + 1, kend, ld),
                             ld1_sel(P, row, nrows, k + 2, kend, ld), ld1_sel(P, row, nrows, k + 3, kend, ld));
       }
     } else {
       const int64_t row = row0 + 4 * (f & 31), k = k0 + (f >> 5);
-      if constexpr (FAST) {
+      if constexpr (MODE == 0) {
         st[q] = ldg4(P + k * ld + row);
+      } else if constexpr (MODE == 1) {
+        const bool ok = row < nrows;  // nrows % 4 == 0: the whole float4 is in or out
+        const float4 v = ldg4(P + k * ld + (ok ? row : 0));
+        st[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         st[q] = make_float4(ld1_sel(P, k, kend, row, nrows, ld), ld1_sel(P, k, kend, row + 1, nrows, ld),
                             ld1_sel(P, k, kend, row + 2, nrows, ld), ld1_sel(P, k, kend, row + 3, nrows, ld));
@@ -216,20 +228,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   // Register-staged double buffering: the loads of tile t+1 are issued BEFORE the MFMAs of tile t
   // and written to the other LDS buffer after them; one barrier per K tile.
-  auto mainloop = [&](auto fast_tag) {
-    constexpr bool FAST = decltype(fast_tag)::value;
-    // with FAST only the full K tiles go through the unguarded loader; a ragged last tile is
-    // loaded by the guarded one.
+  auto mainloop = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool FAST = MODE < 2;
+    // modes 0/1 cover the full K tiles; a ragged last K tile goes through the scalar loader.
     const int nt_fast = FAST ? (int)((kend - kbeg) / BK) : 0;
     float4 stA[2], stB[2];
     auto load = [&](int t) {
       const int64_t k0 = kbeg + (int64_t)t * BK;
       if (FAST && t < nt_fast) {
-        tile_load<ALAY, FAST>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
-        tile_load<BLAY, FAST>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
+        tile_load<ALAY, MODE>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
+        tile_load<BLAY, MODE>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
       } else {
-        tile_load<ALAY, false>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
-        tile_load<BLAY, false>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
+        tile_load<ALAY, 2>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
+        tile_load<BLAY, 2>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
       }
     };
     if (nt > 0) {
@@ -251,9 +263,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       __syncthreads();
     }
   };
-  const bool fast = p.a_vec && p.b_vec && row0 + BM <= p.M && col0 + BN <= p.N;
-  if (fast) mainloop(std::true_type{});
-  else mainloop(std::false_type{});
+  // a LAY_M operand needs its row count to be a multiple of 4 for the clamped vector mode
+  const bool vec_ok = p.a_vec && p.b_vec && (ALAY == LAY_K || (p.M & 3) == 0) && (BLAY == LAY_K || (p.N & 3) == 0);
+  const bool full = row0 + BM <= p.M && col0 + BN <= p.N;
+  if (vec_ok && full) mainloop(std::integral_constant<int, 0>{});
+  else if (vec_ok) mainloop(std::integral_constant<int, 1>{});
+  else mainloop(std::integral_constant<int, 2>{});
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
           float v = alpha * tot[i][j][e];
           if (beta != 0.f) v += beta * old[e];
           cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+          tot[i][j][e] = v;  // final value: the mirrored store below reuses it
         }
       }
   } else {
@@ -295,12 +311,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int64_t row = row0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          float v = alpha * tot[i][j][e];
           if (row < p.M && col < p.N) {
             gptr c = Cout + row * ldc + col;
-            float v = alpha * tot[i][j][e];
             if (beta != 0.f) v += beta * *c;
             *c = v;
           }
+          tot[i][j][e] = v;
         }
       }
   }
@@ -323,10 +340,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
         for (int rr = 0; rr < 32; rr += 2) {
           const int64_t mrow = mrow0 + rr + h;
           if (mrow < p.N && mcol < p.M) {
+            // C is symmetric on entry (SYRK accumulate / symmetric rank-2k update), so the mirror
+            // image equals the value just stored in the lower tile: no second read of C
             gptr c = (gptr)p.C + mrow * p.ldc + mcol;
-            float v = p.alpha * ts[(rr + h) * 33 + r];
-            if (p.beta != 0.f) v += p.beta * *c;
-            *c = v;
+            *c = ts[(rr + h) * 33 + r];
           }
         }
       }
@@ -360,7 +377,10 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
   // Fill at least ~2 workgroups per CU when the output has few tiles and K is deep; keep every
   // split at least 32 K tiles long and the slab modest.
   if (tiles < 256 && ktiles >= 64) {
-    int64_t want = 512 / tiles;  // one resident round: 2 workgroups per CU x 256 CUs
+    // one resident round (2 workgroups per CU x 256 CUs) for compute-bound shapes; a one-tile-wide
+    // output streams its big operand once and is bandwidth-bound: more, shorter splits keep enough
+    // bytes in flight
+    int64_t want = (tm == 1 || tn == 1) ? 2048 / tiles : 512 / tiles;
     int64_t maxs = ktiles / 32;
     int64_t s = want < maxs ? want : maxs;
     if (s > 64) s = 64;

@@ -126,12 +126,18 @@ __device__ __forceinline__ void frag_load(const float *__restrict__ s, int r, in
   }
 }
 
-// Super-block geometry: 256 tiles per super-block, SBW tiles wide (a power of two <= 16, shrunk
-// for skinny outputs so that a one-tile-wide GEMM still spreads over all 8 XCDs), each XCD owning
-// one compact sub-block of 32 tiles (xw wide).
-__host__ __device__ inline int sb_width(int tiles_n) {
+// Super-block geometry: 256 tiles per super-block, SBH x SBW tiles (16 x 16 for large outputs; for
+// skinny outputs the short side shrinks to the next power of two >= its tile count, so that a
+// one-tile-wide or one-tile-tall GEMM still spreads over all 8 XCDs), each XCD owning one compact
+// sub-block of 32 tiles (xh x xw).
+__host__ __device__ inline int sb_width(int tiles_m, int tiles_n) {
   int w = 1;
   while (w < 16 && w < tiles_n) w <<= 1;
+  if (w == 16 && tiles_m < 16) {  // short in M instead: widen the super-block
+    int hgt = 1;
+    while (hgt < 16 && hgt < tiles_m) hgt <<= 1;
+    w = 256 / hgt;
+  }
   return w;
 }
 
@@ -151,8 +157,9 @@ __device__ __forceinline__ bool map_tile(int syrk, int SBW, int tiles_m, int til
     I = sb / sbn;
     J = sb - I * sbn;
   }
-  const int xw = SBW < 4 ? SBW : 4, xh = 32 / xw;   // XCD sub-block: xh x xw tiles
-  const int xcols = SBW / xw;                        // XCD sub-blocks per super-block row
+  int xw = SBW < 4 ? SBW : 4, xh = 32 / xw;          // XCD sub-block: xh x xw tiles
+  if (xh > SBH) { xh = SBH; xw = 32 / xh; }
+  const int xcols = SBW / xw;                         // XCD sub-blocks per super-block row
   const int xcd = slot & 7, w = slot >> 3;
   ti = I * SBH + (xcd / xcols) * xh + w / xw;
   tj = J * SBW + (xcd % xcols) * xw + w % xw;
@@ -381,7 +388,7 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
     // output streams its big operand once and is bandwidth-bound: more, shorter splits keep enough
     // bytes in flight
     int64_t want = (tm == 1 || tn == 1) ? 2048 / tiles : 512 / tiles;
-    int64_t maxs = ktiles / 32;
+    int64_t maxs = (tm == 1 || tn == 1) ? ktiles / 8 : ktiles / 32;
     int64_t s = want < maxs ? want : maxs;
     if (s > 64) s = 64;
     while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ((size_t)1 << 30)) --s;
@@ -439,7 +446,7 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
   p.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
   p.desc = nullptr;
 
-  const int sbw = syrk ? 16 : sb_width(p.tiles_n), sbh = 256 / sbw;
+  const int sbw = syrk ? 16 : sb_width(p.tiles_m, p.tiles_n), sbh = 256 / sbw;
   p.sbw = sbw;
   const int64_t sbm = cdiv(p.tiles_m, sbh), sbn = cdiv(p.tiles_n, sbw);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
@@ -506,7 +513,7 @@ int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int
   p.syrk = 0;
   p.a_vec = p.b_vec = 0;
   p.desc = desc;
-  const int sbw = sb_width(p.tiles_n), sbh = 256 / sbw;
+  const int sbw = sb_width(p.tiles_m, p.tiles_n), sbh = 256 / sbw;
   p.sbw = sbw;
   const int64_t nsb = cdiv(p.tiles_m, sbh) * cdiv(p.tiles_n, sbw);
   if (nsb * 256 > 0x7fffffffLL || batch > 65535) return VIVIT_E_UNSUPPORTED;

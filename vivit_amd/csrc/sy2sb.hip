@@ -81,10 +81,15 @@ __global__ __launch_bounds__(256) void qr_col1_kernel(float *__restrict__ pan, i
     scal = 1.f / (alpha - beta);
   }
   const int64_t r0 = (int64_t)blockIdx.x * QT;
-  for (int idx = tid; idx < QT * SNB; idx += 256) {
-    const int rl = idx / SNB, cc = idx - rl * SNB;
+  for (int idx = tid; idx < QT * (SNB / 4); idx += 256) {
+    const int rl = idx / (SNB / 4), c4 = (idx - rl * (SNB / 4)) * 4;
     const int64_t r = r0 + rl;
-    tile[rl][cc] = (r < mp) ? pan[r * SNB + cc] : 0.f;
+    const bool ok = r < mp;
+    const float4 x = *reinterpret_cast<const float4 *>(pan + (ok ? r : 0) * SNB + c4);
+    tile[rl][c4 + 0] = ok ? x.x : 0.f;
+    tile[rl][c4 + 1] = ok ? x.y : 0.f;
+    tile[rl][c4 + 2] = ok ? x.z : 0.f;
+    tile[rl][c4 + 3] = ok ? x.w : 0.f;
   }
   __syncthreads();
   if (tid < QT) {
@@ -126,9 +131,16 @@ __global__ __launch_bounds__(256) void qr_col2_kernel(float *__restrict__ pan, i
   const int tid = threadIdx.x;
   {
     const int cc = tid & 63, q = tid >> 6;
-    float acc = 0.f;
-    for (int w = q; w < nwg; w += 4) acc += zpart[(int64_t)w * SNB + cc];
-    zq[q][cc] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int w = q;
+    for (; w + 12 < nwg; w += 16) {
+      a0 += zpart[(int64_t)w * SNB + cc];
+      a1 += zpart[(int64_t)(w + 4) * SNB + cc];
+      a2 += zpart[(int64_t)(w + 8) * SNB + cc];
+      a3 += zpart[(int64_t)(w + 12) * SNB + cc];
+    }
+    for (; w < nwg; w += 4) a0 += zpart[(int64_t)w * SNB + cc];
+    zq[q][cc] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
   if (tid < SNB) zs[tid] = (zq[0][tid] + zq[1][tid]) + (zq[2][tid] + zq[3][tid]);
@@ -139,12 +151,22 @@ __global__ __launch_bounds__(256) void qr_col2_kernel(float *__restrict__ pan, i
   float sq = 0.f;
   if (r < mp && r >= c) {
     const float tv = tau * stack[(int64_t)c * lds_ + gi0 + r];
-    float *row = pan + r * SNB;
-    for (int cc = half * 32; cc < half * 32 + 32; ++cc) {
-      if (cc > c) {
-        const float x = row[cc] - tv * zs[cc];
-        row[cc] = x;
-        if (cc == c + 1 && r > c + 1) sq = x * x;
+    float *row = pan + r * SNB + half * 32;
+#pragma unroll
+    for (int g4 = 0; g4 < 8; ++g4) {
+      const int cc = half * 32 + 4 * g4;
+      if (cc + 3 > c) {
+        float4 x = *reinterpret_cast<float4 *>(row + 4 * g4);
+        if (cc + 0 > c) x.x -= tv * zs[cc + 0];
+        if (cc + 1 > c) x.y -= tv * zs[cc + 1];
+        if (cc + 2 > c) x.z -= tv * zs[cc + 2];
+        if (cc + 3 > c) x.w -= tv * zs[cc + 3];
+        *reinterpret_cast<float4 *>(row + 4 * g4) = x;
+        if (r > c + 1) {
+          const int d = c + 1 - cc;  // position of column c+1 inside this float4, if any
+          const float xs = d == 0 ? x.x : d == 1 ? x.y : d == 2 ? x.z : d == 3 ? x.w : 0.f;
+          sq += xs * xs;
+        }
       }
     }
   }

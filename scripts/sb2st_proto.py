@@ -109,3 +109,45 @@ if __name__ == "__main__":
             Zt = apply_q2(ZT.T.copy(), refl, n, b, wgrp)
             Z = Zt.T
             print("   w=", wgrp, "resid", np.abs(band @ Z - Z * wT).max(), "orth", np.abs(Z.T @ Z - np.eye(n)).max())
+
+
+def apply_q2_wavefront(Zt, refl, n, b, w, rng):
+    """Blocks (group g, level k) applied in wavefront order tau = G + k (G = reverse group index),
+    random order inside a wavefront step: checks the independence claim used by the GPU kernel."""
+    Zt = Zt.copy()
+    smax = n - 3
+    groups = [(g0, min(g0 + w, smax + 1)) for g0 in range(0, smax + 1, w)]
+    ng = len(groups)
+    blocks = []
+    for gi, (g0, g1) in enumerate(groups):
+        ks = sorted({k for (s, k) in refl if g0 <= s < g1})
+        for k in ks:
+            blocks.append((ng - 1 - gi + k, gi, k))
+    steps = {}
+    for tau, gi, k in blocks:
+        steps.setdefault(tau, []).append((gi, k))
+    for tau in sorted(steps):
+        lst = steps[tau]
+        rng.shuffle(lst)
+        for gi, k in lst:
+            g0, g1 = groups[gi]
+            for s in range(g1 - 1, g0 - 1, -1):
+                if (s, k) not in refl:
+                    continue
+                c0, v, tv = refl[(s, k)]
+                R = slice(c0, c0 + len(v))
+                Zt[:, R] -= tv * np.outer(Zt[:, R] @ v, v)
+    return Zt
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    for n, b in [(97, 8), (150, 16), (200, 8)]:
+        M = rng.standard_normal((n, n)); M = (M + M.T) / 2
+        band = np.triu(np.tril(M, b), -b)
+        d, e, refl, off = sb2st(band, b, "wavefront")
+        T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        wT, ZT = np.linalg.eigh(T)
+        for wgrp in [b, b // 2]:
+            Z = apply_q2_wavefront(ZT.T.copy(), refl, n, b, wgrp, rng).T
+            print("wavefront Q2", n, b, "w=", wgrp, "resid", np.abs(band @ Z - Z * wT).max())

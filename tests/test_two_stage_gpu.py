@@ -100,3 +100,33 @@ def test_two_stage_eigenvalues(kind, n):
     ref = np.linalg.eigvalsh(S.double().numpy())
     w, _ = kernels.symeig(S.to(DEV), eigenvectors=False)
     assert np.abs(w.cpu().double().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n", [193, 300, 1000, 2048])
+@pytest.mark.parametrize("kind", ["dense", "lowrank", "decay", "clustered"])
+def test_two_stage_eigenvectors(kind, n, monkeypatch):
+    """Full two-stage path with vectors (band reduction, bulge chasing, D&C, Q2 and Q1 back-transforms)."""
+    import subprocess, sys, os, json
+
+    # the path is chosen once per process through VIVIT_TWO_STAGE: run in a child process
+    code = f"""
+import sys, json, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+from test_symeig_large_gpu import make_matrix
+from vivit_amd import kernels
+S = make_matrix({kind!r}, {n})
+ref = np.linalg.eigvalsh(S.double().numpy())
+w, Z = kernels.symeig(S.to("cuda:0"), eigenvectors=True)
+w = w.cpu().double().numpy(); Zc = Z.cpu().double().numpy()
+scale = np.abs(ref).max()
+print(json.dumps(dict(eig=float(np.abs(w - ref).max() / scale), orth=float(np.abs(Zc.T @ Zc - np.eye({n})).max()),
+      resid=float(np.abs(S.double().numpy() @ Zc - Zc * w[None, :]).max() / scale))))
+"""
+    env = dict(os.environ, VIVIT_TWO_STAGE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["eig"] <= 1e-5, res
+    assert res["orth"] <= 5e-5, res
+    assert res["resid"] <= 3e-5, res

@@ -19,19 +19,20 @@ namespace vivit {
 constexpr int KB = 128;  // reflectors per compact-WY block
 
 // Yt[t][i] = v_{a+t}[i] (zero for i <= a+t and for reflector indices beyond n-3)
+// (one-stage: shift = 1, jmax = n-3; two-stage stage-1 reflectors: shift = NB, jmax = n-NB-1)
 __global__ __launch_bounds__(256) void bt_extract_kernel(const float *__restrict__ A, int64_t lda, int n, int a,
-                                                         float *__restrict__ Yt) {
+                                                         float *__restrict__ Yt, int shift, int jmax) {
   const int t = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int j = a + t;
   float v = 0.f;
-  if (j <= n - 3 && i > j) v = A[(int64_t)j * lda + i];
+  if (j <= jmax && i >= j + shift) v = A[(int64_t)j * lda + i];
   Yt[(int64_t)t * n + i] = v;
 }
 
 // T (upper triangular, forward/columnwise larft) from S = Y^T Y and tau
-__global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict__ S, const float *__restrict__ tau, int n,
+__global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict__ S, const float *__restrict__ tau, int jmax,
                                                         int a, float *__restrict__ T) {
   __shared__ float Ts[KB][KB + 1];
   __shared__ float col[KB];
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict_
   __syncthreads();
   for (int i = 0; i < KB; ++i) {
     const int j = a + i;
-    const float ti = (j <= n - 3) ? tau[j] : 0.f;
+    const float ti = (j <= jmax) ? tau[j] : 0.f;
     // col[r] = -tau_i * sum_{c=r}^{i-1} T[r][c] S[c][i]   for r < i
     float acc = 0.f;
     if (r < i)
@@ -64,6 +65,43 @@ static size_t bt_workspace_bytes(int64_t n) {
   return b + 512;
 }
 
+// Zt[n x n] (ld n) <- Zt * Q^T for Q = H_0 H_1 ... (reflector j in row j of A, support i >= j + shift,
+// j <= jmax), compact-WY blocks of KB reflectors, last block first.
+template <class Take>
+static int backtransform_launch(const float *A, int64_t n, int64_t lda, const float *tau, int shift, int64_t jmax,
+                                float *Qt, Take &take, hipStream_t stream) {
+  const int ni = (int)n;
+  float *Yt = (float *)take(sizeof(float) * KB * n);
+  float *W1 = (float *)take(sizeof(float) * n * KB);
+  float *W2 = (float *)take(sizeof(float) * n * KB);
+  float *S = (float *)take(sizeof(float) * KB * KB);
+  float *T = (float *)take(sizeof(float) * KB * KB);
+  const size_t gws1_bytes = gemm_workspace_bytes(KB, KB, n, false);
+  void *gws1 = take(gws1_bytes);
+  const size_t gws2_bytes = gemm_workspace_bytes(n, KB, n, false);
+  void *gws2 = take(gws2_bytes);
+  if (jmax < 0) return VIVIT_OK;
+  int st;
+  for (int64_t a = (jmax / KB) * KB; a >= 0; a -= KB) {
+    bt_extract_kernel<<<dim3((unsigned)cdiv(n, 256), KB), 256, 0, stream>>>(A, lda, ni, (int)a, Yt, shift, (int)jmax);
+    st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KB, KB, n, n, n, KB, 1.f, 0.f, false, gws1, gws1_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    bt_tfactor_kernel<<<1, KB, 0, stream>>>(S, tau, (int)jmax, (int)a, T);
+    const int64_t m = n - a;  // components a+shift .. n-1 carry the block's reflectors (the columns before are
+                              // zero in Yt: starting at the 128-aligned offset a keeps the operands 16-byte aligned)
+    // W1[n x KB] = Zt[:, a:] * Yt[:, a:]^T
+    st = gemm_launch(LAY_K, LAY_K, Qt + a, Yt + a, W1, n, KB, m, n, n, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // W2 = W1 * T^T
+    st = gemm_launch(LAY_K, LAY_K, W1, T, W2, n, KB, KB, KB, KB, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // Zt[:, a:] -= W2 * Yt[:, a:]
+    st = gemm_launch(LAY_K, LAY_M, W2, Yt + a, Qt + a, n, m, KB, KB, n, n, -1.f, 1.f, false, gws2, gws2_bytes, stream);
+    if (st != VIVIT_OK) return st;
+  }
+  return VIVIT_OK;
+}
+
 // ---- two-stage reduction (sy2sb + sb2st) --------------------------------------------------------
 constexpr int TS_NB = 64;
 
@@ -76,7 +114,7 @@ static bool use_two_stage(int64_t n, bool vectors) {
     forced = e ? atoi(e) : -1;
   }
   if (forced >= 0) return forced != 0 && n > 2 * TS_NB;
-  return !vectors && n >= 2048;
+  return !vectors && n >= 2048;  // with vectors the one-stage path stays the default until tuned
 }
 
 static size_t two_stage_workspace_bytes(int64_t n, bool vectors) {
@@ -95,7 +133,7 @@ size_t symeig_large_workspace_bytes(int64_t n, bool vectors) {
   size_t two = two_stage_workspace_bytes(n, vectors);
   size_t b = one > two ? one : two;   // either reduction may be selected at run time
   b += stedc_workspace_bytes(n, vectors);
-  if (vectors) b += bt_workspace_bytes(n);
+  if (vectors) b += bt_workspace_bytes(n) + q2_workspace_bytes(n) + 512;
   return b;
 }
 
@@ -149,6 +187,43 @@ int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, in
 
   if (!vectors && use_two_stage(n, false)) return symeig_two_stage_values(A, n, lda, w, ws, info, stream);
 
+  if (vectors && use_two_stage(n, true)) {
+    // ---- two-stage with vectors: A = Q1 B Q1^T (band), B = Q2 T Q2^T, T = Q_T diag(w) Q_T^T;
+    //      Zt = Q_T^T Q2^T Q1^T, applied right to left on the rows of Qt
+    float *scal = (float *)take(sizeof(float) * 16);
+    float *part = (float *)take(sizeof(float) * 2 * n);
+    void *sbws = take(sy2sb_workspace_bytes(n));
+    float *AB = (float *)take(sizeof(float) * n * (2 * TS_NB + 1));
+    float *R2 = (float *)take(sizeof(float) * n * n);
+    const size_t tau2_bytes = sizeof(float) * n * sb2st_num_levels(n);
+    float *tau2 = (float *)take(tau2_bytes);
+    float *d = (float *)take(sizeof(float) * n);
+    float *e = (float *)take(sizeof(float) * n);
+    int st = prescale_launch(A, n, lda, scal, part, stream);
+    if (st != VIVIT_OK) return st;
+    st = symmetrize_launch(A, n, lda, stream);
+    if (st != VIVIT_OK) return st;
+    float *tau1;
+    st = sy2sb_launch(A, n, lda, sbws, &tau1, stream);
+    if (st != VIVIT_OK) return st;
+    st = sy2sb_extract_band_launch(A, lda, n, AB, stream);
+    if (st != VIVIT_OK) return st;
+    if (hipMemsetAsync(tau2, 0, tau2_bytes, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    st = sb2st_launch(AB, n, d, e, R2, n, n, tau2, stream);
+    if (st != VIVIT_OK) return st;
+    void *dc_base = take(stedc_workspace_bytes(n, true));
+    float *Qt, *dd;
+    int *order;
+    st = stedc_dc_launch(d, e, n, dc_base, &Qt, &dd, &order, info, stream);
+    if (st != VIVIT_OK) return st;
+    void *q2ws = take(q2_workspace_bytes(n));
+    st = q2_apply_launch(Qt, n, n, n, R2, n, tau2, q2ws, stream);
+    if (st != VIVIT_OK) return st;
+    st = backtransform_launch(A, n, lda, tau1, TS_NB, n - TS_NB - 1, Qt, take, stream);
+    if (st != VIVIT_OK) return st;
+    return dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, scal, info, stream);
+  }
+
   // ---- stage 1: A = Q_H T Q_H^T
   SytrdWs tw;
   float *trd_base = (float *)take(sizeof(float) * sytrd_workspace_floats(n));
@@ -169,34 +244,9 @@ int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, in
   st = stedc_dc_launch(tw.d, tw.e, n, dc_base, &Qt, &dd, &order, info, stream);
   if (st != VIVIT_OK) return st;
 
-  // ---- stage 3: Zt = Qt * Q_H^T, blocks of KB reflectors, last block first
-  float *Yt = (float *)take(sizeof(float) * KB * n);
-  float *W1 = (float *)take(sizeof(float) * n * KB);
-  float *W2 = (float *)take(sizeof(float) * n * KB);
-  float *S = (float *)take(sizeof(float) * KB * KB);
-  float *T = (float *)take(sizeof(float) * KB * KB);
-  const size_t gws1_bytes = gemm_workspace_bytes(KB, KB, n, false);
-  void *gws1 = take(gws1_bytes);
-  const size_t gws2_bytes = gemm_workspace_bytes(n, KB, n, false);
-  void *gws2 = take(gws2_bytes);
-  const int64_t nrefl = n - 2;  // reflectors 0 .. n-3
-  for (int64_t a = ((nrefl - 1) / KB) * KB; a >= 0; a -= KB) {
-    bt_extract_kernel<<<dim3((unsigned)cdiv(n, 256), KB), 256, 0, stream>>>(A, lda, ni, (int)a, Yt);
-    st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KB, KB, n, n, n, KB, 1.f, 0.f, false, gws1, gws1_bytes, stream);
-    if (st != VIVIT_OK) return st;
-    bt_tfactor_kernel<<<1, KB, 0, stream>>>(S, tw.tau, ni, (int)a, T);
-    const int64_t m = n - a;  // components a+1 .. n-1 carry the block's reflectors (column a of Yt is zero:
-                              // starting at the 128-aligned offset a keeps the operands 16-byte aligned)
-    // W1[n x KB] = Zt[:, a:] * Yt[:, a:]^T
-    st = gemm_launch(LAY_K, LAY_K, Qt + a, Yt + a, W1, n, KB, m, n, n, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
-    if (st != VIVIT_OK) return st;
-    // W2 = W1 * T^T
-    st = gemm_launch(LAY_K, LAY_K, W1, T, W2, n, KB, KB, KB, KB, KB, 1.f, 0.f, false, nullptr, 0, stream);
-    if (st != VIVIT_OK) return st;
-    // Zt[:, a:] -= W2 * Yt[:, a:]
-    st = gemm_launch(LAY_K, LAY_M, W2, Yt + a, Qt + a, n, m, KB, KB, n, n, -1.f, 1.f, false, nullptr, 0, stream);
-    if (st != VIVIT_OK) return st;
-  }
+  // ---- stage 3: Zt = Qt * Q_H^T
+  st = backtransform_launch(A, n, lda, tw.tau, 1, n - 3, Qt, take, stream);
+  if (st != VIVIT_OK) return st;
 
   // ---- sort ascending, undo the scaling, deliver column eigenvectors
   return dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, tw.scal, info, stream);

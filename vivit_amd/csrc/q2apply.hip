@@ -99,109 +99,152 @@ __global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__rest
 }
 
 // ---- apply:  S <- S - ((S V^T) T^T) V  ---------------------------------------------------------
-__global__ __launch_bounds__(256) void q2_apply_kernel(Q2Step a, const float *__restrict__ Tbuf, float *__restrict__ Zt,
-                                                       int64_t ldz, int nrows) {
+// Window: the 128 columns from wstart = c_start - 1 (a multiple of 64: 16-byte aligned row segments);
+// window column w holds V[t][w - 1], which is non-zero only for w in [t + 1, t + 64].
+// Everything is computed TRANSPOSED so that the slab never leaves the registers: with the 32x32x2
+// MFMA the accumulator of  X^T = A * B  (lane (r, h) holds X[row r][4h + (e&3) + 8(e>>2)]) is, with
+// the k index permuted accordingly, exactly the B operand of the next product.  A wave owns 32 rows
+// of Zt (lane (r, h) keeps S[row r][8q + 4h .. +3], q = 0..15, as loaded by float4) and runs
+//     W1^T = V S^T,   W2^T = T W1^T,   U^T = V^T W2^T,   S -= U
+// with V, V^T and T read from LDS as A operands (ds_read_b128, conflict-free strides 132 / 68).
+// Structurally zero 32x32 tiles of V (parallelogram) and T (upper triangular) are skipped: 240
+// instead of 320 MFMAs per block and wave.  A 512-thread workgroup (8 waves, 2 per SIMD) keeps the
+// block's V/T in LDS (86 KB) and walks over several 256-row slabs; load latency is covered by the
+// SIMD's second wave (a register prefetch of the next slab would spill at 256 VGPRs).
+constexpr int LDS_V = QWIN + 4;    // 132
+constexpr int Q2_THREADS = 512;
+constexpr int Q2_SLAB = 32 * (Q2_THREADS / 64);  // 256 rows per workgroup iteration
+
+template <bool VEC>
+__global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const float *__restrict__ Tbuf,
+                                                              float *__restrict__ Zt, int64_t ldz, int nrows) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *sS = lds;                        // [128][LDS_S]
-  float *sV = sS + 128 * LDS_S;           // [64][LDS_S]
-  float *sT = sV + QW * LDS_S;            // [64][LDS_W]
-  float *sW = sT + QW * LDS_W;            // [128][LDS_W]
+  float *sV = lds;                     // [64][LDS_V]   V[t][w]
+  float *sVt = sV + QW * LDS_V;        // [128][LDS_W]  V^T[w][t]
+  float *sT = sVt + QWIN * LDS_W;      // [64][LDS_W]   T[t'][t]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   int g0, k, c_start;
   q2_block(a, blockIdx.y, g0, k, c_start);
-  const int64_t row0 = (int64_t)blockIdx.x * 128;
+  const int wstart = c_start - 1;
+  const int nslab = (nrows + Q2_SLAB - 1) / Q2_SLAB;
 
-  for (int idx = tid; idx < 128 * QWIN; idx += 256) {
-    const int rr = idx / QWIN, i = idx - rr * QWIN;
-    const int64_t row = row0 + rr, colg = (int64_t)c_start + i;
-    sS[rr * LDS_S + i] = (row < nrows && colg < a.n) ? Zt[row * ldz + colg] : 0.f;
-  }
-  for (int idx = tid; idx < QW * QWIN; idx += 256) {
-    const int t = idx / QWIN, i = idx - t * QWIN;
-    sV[t * LDS_S + i] = q2_v(a, g0, c_start, t, i);
+  for (int idx = tid; idx < QW * QWIN; idx += Q2_THREADS) {
+    const int t = idx / QWIN, w = idx - t * QWIN;
+    const float x = (w >= 1) ? q2_v(a, g0, c_start, t, w - 1) : 0.f;
+    sV[t * LDS_V + w] = x;
+    sVt[w * LDS_W + t] = x;
   }
   const float *T = Tbuf + (int64_t)blockIdx.y * QW * QW;
-  for (int idx = tid; idx < QW * QW; idx += 256) sT[(idx / QW) * LDS_W + (idx % QW)] = T[idx];
+  for (int idx = tid; idx < QW * QW; idx += Q2_THREADS) sT[(idx / QW) * LDS_W + (idx % QW)] = T[idx];
   __syncthreads();
 
-  const int wrow = wave * 32;  // this wave's 32 rows of the slab
-  // GEMM 1: W1[r][t] = sum_i S[r][i] V[t][i]          (K = 128)
-  f32x16 acc1[2];
+  const int64_t colg = (int64_t)wstart + 4 * h;  // + 8 q
+  auto slab_load = [&](int slab, float4(&s)[16]) {
+    const int64_t row = (int64_t)slab * Q2_SLAB + wave * 32 + r;
+    const bool rok = row < nrows;
+    const float *base = Zt + (rok ? row * ldz : 0);
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+    for (int q = 0; q < 16; ++q) {
+      const int64_t c = colg + 8 * q;
+      if constexpr (VEC) {
+        const bool ok = rok && c < a.n;  // n % 4 == 0 and c % 4 == 0: all four in or out
+        const float4 x = *reinterpret_cast<const float4 *>(ok ? base + c : Zt);
+        s[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        float e[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
-#pragma unroll 4
-  for (int q = 0; q < QWIN / 8; ++q) {
-    const float4 av = *reinterpret_cast<const float4 *>(sS + (wrow + r) * LDS_S + 8 * q + 4 * h);
-    const float4 b0 = *reinterpret_cast<const float4 *>(sV + (r)*LDS_S + 8 * q + 4 * h);
-    const float4 b1 = *reinterpret_cast<const float4 *>(sV + (32 + r) * LDS_S + 8 * q + 4 * h);
-    const float aa[4] = {av.x, av.y, av.z, av.w}, bb0[4] = {b0.x, b0.y, b0.z, b0.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w};
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = rok && c + u < a.n;
+          const float x = *(ok ? base + c + u : Zt);
+          e[u] = ok ? x : 0.f;
+        }
+        s[q] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  };
+
+  float4 s[16];
+  for (int slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
+    slab_load(slab, s);  // the SIMD's other wave computes meanwhile
+    __asm__ volatile("" ::: "memory");  // keep the (slab-invariant) V/T fragment reads inside the loop
+    // ---- W1^T = V S^T : tile jt covers w-tiles jt .. jt+2 (q = 4 jt .. 4 jt + 11)
+    f32x16 acc1[2];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[tt], bb0[tt], acc1[0], 0, 0, 0);
-      acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[tt], bb1[tt], acc1[1], 0, 0, 0);
+    for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[jt][e] = 0.f;
+#pragma unroll
+      for (int q = 4 * jt; q < 4 * jt + 12; ++q) {
+        const float4 av = *reinterpret_cast<const float4 *>(sV + (32 * jt + r) * LDS_V + 8 * q + 4 * h);
+        acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, s[q].x, acc1[jt], 0, 0, 0);
+        acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, s[q].y, acc1[jt], 0, 0, 0);
+        acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, s[q].z, acc1[jt], 0, 0, 0);
+        acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, s[q].w, acc1[jt], 0, 0, 0);
+      }
+    }
+    // ---- W2^T = T W1^T : T[t'][t] = 0 for t' > t, so tile pair (jt' = 1, jt = 0) is skipped
+    f32x16 acc2[2];
+#pragma unroll
+    for (int jo = 0; jo < 2; ++jo) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[jo][e] = 0.f;
+#pragma unroll
+      for (int jt = jo; jt < 2; ++jt)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const float4 av = *reinterpret_cast<const float4 *>(sT + (32 * jo + r) * LDS_W + 32 * jt + 8 * e4 + 4 * h);
+          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc1[jt][4 * e4 + 0], acc2[jo], 0, 0, 0);
+          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc1[jt][4 * e4 + 1], acc2[jo], 0, 0, 0);
+          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc1[jt][4 * e4 + 2], acc2[jo], 0, 0, 0);
+          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc1[jt][4 * e4 + 3], acc2[jo], 0, 0, 0);
+        }
+    }
+    // ---- U^T = V^T W2^T, one w-tile at a time; w-tile ji needs t'-tiles max(0, ji-2) .. min(1, ji)
+#pragma unroll
+    for (int ji = 0; ji < 4; ++ji) {
+      f32x16 u;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) u[e] = 0.f;
+#pragma unroll
+      for (int jo = (ji == 3 ? 1 : 0); jo < (ji == 0 ? 1 : 2); ++jo)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const float4 av = *reinterpret_cast<const float4 *>(sVt + (32 * ji + r) * LDS_W + 32 * jo + 8 * e4 + 4 * h);
+          u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc2[jo][4 * e4 + 0], u, 0, 0, 0);
+          u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc2[jo][4 * e4 + 1], u, 0, 0, 0);
+          u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc2[jo][4 * e4 + 2], u, 0, 0, 0);
+          u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc2[jo][4 * e4 + 3], u, 0, 0, 0);
+        }
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        float4 &x = s[4 * ji + e4];
+        x.x -= u[4 * e4 + 0]; x.y -= u[4 * e4 + 1]; x.z -= u[4 * e4 + 2]; x.w -= u[4 * e4 + 3];
+      }
+    }
+    // ---- store the slab back (same addresses as loaded)
+    {
+      const int64_t row = (int64_t)slab * Q2_SLAB + wave * 32 + r;
+      if (row < nrows) {
+        float *base = Zt + row * ldz;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int64_t c = colg + 8 * q;
+          if constexpr (VEC) {
+            if (c < a.n) *reinterpret_cast<float4 *>(base + c) = s[q];
+          } else {
+            const float e[4] = {s[q].x, s[q].y, s[q].z, s[q].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (c + u < a.n) base[c + u] = e[u];
+          }
+        }
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sW[(wrow + (e & 3) + 8 * (e >> 2) + 4 * h) * LDS_W + 32 * j + r] = acc1[j][e];
-  __syncthreads();
-  // GEMM 2: W2[r][t'] = sum_t W1[r][t] T[t'][t]        (K = 64)
-  f32x16 acc2[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
-#pragma unroll 4
-  for (int q = 0; q < QW / 8; ++q) {
-    const float4 av = *reinterpret_cast<const float4 *>(sW + (wrow + r) * LDS_W + 8 * q + 4 * h);
-    const float4 b0 = *reinterpret_cast<const float4 *>(sT + (r)*LDS_W + 8 * q + 4 * h);
-    const float4 b1 = *reinterpret_cast<const float4 *>(sT + (32 + r) * LDS_W + 8 * q + 4 * h);
-    const float aa[4] = {av.x, av.y, av.z, av.w}, bb0[4] = {b0.x, b0.y, b0.z, b0.w}, bb1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[tt], bb0[tt], acc2[0], 0, 0, 0);
-      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[tt], bb1[tt], acc2[1], 0, 0, 0);
-    }
-  }
-  __syncthreads();  // every wave has finished reading W1
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sW[(wrow + (e & 3) + 8 * (e >> 2) + 4 * h) * LDS_W + 32 * j + r] = acc2[j][e];
-  __syncthreads();
-  // GEMM 3: U[r][i] = sum_t' W2[r][t'] V[t'][i]        (K = 64, N = 128)
-  f32x16 acc3[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc3[j][e] = 0.f;
-#pragma unroll 2
-  for (int q = 0; q < QW / 8; ++q) {
-    const float4 av = *reinterpret_cast<const float4 *>(sW + (wrow + r) * LDS_W + 8 * q + 4 * h);
-    const float aa[4] = {av.x, av.y, av.z, av.w};
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const float *vrow = sV + (8 * q + 4 * h + tt) * LDS_S;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc3[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[tt], vrow[32 * j + r], acc3[j], 0, 0, 0);
-    }
-  }
-  // S_new = S_old - U, straight to global memory (C/D layout: 128-B row segments)
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int rr = wrow + (e & 3) + 8 * (e >> 2) + 4 * h, i = 32 * j + r;
-      const int64_t row = row0 + rr, colg = (int64_t)c_start + i;
-      if (row < nrows && colg < a.n) Zt[row * ldz + colg] = sS[rr * LDS_S + i] - acc3[j][e];
-    }
 }
 
-constexpr int Q2_LDS_BYTES = (128 * LDS_S + QW * LDS_S + QW * LDS_W + 128 * LDS_W) * 4;
+constexpr int Q2_LDS_BYTES = (QW * LDS_V + QWIN * LDS_W + QW * LDS_W) * 4;
 
 size_t q2_workspace_bytes(int64_t n) {
   const int64_t ngroups = cdiv(n - 2 > 0 ? n - 2 : 1, QW);
@@ -214,12 +257,15 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
   if (n < 3) return VIVIT_OK;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(q2_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(q2_apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            Q2_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(q2_apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             Q2_LDS_BYTES) != hipSuccess)
       return VIVIT_E_LAUNCH;
     attr = true;
   }
   float *Tbuf = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+  const bool vec = ((reinterpret_cast<uintptr_t>(Zt) & 15) == 0) && (ldz % 4 == 0) && (n % 4 == 0);
   const int nsweeps = (int)(n - 2);
   const int ngroups = (int)cdiv(nsweeps, QW);
   // kmax of group g: largest k with a reflector for its first sweep g0: g0 + 1 + k*QB <= n - 1
@@ -236,7 +282,15 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     a.tau = tau; a.G_lo = G_lo;
     const unsigned nblk = (unsigned)(G_hi - G_lo + 1);
     q2_prepare_kernel<<<nblk, 256, 0, stream>>>(a, Tbuf);
-    q2_apply_kernel<<<dim3((unsigned)cdiv(nrows, 128), nblk), 256, Q2_LDS_BYTES, stream>>>(a, Tbuf, Zt, ldz, (int)nrows);
+    // a workgroup walks over several slabs (V, T stay in LDS, next slab prefetched); keep >= ~1000 workgroups
+    const int64_t nslab = cdiv(nrows, Q2_SLAB);
+    int64_t gx = cdiv(768, nblk);
+    if (gx < 1) gx = 1;
+    if (gx > nslab) gx = nslab;
+    if (vec)
+      q2_apply_kernel<true><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, Tbuf, Zt, ldz, (int)nrows);
+    else
+      q2_apply_kernel<false><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, Tbuf, Zt, ldz, (int)nrows);
   }
   return launch_status();
 }

@@ -24,10 +24,11 @@
 
 namespace vivit {
 
-constexpr int BM = 128, BN = 128, BK = 16;
-constexpr int SK = BK + 4;                     // LDS row stride (floats) of a LAY_K tile [128][20]
-constexpr int SM = BM + 4;                     // LDS row stride (floats) of a LAY_M tile [16][132]
-constexpr int TILE_FLOATS = BM * SK;           // 2560 floats (>= 16*132 = 2112)
+constexpr int BM = 128, BN = 128, BK = 16;     // default tile (2 x 2 waves); the WM = 1 variant is 64 x 256
+constexpr int SK = BK + 4;                     // LDS row stride (floats) of a LAY_K tile [rows][20]
+__host__ __device__ constexpr int tile_floats(int rows) {  // one operand tile of `rows` rows in either layout
+  return rows * SK > BK * (rows + 4) ? rows * SK : BK * (rows + 4);
+}
 constexpr int FLUSH_TILES = 2048 / BK;         // second-level accumulation period
 constexpr int SB = 16;                         // super-block edge in tiles
 
@@ -54,17 +55,17 @@ __device__ __forceinline__ float ld1_sel(gcptr P, int64_t idx_major, int64_t n_m
   return ok ? x : 0.f;
 }
 
-// Global -> registers for one 128 x 16 operand tile (2 float4 per thread).  MODE:
+// Global -> registers for one ROWS x 16 operand tile (ROWS / 64 float4 per thread).  MODE:
 //   0  tile completely in range, operand 16-byte aligned: unconditional float4
 //   1  aligned operand, ragged rows (and, for LAY_M, row count % 4 == 0): float4 from a clamped
 //      row + zero select -- still one vector load per thread and no branch
 //   2  anything else: clamped scalar loads
 // Full K tiles only for modes 0/1 (a ragged last K tile is loaded with mode 2).
-template <int LAY, int MODE>
+template <int LAY, int MODE, int ROWS>
 __device__ __forceinline__ void tile_load(gcptr P, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
-                                          int64_t kend, int tid, float4 (&st)[2]) {
+                                          int64_t kend, int tid, float4 (&st)[ROWS / 64]) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < ROWS / 64; ++q) {
     const int f = tid + 256 * q;
     if (LAY == LAY_K) {
       const int64_t row = row0 + (f >> 2), k = k0 + 4 * (f & 3);
@@ -79,7 +80,7 @@ __device__ __forceinline__ void tile_load(gcptr P, int64_t ld, int64_t row0, int
                             ld1_sel(P, row, nrows, k + 2, kend, ld), ld1_sel(P, row, nrows, k + 3, kend, ld));
       }
     } else {
-      const int64_t row = row0 + 4 * (f & 31), k = k0 + (f >> 5);
+      const int64_t row = row0 + 4 * (f & (ROWS / 4 - 1)), k = k0 + f / (ROWS / 4);
       if constexpr (MODE == 0) {
         st[q] = ldg4(P + k * ld + row);
       } else if constexpr (MODE == 1) {
@@ -95,15 +96,15 @@ __device__ __forceinline__ void tile_load(gcptr P, int64_t ld, int64_t row0, int
 }
 
 // Registers -> LDS.
-template <int LAY>
-__device__ __forceinline__ void tile_store(float *__restrict__ s, int tid, const float4 (&st)[2]) {
+template <int LAY, int ROWS>
+__device__ __forceinline__ void tile_store(float *__restrict__ s, int tid, const float4 (&st)[ROWS / 64]) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < ROWS / 64; ++q) {
     const int f = tid + 256 * q;
     if (LAY == LAY_K) {
       *reinterpret_cast<float4 *>(s + (f >> 2) * SK + 4 * (f & 3)) = st[q];
     } else {
-      *reinterpret_cast<float4 *>(s + (f >> 5) * SM + 4 * (f & 31)) = st[q];
+      *reinterpret_cast<float4 *>(s + (f / (ROWS / 4)) * (ROWS + 4) + 4 * (f & (ROWS / 4 - 1))) = st[q];
     }
   }
 }
@@ -112,7 +113,7 @@ __device__ __forceinline__ void tile_store(float *__restrict__ s, int tid, const
 // t in 0..3) consumes k = 8q + 4h + t from lane half h = lane >> 5; both layouts use that same
 // assignment so any A layout pairs with any B layout.
 //   frag[q][t] for rows r0 + (lane & 31).
-template <int LAY>
+template <int LAY, int ROWS>
 __device__ __forceinline__ void frag_load(const float *__restrict__ s, int r, int h, float (&fr)[2][4]) {
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -121,7 +122,7 @@ __device__ __forceinline__ void frag_load(const float *__restrict__ s, int r, in
       fr[q][0] = v.x; fr[q][1] = v.y; fr[q][2] = v.z; fr[q][3] = v.w;
     } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fr[q][t] = s[(8 * q + 4 * h + t) * SM + r];
+      for (int t = 0; t < 4; ++t) fr[q][t] = s[(8 * q + 4 * h + t) * (ROWS + 4) + r];
     }
   }
 }
@@ -168,9 +169,15 @@ __device__ __forceinline__ bool map_tile(int syrk, int SBW, int tiles_m, int til
   return true;
 }
 
-template <int ALAY, int BLAY>
+// WM = waves along M: 2 -> 128 x 128 tile (2 x 2 waves), 1 -> 64 x 256 tile (1 x 4 waves) for outputs
+// with at most 64 rows (the panel products of the band reduction), where the square tile would
+// spend half of its MFMAs on padding.
+template <int ALAY, int BLAY, int WM = 2>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[4 * TILE_FLOATS];
+  constexpr int WN = 4 / WM, BM = 64 * WM, BN = 64 * WN;
+  constexpr int TA = tile_floats(BM), TB = tile_floats(BN);
+  static_assert(WM == 1 || WM == 2, "wave grid");
+  __shared__ __attribute__((aligned(16))) float smem[2 * TA + 2 * TB];
   if (p.desc) {  // batched mode: this problem's pointers and sizes come from device memory
     const GemmDesc ds = p.desc[blockIdx.z];
     p.A = ds.A; p.B = ds.B; p.C = ds.C;
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 31, h = lane >> 5;
 
   const int64_t row0 = (int64_t)ti * BM, col0 = (int64_t)tj * BN;
@@ -194,8 +201,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
   const int nt = (int)((kend - kbeg + BK - 1) / BK);
 
-#define SA(b) (smem + (b) * TILE_FLOATS)
-#define SB_(b) (smem + (2 + (b)) * TILE_FLOATS)
+#define SA(b) (smem + (b) * TA)
+#define SB_(b) (smem + 2 * TA + (b) * TB)
 
   f32x16 acc[2][2], tot[2][2];
 #pragma unroll
@@ -209,9 +216,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   auto compute = [&](int cur) {
     float fa[2][2][4], fb[2][2][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) frag_load<ALAY>(SA(cur), wm * 64 + i * 32 + r, h, fa[i]);
+    for (int i = 0; i < 2; ++i) frag_load<ALAY, BM>(SA(cur), wm * 64 + i * 32 + r, h, fa[i]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) frag_load<BLAY>(SB_(cur), wn * 64 + j * 32 + r, h, fb[j]);
+    for (int j = 0; j < 2; ++j) frag_load<BLAY, BN>(SB_(cur), wn * 64 + j * 32 + r, h, fb[j]);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -240,21 +247,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     constexpr bool FAST = MODE < 2;
     // modes 0/1 cover the full K tiles; a ragged last K tile goes through the scalar loader.
     const int nt_fast = FAST ? (int)((kend - kbeg) / BK) : 0;
-    float4 stA[2], stB[2];
+    float4 stA[BM / 64], stB[BN / 64];
     auto load = [&](int t) {
       const int64_t k0 = kbeg + (int64_t)t * BK;
       if (FAST && t < nt_fast) {
-        tile_load<ALAY, MODE>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
-        tile_load<BLAY, MODE>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
+        tile_load<ALAY, MODE, BM>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
+        tile_load<BLAY, MODE, BN>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
       } else {
-        tile_load<ALAY, 2>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
-        tile_load<BLAY, 2>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
+        tile_load<ALAY, 2, BM>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, stA);
+        tile_load<BLAY, 2, BN>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, stB);
       }
     };
     if (nt > 0) {
       load(0);
-      tile_store<ALAY>(SA(0), tid, stA);
-      tile_store<BLAY>(SB_(0), tid, stB);
+      tile_store<ALAY, BM>(SA(0), tid, stA);
+      tile_store<BLAY, BN>(SB_(0), tid, stB);
     }
     __syncthreads();
     int since_flush = 0;
@@ -264,8 +271,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       compute(cur);
       if (++since_flush == FLUSH_TILES) { since_flush = 0; flush(); }
       if (t + 1 < nt) {
-        tile_store<ALAY>(SA(cur ^ 1), tid, stA);
-        tile_store<BLAY>(SB_(cur ^ 1), tid, stB);
+        tile_store<ALAY, BM>(SA(cur ^ 1), tid, stA);
+        tile_store<BLAY, BN>(SB_(cur ^ 1), tid, stB);
       }
       __syncthreads();
     }
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       }
   }
 
-  if (p.syrk == 1 && !partial && ti != tj) {
+  if (WM == 2 && p.syrk == 1 && !partial && ti != tj) {
     // Mirror image: C[col][row] = same value, transposed through LDS (32x33 floats per wave)
     // so that the second store is also 128-B coalesced.
     float *ts = smem + wave * (32 * 33);
@@ -374,8 +381,12 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
   C[i * ldc + j] = v;
 }
 
+// wave grid of the tile: 1 x 4 waves (64 x 256) when the output has at most 64 rows and is wide
+static int pick_wm(int64_t M, int64_t N, bool syrk) { return (!syrk && M <= 64 && N > 128) ? 1 : 2; }
+
 static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit, int64_t &kchunk) {
-  const int64_t tm = cdiv(M, BM), tn = cdiv(N, BN);
+  const int wm = pick_wm(M, N, syrk);
+  const int64_t tm = cdiv(M, 64 * wm), tn = cdiv(N, 256 / wm);
   const int64_t tiles = syrk ? tm * (tm + 1) / 2 : tm * tn;
   ksplit = 1;
   kchunk = cdiv(K, BK) * BK;
@@ -439,8 +450,9 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
     if (!workspace || workspace_bytes < need) return VIVIT_E_WORKSPACE;
     p.slab = static_cast<float *>(workspace);
   }
-  p.tiles_m = (int)cdiv(M, BM);
-  p.tiles_n = (int)cdiv(N, BN);
+  const int wm = pick_wm(M, N, syrk);
+  p.tiles_m = (int)cdiv(M, 64 * wm);
+  p.tiles_n = (int)cdiv(N, 256 / wm);
   p.syrk = syrk ? 1 : 0;
   p.a_vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   p.b_vec = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
@@ -455,7 +467,16 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
   dim3 block(256, 1, 1);
   const bool prof = syrk && A == B && prof_enabled();  // only the Gram SYRK is profiled as such
   if (prof) prof_begin(0, (double)M * (double)(M + 1) * (double)K, stream);
-  if (alay == LAY_K && blay == LAY_K)
+  if (wm == 1) {
+    if (alay == LAY_K && blay == LAY_K)
+      gemm_kernel<LAY_K, LAY_K, 1><<<grid, block, 0, stream>>>(p);
+    else if (alay == LAY_K && blay == LAY_M)
+      gemm_kernel<LAY_K, LAY_M, 1><<<grid, block, 0, stream>>>(p);
+    else if (alay == LAY_M && blay == LAY_K)
+      gemm_kernel<LAY_M, LAY_K, 1><<<grid, block, 0, stream>>>(p);
+    else
+      gemm_kernel<LAY_M, LAY_M, 1><<<grid, block, 0, stream>>>(p);
+  } else if (alay == LAY_K && blay == LAY_K)
     gemm_kernel<LAY_K, LAY_K><<<grid, block, 0, stream>>>(p);
   else if (alay == LAY_K && blay == LAY_M)
     gemm_kernel<LAY_K, LAY_M><<<grid, block, 0, stream>>>(p);

@@ -11,6 +11,8 @@
 // Blocks only conflict with their neighbours in (g, k); with G the group index counted from the
 // last group, all blocks with equal tau = G + k are independent (validated in scripts/sb2st_proto.py),
 // so the host issues one prepare (T factors) + one apply launch per wavefront step.
+#include <type_traits>
+
 #include "common.h"
 #include "device_utils.h"
 #include "eig_internal.h"
@@ -30,12 +32,12 @@ struct Q2Step {
   int nk, n, ngroups, tau, G_lo;
 };
 
-__device__ __forceinline__ void q2_block(const Q2Step &a, int blk, int &g0, int &k, int &c_start) {
+// super-block blk of super-step a.tau: group (first sweep g0) and level pair K (levels 2K, 2K+1)
+__device__ __forceinline__ void q2_sblock(const Q2Step &a, int blk, int &g0, int &K) {
   const int G = a.G_lo + blk;
   const int g = a.ngroups - 1 - G;
   g0 = g * QW;
-  k = a.tau - G;
-  c_start = g0 + 1 + k * QB;
+  K = a.tau - G;
 }
 
 // V window element: reflector t of the block at window column i
@@ -55,8 +57,10 @@ __global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__rest
   __shared__ float Ts[QW][QW + 1];
   __shared__ float col[QW], taus[QW];
   const int tid = threadIdx.x;
-  int g0, k, c_start;
-  q2_block(a, blockIdx.x, g0, k, c_start);
+  int g0, K;
+  q2_sblock(a, blockIdx.x >> 1, g0, K);
+  const int k = 2 * K + (blockIdx.x & 1);
+  const int c_start = g0 + 1 + k * QB;
   for (int idx = tid; idx < QW * QWIN; idx += 256) {
     const int t = idx / QWIN, i = idx - t * QWIN;
     V[t][i] = q2_v(a, g0, c_start, t, i);
@@ -98,137 +102,184 @@ __global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__rest
   for (int idx = tid; idx < QW * QW; idx += 256) T[idx] = Ts[idx / QW][idx % QW];
 }
 
-// ---- apply:  S <- S - ((S V^T) T^T) V  ---------------------------------------------------------
-// Window: the 128 columns from wstart = c_start - 1 (a multiple of 64: 16-byte aligned row segments);
-// window column w holds V[t][w - 1], which is non-zero only for w in [t + 1, t + 64].
+// ---- apply:  S <- S - ((S V^T) T^T) V  for the two blocks (g, 2K), (g, 2K+1) of a super-block ----
+// Window: 192 columns from wstart = g0 + 128 K (a multiple of 64: 16-byte aligned row segments);
+// block A = level 2K works on window columns [0, 128), block B = level 2K+1 on [64, 192); inside a
+// block, window column w holds V[t][w - 1], non-zero only for w in [t + 1, t + 64].
 // Everything is computed TRANSPOSED so that the slab never leaves the registers: with the 32x32x2
 // MFMA the accumulator of  X^T = A * B  (lane (r, h) holds X[row r][4h + (e&3) + 8(e>>2)]) is, with
 // the k index permuted accordingly, exactly the B operand of the next product.  A wave owns 32 rows
-// of Zt (lane (r, h) keeps S[row r][8q + 4h .. +3], q = 0..15, as loaded by float4) and runs
+// of Zt (lane (r, h) keeps S[row r][8q + 4h .. +3], q = 0..23, as loaded by float4) and runs
 //     W1^T = V S^T,   W2^T = T W1^T,   U^T = V^T W2^T,   S -= U
-// with V, V^T and T read from LDS as A operands (ds_read_b128, conflict-free strides 132 / 68).
-// Structurally zero 32x32 tiles of V (parallelogram) and T (upper triangular) are skipped: 240
-// instead of 320 MFMAs per block and wave.  A 512-thread workgroup (8 waves, 2 per SIMD) keeps the
-// block's V/T in LDS (86 KB) and walks over several 256-row slabs; load latency is covered by the
-// SIMD's second wave (a register prefetch of the next slab would spill at 256 VGPRs).
-constexpr int LDS_V = QWIN + 4;    // 132
+// per block with V and T read from LDS as A operands.  Structurally zero 32x32 tiles of V
+// (parallelogram) and T (upper triangular) are skipped: 240 instead of 320 MFMAs per block and wave.
+// Pairing two levels reads/writes 192 instead of 2 x 128 columns of Zt per row (the kernel is close
+// to HBM-bound) and halves the number of launches.  A 512-thread workgroup (8 waves, 2 per SIMD)
+// keeps both blocks' V/T in LDS (102 KB) and walks over several 256-row slabs.
+constexpr int LDS_V = QWIN + 4;    // 132: conflict-free ds_read_b128 fragments
 constexpr int Q2_THREADS = 512;
 constexpr int Q2_SLAB = 32 * (Q2_THREADS / 64);  // 256 rows per workgroup iteration
+constexpr int Q2_NQ = 24;                        // float4 per lane: 192 window columns
 
 template <bool VEC>
 __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const float *__restrict__ Tbuf,
                                                               float *__restrict__ Zt, int64_t ldz, int nrows) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *sV = lds;                     // [64][LDS_V]   V[t][w]
-  float *sVt = sV + QW * LDS_V;        // [128][LDS_W]  V^T[w][t]
-  float *sT = sVt + QWIN * LDS_W;      // [64][LDS_W]   T[t'][t]
+  float *sV = lds;                      // [2][64][LDS_V]   V[t][w]
+  float *sT = sV + 2 * QW * LDS_V;      // [2][64][LDS_W]   T[t'][t]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  int g0, k, c_start;
-  q2_block(a, blockIdx.y, g0, k, c_start);
-  const int wstart = c_start - 1;
+  int g0, K;
+  q2_sblock(a, blockIdx.y, g0, K);
+  const int wstart = g0 + 2 * K * QB;
+  const bool haveB = g0 + 1 + (2 * K + 1) * QB < a.n;  // level 2K+1 exists for this group
   const int nslab = (nrows + Q2_SLAB - 1) / Q2_SLAB;
 
-  for (int idx = tid; idx < QW * QWIN; idx += Q2_THREADS) {
-    const int t = idx / QWIN, w = idx - t * QWIN;
-    const float x = (w >= 1) ? q2_v(a, g0, c_start, t, w - 1) : 0.f;
-    sV[t * LDS_V + w] = x;
-    sVt[w * LDS_W + t] = x;
+  for (int idx = tid; idx < 2 * QW * QWIN; idx += Q2_THREADS) {
+    const int b = idx / (QW * QWIN), rem = idx - b * (QW * QWIN);
+    const int t = rem / QWIN, w = rem - t * QWIN;
+    sV[(b * QW + t) * LDS_V + w] = (w >= 1) ? q2_v(a, g0, g0 + 1 + (2 * K + b) * QB, t, w - 1) : 0.f;
   }
-  const float *T = Tbuf + (int64_t)blockIdx.y * QW * QW;
-  for (int idx = tid; idx < QW * QW; idx += Q2_THREADS) sT[(idx / QW) * LDS_W + (idx % QW)] = T[idx];
+  const float *T = Tbuf + (int64_t)blockIdx.y * 2 * QW * QW;
+  for (int idx = tid; idx < 2 * QW * QW; idx += Q2_THREADS) sT[(idx / QW) * LDS_W + (idx % QW)] = T[idx];
   __syncthreads();
 
   const int64_t colg = (int64_t)wstart + 4 * h;  // + 8 q
-  auto slab_load = [&](int slab, float4(&s)[16]) {
+  // FAST: window completely inside the matrix and float4-aligned: unguarded loads/stores at
+  // immediate offsets from one base pointer (rows past the end read row 0 and are not stored)
+  const bool fast = VEC && wstart + 8 * Q2_NQ <= a.n;
+  float4 s[Q2_NQ];
+  for (int slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
+    __asm__ volatile("" ::: "memory");  // keep the (slab-invariant) V/T fragment reads inside the loop
     const int64_t row = (int64_t)slab * Q2_SLAB + wave * 32 + r;
     const bool rok = row < nrows;
-    const float *base = Zt + (rok ? row * ldz : 0);
+    float *base = Zt + (rok ? row * ldz : 0);
+    if (fast) {
+      const float4 *b4 = reinterpret_cast<const float4 *>(base + colg);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int64_t c = colg + 8 * q;
-      if constexpr (VEC) {
-        const bool ok = rok && c < a.n;  // n % 4 == 0 and c % 4 == 0: all four in or out
-        const float4 x = *reinterpret_cast<const float4 *>(ok ? base + c : Zt);
-        s[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-      } else {
-        float e[4];
+      for (int q = 0; q < Q2_NQ; ++q) s[q] = b4[2 * q];
+    } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool ok = rok && c + u < a.n;
-          const float x = *(ok ? base + c + u : Zt);
-          e[u] = ok ? x : 0.f;
+      for (int q = 0; q < Q2_NQ; ++q) {
+        const int64_t c = colg + 8 * q;
+        if constexpr (VEC) {
+          const bool ok = rok && c < a.n;  // n % 4 == 0 and c % 4 == 0: all four in or out
+          const float4 x = *reinterpret_cast<const float4 *>(ok ? base + c : Zt);
+          s[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+          float e[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool ok = rok && c + u < a.n;
+            const float x = *(ok ? base + c + u : Zt);
+            e[u] = ok ? x : 0.f;
+          }
+          s[q] = make_float4(e[0], e[1], e[2], e[3]);
         }
-        s[q] = make_float4(e[0], e[1], e[2], e[3]);
       }
     }
-  };
 
-  float4 s[16];
-  for (int slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
-    slab_load(slab, s);  // the SIMD's other wave computes meanwhile
-    __asm__ volatile("" ::: "memory");  // keep the (slab-invariant) V/T fragment reads inside the loop
-    // ---- W1^T = V S^T : tile jt covers w-tiles jt .. jt+2 (q = 4 jt .. 4 jt + 11)
-    f32x16 acc1[2];
+    auto apply = [&](auto q0tag, const float *__restrict__ bV, const float *__restrict__ bT) {
+      constexpr int Q0 = decltype(q0tag)::value;
+      // LDS fragment reads are software-pipelined one MFMA group (4 x 64 cycles) ahead by hand.
+      // ---- W1^T = V S^T : tile jt covers w-tiles jt .. jt+2 (q = 4 jt .. 4 jt + 11)
+      f32x16 acc1[2];
+      const float *pV = bV + r * LDS_V + 4 * h;
+      float4 av = *reinterpret_cast<const float4 *>(pV);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // prologue fragment
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
+      for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc1[jt][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc1[jt][e] = 0.f;
 #pragma unroll
-      for (int q = 4 * jt; q < 4 * jt + 12; ++q) {
-        const float4 av = *reinterpret_cast<const float4 *>(sV + (32 * jt + r) * LDS_V + 8 * q + 4 * h);
-        acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, s[q].x, acc1[jt], 0, 0, 0);
-        acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, s[q].y, acc1[jt], 0, 0, 0);
-        acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, s[q].z, acc1[jt], 0, 0, 0);
-        acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, s[q].w, acc1[jt], 0, 0, 0);
+        for (int q = 4 * jt; q < 4 * jt + 12; ++q) {
+          // next fragment: (jt, q + 1), or the first one of tile jt = 1
+          const int nj = (q + 1 < 4 * jt + 12) ? jt : jt + 1, nq = (q + 1 < 4 * jt + 12) ? q + 1 : 4;
+          float4 an = av;
+          if (nj < 2) an = *reinterpret_cast<const float4 *>(pV + 32 * nj * LDS_V + 8 * nq);
+          acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, s[Q0 + q].x, acc1[jt], 0, 0, 0);
+          acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, s[Q0 + q].y, acc1[jt], 0, 0, 0);
+          acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, s[Q0 + q].z, acc1[jt], 0, 0, 0);
+          acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, s[Q0 + q].w, acc1[jt], 0, 0, 0);
+          av = an;
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next group's LDS fragment first,
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // then this group's 4 MFMAs
+        }
       }
-    }
-    // ---- W2^T = T W1^T : T[t'][t] = 0 for t' > t, so tile pair (jt' = 1, jt = 0) is skipped
-    f32x16 acc2[2];
+      // ---- W2^T = T W1^T : T[t'][t] = 0 for t' > t, so tile pair (jt' = 1, jt = 0) is skipped
+      f32x16 acc2[2];
+      const float *pT = bT + r * LDS_W + 4 * h;
+      // group order: (jo, jt, e4) = (0,0,*), (0,1,*), (1,1,*)
+      av = *reinterpret_cast<const float4 *>(pT);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
-    for (int jo = 0; jo < 2; ++jo) {
+      for (int e = 0; e < 16; ++e) { acc2[0][e] = 0.f; acc2[1][e] = 0.f; }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc2[jo][e] = 0.f;
+      for (int g = 0; g < 12; ++g) {
+        const int jo = g < 8 ? 0 : 1, jt = g < 4 ? 0 : 1, e4 = g & 3;
+        const int gn = g + 1, njo = gn < 8 ? 0 : 1, njt = gn < 4 ? 0 : 1, ne4 = gn & 3;
+        float4 an = av;
+        if (gn < 12) an = *reinterpret_cast<const float4 *>(pT + 32 * njo * LDS_W + 32 * njt + 8 * ne4);
+        acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc1[jt][4 * e4 + 0], acc2[jo], 0, 0, 0);
+        acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc1[jt][4 * e4 + 1], acc2[jo], 0, 0, 0);
+        acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc1[jt][4 * e4 + 2], acc2[jo], 0, 0, 0);
+        acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc1[jt][4 * e4 + 3], acc2[jo], 0, 0, 0);
+        av = an;
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next group's LDS fragment first,
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // then this group's 4 MFMAs
+      }
+      // ---- U^T = V^T W2^T, one w-tile at a time; w-tile ji needs t'-tiles max(0, ji-2) .. min(1, ji).
+      // A operand V[t'][w = 32 ji + r]: four ds_read_b32 per MFMA group from the t-major copy.
+      // group order: (ji, jo, e4) with jo in the valid range: 6 x 4 = 24 groups
+      const float *pU = bV + 4 * h * LDS_V + r;
+      auto ldu = [&](int ji, int jo, int e4) {
+        const float *q = pU + (32 * jo + 8 * e4) * LDS_V + 32 * ji;
+        return make_float4(q[0], q[LDS_V], q[2 * LDS_V], q[3 * LDS_V]);
+      };
+      av = ldu(0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-      for (int jt = jo; jt < 2; ++jt)
+      for (int ji = 0; ji < 4; ++ji) {
+        f32x16 u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u[e] = 0.f;
+        const int jlo = (ji == 3 ? 1 : 0), jhi = (ji == 0 ? 1 : 2);
+#pragma unroll
+        for (int jo = jlo; jo < jhi; ++jo)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            // next group
+            int nji = ji, njo = jo, ne4 = e4 + 1;
+            if (ne4 == 4) { ne4 = 0; njo = jo + 1; if (njo == jhi) { nji = ji + 1; njo = (nji == 3 ? 1 : 0); } }
+            float4 an = av;
+            if (nji < 4) an = ldu(nji, njo, ne4);
+            u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc2[jo][4 * e4 + 0], u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc2[jo][4 * e4 + 1], u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc2[jo][4 * e4 + 2], u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc2[jo][4 * e4 + 3], u, 0, 0, 0);
+            av = an;
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // next group's LDS fragment first,
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // then this group's 4 MFMAs
+          }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
-          const float4 av = *reinterpret_cast<const float4 *>(sT + (32 * jo + r) * LDS_W + 32 * jt + 8 * e4 + 4 * h);
-          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc1[jt][4 * e4 + 0], acc2[jo], 0, 0, 0);
-          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc1[jt][4 * e4 + 1], acc2[jo], 0, 0, 0);
-          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc1[jt][4 * e4 + 2], acc2[jo], 0, 0, 0);
-          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc1[jt][4 * e4 + 3], acc2[jo], 0, 0, 0);
+          float4 &x = s[Q0 + 4 * ji + e4];
+          x.x -= u[4 * e4 + 0]; x.y -= u[4 * e4 + 1]; x.z -= u[4 * e4 + 2]; x.w -= u[4 * e4 + 3];
         }
-    }
-    // ---- U^T = V^T W2^T, one w-tile at a time; w-tile ji needs t'-tiles max(0, ji-2) .. min(1, ji)
-#pragma unroll
-    for (int ji = 0; ji < 4; ++ji) {
-      f32x16 u;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) u[e] = 0.f;
-#pragma unroll
-      for (int jo = (ji == 3 ? 1 : 0); jo < (ji == 0 ? 1 : 2); ++jo)
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          const float4 av = *reinterpret_cast<const float4 *>(sVt + (32 * ji + r) * LDS_W + 32 * jo + 8 * e4 + 4 * h);
-          u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc2[jo][4 * e4 + 0], u, 0, 0, 0);
-          u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc2[jo][4 * e4 + 1], u, 0, 0, 0);
-          u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc2[jo][4 * e4 + 2], u, 0, 0, 0);
-          u = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc2[jo][4 * e4 + 3], u, 0, 0, 0);
-        }
-#pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) {
-        float4 &x = s[4 * ji + e4];
-        x.x -= u[4 * e4 + 0]; x.y -= u[4 * e4 + 1]; x.z -= u[4 * e4 + 2]; x.w -= u[4 * e4 + 3];
       }
-    }
+    };
+    apply(std::integral_constant<int, 0>{}, sV, sT);
+    if (haveB) apply(std::integral_constant<int, 8>{}, sV + QW * LDS_V, sT + QW * LDS_W);
+
     // ---- store the slab back (same addresses as loaded)
-    {
-      const int64_t row = (int64_t)slab * Q2_SLAB + wave * 32 + r;
-      if (row < nrows) {
-        float *base = Zt + row * ldz;
+    if (rok) {
+      if (fast) {
+        float4 *b4 = reinterpret_cast<float4 *>(base + colg);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < Q2_NQ; ++q) b4[2 * q] = s[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < Q2_NQ; ++q) {
           const int64_t c = colg + 8 * q;
           if constexpr (VEC) {
             if (c < a.n) *reinterpret_cast<float4 *>(base + c) = s[q];
@@ -244,11 +295,11 @@ __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const fl
   }
 }
 
-constexpr int Q2_LDS_BYTES = (QW * LDS_V + QWIN * LDS_W + QW * LDS_W) * 4;
+constexpr int Q2_LDS_BYTES = (2 * QW * LDS_V + 2 * QW * LDS_W) * 4;
 
 size_t q2_workspace_bytes(int64_t n) {
   const int64_t ngroups = cdiv(n - 2 > 0 ? n - 2 : 1, QW);
-  return (size_t)(ngroups + 2) * QW * QW * sizeof(float) + 256;
+  return (size_t)2 * (ngroups + 2) * QW * QW * sizeof(float) + 256;
 }
 
 // Zt[nrows x n] (ldz) <- Zt * Q2^T
@@ -268,24 +319,23 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
   const bool vec = ((reinterpret_cast<uintptr_t>(Zt) & 15) == 0) && (ldz % 4 == 0) && (n % 4 == 0);
   const int nsweeps = (int)(n - 2);
   const int ngroups = (int)cdiv(nsweeps, QW);
-  // kmax of group g: largest k with a reflector for its first sweep g0: g0 + 1 + k*QB <= n - 1
-  auto kmax = [&](int g) { return (int)((n - 2 - (int64_t)g * QW) / QB); };
+  // Kmax of group g: largest level pair K with a reflector for its first sweep g0: g0 + 1 + 2K*QB <= n - 1
+  auto Kmax = [&](int g) { return (int)((n - 2 - (int64_t)g * QW) / QB) / 2; };
   Q2Step a;
   a.R2 = R2; a.ldr = ldr; a.tau2 = tau2; a.nk = sb2st_num_levels(n); a.n = (int)n; a.ngroups = ngroups;
-  const int tau_max = (ngroups - 1) + kmax(0);
+  const int tau_max = (ngroups - 1) + Kmax(0);
+  const int64_t nslab = cdiv(nrows, Q2_SLAB);
   int G_lo = 0;
   for (int tau = 0; tau <= tau_max; ++tau) {
-    // valid G: 0 <= G <= min(tau, ngroups-1) and tau - G <= kmax(group of G); G + kmax(G) grows with G
-    while (G_lo < ngroups && G_lo + kmax(ngroups - 1 - G_lo) < tau) ++G_lo;
+    // valid G: 0 <= G <= min(tau, ngroups-1) and tau - G <= Kmax(group of G); G + Kmax(G) grows with G
+    while (G_lo < ngroups && G_lo + Kmax(ngroups - 1 - G_lo) < tau) ++G_lo;
     const int G_hi = tau < ngroups - 1 ? tau : ngroups - 1;
     if (G_lo > G_hi) continue;
     a.tau = tau; a.G_lo = G_lo;
     const unsigned nblk = (unsigned)(G_hi - G_lo + 1);
-    q2_prepare_kernel<<<nblk, 256, 0, stream>>>(a, Tbuf);
-    // a workgroup walks over several slabs (V, T stay in LDS, next slab prefetched); keep >= ~1000 workgroups
-    const int64_t nslab = cdiv(nrows, Q2_SLAB);
-    int64_t gx = cdiv(768, nblk);
-    if (gx < 1) gx = 1;
+    q2_prepare_kernel<<<2 * nblk, 256, 0, stream>>>(a, Tbuf);
+    // a workgroup walks over several slabs (V, T stay in LDS); ~2000 workgroups keep the tail short
+    int64_t gx = cdiv(2048, nblk);
     if (gx > nslab) gx = nslab;
     if (vec)
       q2_apply_kernel<true><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, Tbuf, Zt, ldz, (int)nrows);

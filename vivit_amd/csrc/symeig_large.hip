@@ -106,7 +106,10 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
 constexpr int TS_NB = 64;
 
 // 1 = use the two-stage tridiagonalisation.  Values-only solves switch at n >= 2048 (the band
-// reduction is MFMA-bound, the one-stage reduction HBM-bound); VIVIT_TWO_STAGE=0/1 overrides.
+// reduction is MFMA-bound, the one-stage reduction HBM-bound).  With eigenvectors the second
+// back-transformation (Q2, q2apply.hip) has to be paid for: measured crossover between n = 8192
+// (one-stage 549 ms, two-stage 595 ms) and n = 16384 (1857 ms vs 1507 ms); n = 40960: 16.4 s vs 8.8 s.
+// VIVIT_TWO_STAGE=0/1 overrides.
 static bool use_two_stage(int64_t n, bool vectors) {
   static int forced = -2;
   if (forced == -2) {
@@ -114,7 +117,7 @@ static bool use_two_stage(int64_t n, bool vectors) {
     forced = e ? atoi(e) : -1;
   }
   if (forced >= 0) return forced != 0 && n > 2 * TS_NB;
-  return !vectors && n >= 2048;  // with vectors the one-stage path stays the default until tuned
+  return vectors ? n >= 12288 : n >= 2048;
 }
 
 static size_t two_stage_workspace_bytes(int64_t n, bool vectors) {

@@ -53,6 +53,46 @@ def test_gemm_asymmetric_identity():
     assert torch.equal(out.cpu(), B.T)
 
 
+@pytest.mark.parametrize(
+    "m,n,k",
+    # outputs with >= 200 tiles of 256 x 256: the large-tile kernel (gemm256_kernel), full and ragged
+    # edge tiles, K with and without a tail (< 16) and longer than one flush period (2048)
+    [(4096, 4096, 64), (3600, 3604, 83), (3840, 3584, 4200), (3588, 4000, 2048 + 16)],
+)
+def test_gemm_large_tile(m, n, k):
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(m + 3 * n + 7 * k)
+    A = torch.randn(m, k, generator=g)
+    B = torch.randn(n, k, generator=g)
+    C0 = torch.randn(m, n, generator=g)
+    Ad, Bd = A.to(_dev()), B.to(_dev())
+    ref = (Ad.double() @ Bd.double().T).cpu()
+    tol = 2e-6 * (k ** 0.5) + 1e-6
+    assert _rel(kernels.gemm_nt(Ad, Bd), ref) < tol
+    assert _rel(kernels.gemm_nn(Ad, Bd.T.contiguous()), ref) < tol
+    assert _rel(kernels.gemm_tn(Ad.T.contiguous(), Bd.T.contiguous()), ref) < tol
+    Cd = C0.to(_dev()).clone()
+    kernels.gemm_nt(Ad, Bd, out=Cd, alpha=0.5, beta=-2.0)
+    assert _rel(Cd, 0.5 * ref - 2.0 * C0.double()) < tol
+
+
+@pytest.mark.parametrize("n,p", [(5120, 320), (5000, 4117)])
+def test_gram_syrk_large_tile(n, p):
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(n + p)
+    Ad = torch.randn(n, p, generator=g).to(_dev())
+    ref = (Ad.double() @ Ad.double().T).cpu()
+    G = kernels.gram_syrk(Ad)
+    tol = 2e-6 * (p ** 0.5) + 1e-6
+    assert _rel(G, ref) < tol
+    assert torch.equal(G, G.T), "Gram must be exactly symmetric"
+    G2 = kernels.gram_syrk(Ad, out=G.clone(), alpha=1.0, beta=1.0)
+    assert _rel(G2, 2 * ref) < tol
+    assert torch.equal(G2, G2.T)
+
+
 @pytest.mark.parametrize("n,p", [(1, 1), (3, 10), (15, 42), (128, 64), (200, 333), (640, 513), (1280, 4096), (300, 100000)])
 def test_gram_syrk(n, p):
     from vivit_amd import kernels

@@ -18,6 +18,7 @@
 // SYRK mode (the Gram build, K1): B == A, only super-blocks/tiles with tile_i >= tile_j are
 // computed (n(n+1)p flops instead of 2n^2p) and off-diagonal tiles are stored twice, the mirror
 // image transposed through LDS so that both stores are coalesced.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -364,6 +365,265 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large-output variant: 256 x 256 x 16 tile, 4 waves in a 2 x 2 grid, each wave a 128 x 128 block =
+// 4 x 4 MFMA tiles (256 accumulator registers: one wave per SIMD, the unified 512-register file).
+// Half the LDS operand traffic per flop of the 128 x 128 tile and 128 MFMAs (8192 cycles) per wave
+// between barriers.  With a single wave per SIMD nothing else hides latency, so:
+//  * operands go global -> LDS directly (`global_load_lds_dwordx4`: lane i's 16 bytes land at
+//    M0 + 16 i, probed in scripts/probe/lds_probe.hip), no staging registers, three LDS stages: the
+//    loads of tile t+2 are issued at the top of tile t (two K tiles ~ 16 000 cycles of latency cover;
+//    a register-staged version with half a tile of cover stalled on HBM round trips).  The LDS image
+//    of a wave instruction is one contiguous KB, so K-major tiles cannot be padded; instead each lane
+//    fetches the 16-byte chunk `pos ^ ((row >> 2) & 3)` of its row (the lane -> global address map is
+//    free), which makes the ds_read_b128 fragment reads conflict-free.  The DMA is issued through
+//    inline asm with hand-placed `s_waitcnt vmcnt` (the compiler would wait for vmcnt(0) in front of
+//    every LDS read that follows an LDS-DMA it knows about).
+//  * the K loop is software-pipelined in half K tiles (8 k): the fragment reads of the next half are
+//    issued in front of the 64 MFMAs of the current one; one barrier per K tile.
+// Ragged edge tiles read clamped (duplicate) rows instead of zeros: those accumulators are never stored.
+// The second accumulation level lives in C itself: every 2048 k the accumulators are added into the
+// output tile (read-modify-write through L2, 128 KB per wave every ~10^6 cycles) and cleared - the same
+// pairwise-like rounding as the register `tot` of the small tile, without the registers.
+constexpr int B2 = 256;
+constexpr int T2 = B2 * BK;                         // 4096 floats (16 KB) per operand tile, unpadded
+constexpr int STG2 = 2 * T2;                        // one stage: A tile, B tile
+constexpr int GEMM256_LDS_BYTES = 3 * STG2 * 4;     // 96 KB
+
+template <int LAY>
+__device__ __forceinline__ void frag_half(const float *__restrict__ s, int row, int q, int h, float (&fr)[4]) {
+  if (LAY == LAY_K) {
+    const int c = (2 * q + h) ^ ((row >> 2) & 3);
+    const float4 v = *reinterpret_cast<const float4 *>(s + row * BK + 4 * c);
+    fr[0] = v.x; fr[1] = v.y; fr[2] = v.z; fr[3] = v.w;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fr[t] = s[(8 * q + 4 * h + t) * B2 + row];
+  }
+}
+
+// this lane's global source for 1 KB block `blk` (0..15) of an operand tile at K offset 0
+template <int LAY>
+__device__ __forceinline__ gcptr dma_src(const float *P, int64_t ld, int64_t row0, int64_t nrows, int blk, int lane) {
+  if (LAY == LAY_K) {  // block = 16 rows x 16 k; lane -> (row, swizzled 16-byte chunk)
+    const int rl = lane >> 2, pos = lane & 3;
+    int64_t row = row0 + 16 * blk + rl;
+    row = row < nrows ? row : nrows - 1;
+    return (gcptr)(P + row * ld + 4 * (pos ^ ((rl >> 2) & 3)));
+  } else {             // block = k row `blk` x 256 rows; lane -> rows 4 lane .. 4 lane + 3
+    int64_t row = row0 + 4 * lane;
+    row = row + 4 <= nrows ? row : nrows - 4;  // nrows % 4 == 0 and nrows >= 4 (host)
+    return (gcptr)(P + (int64_t)blk * ld + row);
+  }
+}
+
+__device__ __forceinline__ void dma16(gcptr src, unsigned lds_byte_addr) {
+  __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory");
+}
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem2[];
+  int ti, tj;
+  if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)ti * B2, col0 = (int64_t)tj * B2;
+  const int nt = (int)(p.K / BK);  // K % 16 == 0 (host)
+
+#define S2A(st) (smem2 + (st) * STG2)
+#define S2B(st) (smem2 + (st) * STG2 + T2)
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  gptr Cout = (gptr)p.C;
+  const int64_t ldc = p.ldc;
+  const bool full_tile = row0 + B2 <= p.M && col0 + B2 <= p.N;
+  // C <- C' + alpha * acc with C' = beta * C on the first flush and C afterwards; acc <- final value
+  auto flush_to_c = [&](bool first) __attribute__((always_inline)) {
+    const float beta = first ? p.beta : 1.f;
+    // the 256 output addresses are loop-invariant: without an opaque term LICM hoists them out of the
+    // K loop (512 registers of addresses -> scratch spills in the hot loop)
+    int opaque = 0;
+    __asm__ volatile("" : "+v"(opaque));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __asm__ volatile("" ::: "memory");  // one tile (16 loads, 16 stores) at a time
+        const int64_t rbase = row0 + wm * 128 + i * 32 + 4 * h + opaque, col = col0 + wn * 128 + j * 32 + r;
+        if (full_tile) {
+          gptr cbase = Cout + rbase * ldc + col;
+          float old[16];
+          if (beta != 0.f) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) old[e] = cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc];
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = p.alpha * acc[i][j][e];
+            if (beta != 0.f) v += beta * old[e];
+            cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+            acc[i][j][e] = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
+            float v = p.alpha * acc[i][j][e];
+            if (row < p.M && col < p.N) {
+              gptr c = Cout + row * ldc + col;
+              if (beta != 0.f) v += beta * *c;
+              *c = v;
+            }
+            acc[i][j][e] = v;
+          }
+        }
+      }
+  };
+  auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+
+  float fa[2][4][4], fb[2][4][4];  // [half parity][tile][k pair]
+  auto frags = [&](int st, int q, int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) frag_half<ALAY>(S2A(st), wm * 128 + i * 32 + r, q, h, fa[par][i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) frag_half<BLAY>(S2B(st), wn * 128 + j * 32 + r, q, h, fb[par][j]);
+  };
+  auto mfma_half = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][i][tt], fb[par][j][tt], acc[i][j], 0, 0, 0);
+  };
+  constexpr int NFR_A = (ALAY == LAY_K) ? 4 : 16, NFR_B = (BLAY == LAY_K) ? 4 : 16;  // DS reads per half
+
+  // DMA sources: wave w moves blocks w, w+4, w+8, w+12 of each operand tile; pointers advance per K tile
+  gcptr srcA[4], srcB[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    srcA[u] = dma_src<ALAY>(p.A, p.lda, row0, p.M, wave + 4 * u, lane);
+    srcB[u] = dma_src<BLAY>(p.B, p.ldb, col0, p.N, wave + 4 * u, lane);
+  }
+  const int64_t stepA = (ALAY == LAY_K) ? BK : (int64_t)BK * p.lda, stepB = (BLAY == LAY_K) ? BK : (int64_t)BK * p.ldb;
+  // LDS byte address of this wave's first block (wave-uniform: SGPR for M0)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem2 +
+                                                       (unsigned)(wave * 256 * 4));
+  // issue the 8 DMA instructions of the next not yet requested K tile into stage st
+  auto issue = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      dma16(srcA[u], lds0 + (unsigned)((st * STG2 + 4 * u * 256) * 4));
+      srcA[u] += stepA;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      dma16(srcB[u], lds0 + (unsigned)((st * STG2 + T2 + 4 * u * 256) * 4));
+      srcB[u] += stepB;
+    }
+  };
+
+  // One K tile at stage S.  LOAD: request tile t+2 into stage S+2; NEXT: tile t+1 exists.  Tile t+1's DMA
+  // was requested one K tile (8192 MFMA cycles) ago; every wave waits for its own part at the top of the
+  // tile, BEFORE requesting tile t+2, and the barrier between the two halves publishes it to the other
+  // waves.  That wait is the compiler-visible `s_waitcnt` builtin on purpose: hipcc cannot see the asm DMA,
+  // but it does see its own spill reloads / flush accesses in the loop preheader, and with those pending in
+  // its scoreboard it would put a vmcnt(0) in front of the first MFMA of every trip - after the DMA request.
+  auto body = [&](auto stage, bool do_load, bool has_next) __attribute__((always_inline)) {
+    constexpr int S = decltype(stage)::value, S1 = (S + 1) % 3, S2 = (S + 2) % 3;
+    __builtin_amdgcn_sched_barrier(0);   // tile boundary: the wait below stays behind the previous tile's MFMAs
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (do_load) issue(S2);
+    frags(S, 1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, NFR_A + NFR_B, 0);   // fragments of the second half
+    mfma_half(0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+    if (has_next) {
+      __builtin_amdgcn_sched_barrier(0);  // the 64 MFMAs above stay above the barrier
+      __syncthreads();
+      frags(S1, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NFR_A + NFR_B, 0);   // first-half fragments of tile t+1
+    }
+    mfma_half(1);
+    __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  // K is processed in chunks of FLUSH_TILES tiles: a clean software-pipelined loop per chunk (the
+  // accumulators stay in AGPRs), then the chunk sum is added into C.
+  auto chunk = [&](int t0, int t1) __attribute__((always_inline)) {
+    __syncthreads();  // every wave is done with the LDS stages of the previous chunk
+    issue(0);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t0 + 1 < t1) issue(1);
+    __syncthreads();
+    frags(0, 0, 0);
+    int t = t0;
+    for (; t + 4 < t1; t += 3) {  // steady state: three tiles per trip, every one requests tile t+2
+      body(I0{}, true, true);
+      body(I1{}, true, true);
+      body(I2{}, true, true);
+    }
+    // at most 4 tiles left
+    if (t < t1) { body(I0{}, t + 2 < t1, t + 1 < t1); ++t; }
+    if (t < t1) { body(I1{}, t + 2 < t1, t + 1 < t1); ++t; }
+    if (t < t1) { body(I2{}, t + 2 < t1, t + 1 < t1); ++t; }
+    if (t < t1) { body(I0{}, false, false); ++t; }
+  };
+  bool first_flush = true;
+  for (int t0 = 0; t0 < nt; t0 += FLUSH_TILES) {
+    const int t1 = t0 + FLUSH_TILES < nt ? t0 + FLUSH_TILES : nt;
+    if (t0 > 0) clear_acc();
+    chunk(t0, t1);
+    flush_to_c(first_flush);  // after the last chunk acc holds the final values of the tile
+    first_flush = false;
+  }
+
+  if (p.syrk == 1 && ti != tj) {
+    // Mirror image through LDS (32 x 33 floats per wave), as in the small-tile kernel
+    float *ts = smem2 + wave * (32 * 33);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ts[r * 33 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[i][j][e];
+        __syncthreads();
+        const int64_t mrow0 = col0 + wn * 128 + j * 32;
+        const int64_t mcol = row0 + wm * 128 + i * 32 + r;
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += 2) {
+          const int64_t mrow = mrow0 + rr + h;
+          if (mrow < p.N && mcol < p.M) {
+            gptr c = (gptr)p.C + mrow * p.ldc + mcol;
+            *c = ts[(rr + h) * 33 + r];
+          }
+        }
+      }
+  }
+}
+
 // C = alpha * sum_z slab[z] + beta * C  (fixed summation order); SYRK slabs hold the lower
 // tiles only, the upper triangle is read from the transposed position.
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ slab, float *__restrict__ C,
@@ -425,6 +685,60 @@ __global__ __launch_bounds__(256) void scale_c_kernel(float *__restrict__ C, int
   C[i * ldc + j] = beta == 0.f ? 0.f : beta * C[i * ldc + j];
 }
 
+// The 256 x 256 tile pays off once the output has enough of them to fill the chip (one per CU).
+static bool use_gemm256(int64_t M, int64_t N, int64_t K, bool syrk) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char *e = getenv("VIVIT_GEMM256");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced == 0) return false;
+  const int64_t tm = cdiv(M, B2), tn = cdiv(N, B2);
+  const int64_t tiles = syrk ? tm * (tm + 1) / 2 : tm * tn;
+  return tiles >= 200 && K >= 64;
+}
+
+static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    const void *fns[4] = {reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_K>),
+                          reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_M>),
+                          reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_K>),
+                          reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_M>)};
+    for (const void *f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS_BYTES) != hipSuccess)
+        return VIVIT_E_LAUNCH;
+    attr = true;
+  }
+  p.ksplit = 1;
+  p.kchunk = cdiv(p.K, BK) * BK;
+  p.slab = nullptr;
+  p.tiles_m = (int)cdiv(p.M, B2);
+  p.tiles_n = (int)cdiv(p.N, B2);
+  p.syrk = syrk ? 1 : 0;
+  p.a_vec = ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0 && (p.lda & 3) == 0) ? 1 : 0;
+  p.b_vec = ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0 && (p.ldb & 3) == 0) ? 1 : 0;
+  p.desc = nullptr;
+  const int sbw = syrk ? 16 : sb_width(p.tiles_m, p.tiles_n), sbh = 256 / sbw;
+  p.sbw = sbw;
+  const int64_t sbm = cdiv(p.tiles_m, sbh), sbn = cdiv(p.tiles_n, sbw);
+  const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
+  if (nsb * 256 > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
+  dim3 grid((unsigned)(nsb * 256), 1, 1);
+  const bool prof = syrk && p.A == p.B && prof_enabled();
+  if (prof) prof_begin(0, (double)p.M * (double)(p.M + 1) * (double)p.K, stream);
+  if (alay == LAY_K && blay == LAY_K)
+    gemm256_kernel<LAY_K, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(p);
+  else if (alay == LAY_K && blay == LAY_M)
+    gemm256_kernel<LAY_K, LAY_M><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(p);
+  else if (alay == LAY_M && blay == LAY_K)
+    gemm256_kernel<LAY_M, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(p);
+  else
+    gemm256_kernel<LAY_M, LAY_M><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(p);
+  if (prof) prof_end(0, stream);
+  return launch_status();
+}
+
 int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, int64_t M, int64_t N,
                 int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, float beta, bool syrk,
                 void *workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -443,6 +757,19 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.alpha = alpha; p.beta = beta;
+  {
+    const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
+                     (ldb & 3) == 0 && (alay == LAY_K || (M & 3) == 0) && (blay == LAY_K || (N & 3) == 0);
+    const int64_t Kmain = K / BK * BK;
+    if (vec && use_gemm256(M, N, Kmain, syrk)) {
+      p.K = Kmain;
+      int st = gemm256_launch(alay, blay, p, syrk, stream);
+      if (st != VIVIT_OK || Kmain == K) return st;
+      // ragged K tail (< 16) through the small-tile kernel, accumulating
+      const float *At = A + (alay == LAY_K ? Kmain : Kmain * lda), *Bt = B + (blay == LAY_K ? Kmain : Kmain * ldb);
+      return gemm_launch(alay, blay, At, Bt, C, M, N, K - Kmain, lda, ldb, ldc, alpha, 1.f, syrk, workspace, workspace_bytes, stream);
+    }
+  }
   choose_split(M, N, K, syrk, p.ksplit, p.kchunk);
   p.slab = nullptr;
   if (p.ksplit > 1) {

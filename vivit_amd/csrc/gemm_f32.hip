@@ -548,23 +548,44 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
   // waves.  That wait is the compiler-visible `s_waitcnt` builtin on purpose: hipcc cannot see the asm DMA,
   // but it does see its own spill reloads / flush accesses in the loop preheader, and with those pending in
   // its scoreboard it would put a vmcnt(0) in front of the first MFMA of every trip - after the DMA request.
+  // The LDS reads (8 per half) and DMA requests (8 per tile) are spread over the four 16-MFMA k-steps of a
+  // half instead of being issued back to back (the LDS / VMEM issue queues are short: a burst stalls the
+  // wave at issue and drains the MFMA pipe); sched_barrier(0) fences keep hipcc from regrouping them.
+  auto frag1 = [&](int st, int q, int par, int u) __attribute__((always_inline)) {  // A tile u and B tile u
+    frag_half<ALAY>(S2A(st), wm * 128 + u * 32 + r, q, h, fa[par][u]);
+    frag_half<BLAY>(S2B(st), wn * 128 + u * 32 + r, q, h, fb[par][u]);
+  };
+  auto mfma_step = [&](int par, int tt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][i][tt], fb[par][j][tt], acc[i][j], 0, 0, 0);
+  };
+  auto issue2 = [&](int st, int u) __attribute__((always_inline)) {  // DMA blocks u of A and B
+    dma16(srcA[u], lds0 + (unsigned)((st * STG2 + 4 * u * 256) * 4));
+    srcA[u] += stepA;
+    dma16(srcB[u], lds0 + (unsigned)((st * STG2 + T2 + 4 * u * 256) * 4));
+    srcB[u] += stepB;
+  };
   auto body = [&](auto stage, bool do_load, bool has_next) __attribute__((always_inline)) {
     constexpr int S = decltype(stage)::value, S1 = (S + 1) % 3, S2 = (S + 2) % 3;
     __builtin_amdgcn_sched_barrier(0);   // tile boundary: the wait below stays behind the previous tile's MFMAs
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    if (do_load) issue(S2);
-    frags(S, 1, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, NFR_A + NFR_B, 0);   // fragments of the second half
-    mfma_half(0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
-    if (has_next) {
-      __builtin_amdgcn_sched_barrier(0);  // the 64 MFMAs above stay above the barrier
-      __syncthreads();
-      frags(S1, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, NFR_A + NFR_B, 0);   // first-half fragments of tile t+1
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      if (do_load) issue2(S2, tt);
+      frag1(S, 1, 1, tt);
+      mfma_step(0, tt);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    mfma_half(1);
-    __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+    if (has_next) __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      if (has_next) frag1(S1, 0, 0, tt);
+      mfma_step(1, tt);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;

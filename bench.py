@@ -209,7 +209,7 @@ def main():
         else:
             achieved = syrk_flops / (syrk_ms / 1e3) / 1e12
             roofline = {
-                "kernel": "gemm_kernel<LAY_K,LAY_K> (Gram SYRK, fp32 MFMA)",
+                "kernel": "gemm256_kernel<LAY_K,LAY_K> (Gram SYRK, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F32_PEAK_TF, "traffic": None,
                 "launches_sampled": int(syrk_cnt), "avg_launch_ms": syrk_ms / max(syrk_cnt, 1),

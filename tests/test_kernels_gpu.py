@@ -57,7 +57,7 @@ def test_gemm_asymmetric_identity():
     "m,n,k",
     # outputs with >= 200 tiles of 256 x 256: the large-tile kernel (gemm256_kernel), full and ragged
     # edge tiles, K with and without a tail (< 16) and longer than one flush period (2048)
-    [(4096, 4096, 64), (3600, 3604, 83), (3840, 3584, 4200), (3588, 4000, 2048 + 16)],
+    [(4096, 4096, 1024), (3600, 3604, 1043), (3840, 3584, 4200), (3588, 4000, 8192 + 1024 + 16)],
 )
 def test_gemm_large_tile(m, n, k):
     from vivit_amd import kernels
@@ -77,7 +77,7 @@ def test_gemm_large_tile(m, n, k):
     assert _rel(Cd, 0.5 * ref - 2.0 * C0.double()) < tol
 
 
-@pytest.mark.parametrize("n,p", [(5120, 320), (5000, 4117)])
+@pytest.mark.parametrize("n,p", [(5120, 1040), (5000, 9117)])
 def test_gram_syrk_large_tile(n, p):
     from vivit_amd import kernels
 

@@ -382,13 +382,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 //  * the K loop is software-pipelined in half K tiles (8 k): the fragment reads of the next half are
 //    issued in front of the 64 MFMAs of the current one; one barrier per K tile.
 // Ragged edge tiles read clamped (duplicate) rows instead of zeros: those accumulators are never stored.
-// The second accumulation level lives in C itself: every 2048 k the accumulators are added into the
+// The second accumulation level lives in C itself: every 8192 k the accumulators are added into the
 // output tile (read-modify-write through L2, 128 KB per wave every ~10^6 cycles) and cleared - the same
 // pairwise-like rounding as the register `tot` of the small tile, without the registers.
 constexpr int B2 = 256;
 constexpr int T2 = B2 * BK;                         // 4096 floats (16 KB) per operand tile, unpadded
 constexpr int STG2 = 2 * T2;                        // one stage: A tile, B tile
 constexpr int GEMM256_LDS_BYTES = 3 * STG2 * 4;     // 96 KB
+constexpr int FLUSH2_TILES = 8192 / BK;             // second-level accumulation period of this kernel
 
 template <int LAY>
 __device__ __forceinline__ void frag_half(const float *__restrict__ s, int row, int q, int h, float (&fr)[4]) {
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
-  // K is processed in chunks of FLUSH_TILES tiles: a clean software-pipelined loop per chunk (the
+  // K is processed in chunks of FLUSH2_TILES tiles: a clean software-pipelined loop per chunk (the
   // accumulators stay in AGPRs), then the chunk sum is added into C.
   auto chunk = [&](int t0, int t1) __attribute__((always_inline)) {
     __syncthreads();  // every wave is done with the LDS stages of the previous chunk
@@ -612,8 +613,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
     if (t < t1) { body(I0{}, false, false); ++t; }
   };
   bool first_flush = true;
-  for (int t0 = 0; t0 < nt; t0 += FLUSH_TILES) {
-    const int t1 = t0 + FLUSH_TILES < nt ? t0 + FLUSH_TILES : nt;
+  for (int t0 = 0; t0 < nt; t0 += FLUSH2_TILES) {
+    const int t1 = t0 + FLUSH2_TILES < nt ? t0 + FLUSH2_TILES : nt;
     if (t0 > 0) clear_acc();
     chunk(t0, t1);
     flush_to_c(first_flush);  // after the last chunk acc holds the final values of the tile
@@ -716,7 +717,9 @@ static bool use_gemm256(int64_t M, int64_t N, int64_t K, bool syrk) {
   if (forced == 0) return false;
   const int64_t tm = cdiv(M, B2), tn = cdiv(N, B2);
   const int64_t tiles = syrk ? tm * (tm + 1) / 2 : tm * tn;
-  return tiles >= 200 && K >= 64;
+  // one workgroup per CU: prologue (first DMA round trip) and epilogue (256 KB of C) are not overlapped with
+  // another workgroup's main loop, so the contraction must be long enough to amortise them
+  return tiles >= 200 && K >= 1024;
 }
 
 static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, hipStream_t stream) {

@@ -101,4 +101,24 @@ __device__ inline int ql_implicit(float *d, float *e, int n, float *z) {
 }
 
 
+
+// Compact-WY T factor, column-parallel.  The forward (columnwise) larft recurrence
+//   T[0:i, i] = -tau_i T[0:i, 0:i] S[0:i, i],  T[i][i] = tau_i          (S = V^T V)
+// is the statement T (D^-1 + striu(S)) = I, D = diag(tau); T is therefore also the LEFT inverse and
+// column j can be computed on its own by back substitution
+//   T[j][j] = tau_j,   T[i][j] = -tau_i sum_{c=i+1..j} S[i][c] T[c][j]   (i = j-1 .. 0)
+// (tau_i = 0 gives a zero row and column, as in the recurrence).  One thread per column: O(nb^2/2)
+// multiply-adds without a single barrier instead of nb barrier-separated steps.
+// S, T: LDS arrays with row stride ld (thread j walks column j: conflict-free for ld odd).
+__device__ __forceinline__ void tfactor_column(const float *S, const float *taus, float *T, int ld, int nb, int j) {
+  if (j >= nb) return;
+  for (int i = j + 1; i < nb; ++i) T[i * ld + j] = 0.f;
+  T[j * ld + j] = taus[j];
+  for (int i = j - 1; i >= 0; --i) {
+    float acc = 0.f;
+    for (int c = i + 1; c <= j; ++c) acc += S[i * ld + c] * T[c * ld + j];
+    T[i * ld + j] = -taus[i] * acc;
+  }
+}
+
 } // namespace vivit

@@ -507,17 +507,6 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) frag_half<BLAY>(S2B(st), wn * 128 + j * 32 + r, q, h, fb[par][j]);
   };
-  auto mfma_half = [&](int par) __attribute__((always_inline)) {
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][i][tt], fb[par][j][tt], acc[i][j], 0, 0, 0);
-  };
-  constexpr int NFR_A = (ALAY == LAY_K) ? 4 : 16, NFR_B = (BLAY == LAY_K) ? 4 : 16;  // DS reads per half
-
   // DMA sources: wave w moves blocks w, w+4, w+8, w+12 of each operand tile; pointers advance per K tile
   gcptr srcA[4], srcB[4];
 #pragma unroll

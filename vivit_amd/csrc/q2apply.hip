@@ -22,7 +22,6 @@ namespace vivit {
 constexpr int QB = 64;            // reflector length (= half bandwidth NB)
 constexpr int QW = 64;            // sweeps per block
 constexpr int QWIN = QB + QW;     // window width (128)
-constexpr int LDS_S = QWIN + 4;   // 132: conflict-free ds_read_b128 fragments
 constexpr int LDS_W = QW + 4;     // 68
 
 struct Q2Step {
@@ -55,7 +54,7 @@ __global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__rest
   __shared__ float V[QW][QWIN + 1];
   __shared__ float S[QW][QW + 1];
   __shared__ float Ts[QW][QW + 1];
-  __shared__ float col[QW], taus[QW];
+  __shared__ float taus[QW];
   const int tid = threadIdx.x;
   int g0, K;
   q2_sblock(a, blockIdx.x >> 1, g0, K);
@@ -69,7 +68,6 @@ __global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__rest
     const int s = g0 + tid;
     taus[tid] = (s <= a.n - 3 && c_start + tid < a.n) ? a.tau2[(int64_t)s * a.nk + k] : 0.f;
   }
-  for (int idx = tid; idx < QW * QW; idx += 256) Ts[idx / QW][idx % QW] = 0.f;
   __syncthreads();
   {  // S = V V^T (64 x 64), 16 entries per thread
     const int r = tid >> 2, cb = (tid & 3) * 16;
@@ -85,19 +83,9 @@ __global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__rest
     for (int c = 0; c < 16; ++c) S[r][cb + c] = acc[c];
   }
   __syncthreads();
-  // forward columnwise larft: T[0:i, i] = -tau_i T[0:i, 0:i] S[0:i, i]
-  for (int i = 0; i < QW; ++i) {
-    const float ti = taus[i];
-    if (tid < i) {
-      float acc = 0.f;
-      for (int c = tid; c < i; ++c) acc += Ts[tid][c] * S[c][i];
-      col[tid] = -ti * acc;
-    }
-    __syncthreads();
-    if (tid < i) Ts[tid][i] = col[tid];
-    if (tid == i) Ts[i][i] = ti;
-    __syncthreads();
-  }
+  // T factor, one thread per column (device_utils.h:tfactor_column)
+  if (tid < QW) tfactor_column(&S[0][0], taus, &Ts[0][0], QW + 1, QW, tid);
+  __syncthreads();
   float *T = Tbuf + (int64_t)blockIdx.x * QW * QW;
   for (int idx = tid; idx < QW * QW; idx += 256) T[idx] = Ts[idx / QW][idx % QW];
 }

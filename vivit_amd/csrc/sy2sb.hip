@@ -185,27 +185,18 @@ __global__ __launch_bounds__(256) void sb_panel_store_kernel(float *__restrict__
   A[(j0 + SNB + r) * lda + j0 + c] = (r < c) ? pan[(int64_t)r * SNB + c] : (r == c ? betas[c] : 0.f);
 }
 
-// T (nb x nb upper triangular, forward/columnwise larft) from S = V^T V and tau; nb <= 128
-__global__ __launch_bounds__(128) void larft_kernel(const float *__restrict__ S, const float *__restrict__ tau, int nb,
+// T (nb x nb upper triangular, forward/columnwise larft) from S = V^T V and tau; nb <= SNB.
+// One thread per column (device_utils.h:tfactor_column).
+__global__ __launch_bounds__(SNB) void larft_kernel(const float *__restrict__ S, const float *__restrict__ tau, int nb,
                                                     int nvalid, float *__restrict__ T) {
-  __shared__ float Ts[128][129];
-  __shared__ float col[128];
+  __shared__ float Ss[SNB * (SNB + 1)], Ts[SNB * (SNB + 1)], taus[SNB];
   const int r = threadIdx.x;
-  for (int c = 0; c < nb; ++c) Ts[r][c] = 0.f;
+  for (int idx = r; idx < nb * nb; idx += SNB) Ss[(idx / nb) * (SNB + 1) + (idx % nb)] = S[idx];
+  taus[r] = (r < nvalid && r < nb) ? tau[r] : 0.f;
   __syncthreads();
-  for (int i = 0; i < nb; ++i) {
-    const float ti = (i < nvalid) ? tau[i] : 0.f;
-    float acc = 0.f;
-    if (r < i)
-      for (int c = r; c < i; ++c) acc += Ts[r][c] * S[c * nb + i];
-    col[r] = -ti * acc;
-    __syncthreads();
-    if (r < i) Ts[r][i] = col[r];
-    if (r == i) Ts[i][i] = ti;
-    __syncthreads();
-  }
-  if (r < nb)
-    for (int c = 0; c < nb; ++c) T[r * nb + c] = Ts[r][c];
+  tfactor_column(Ss, taus, Ts, SNB + 1, nb, r);
+  __syncthreads();
+  for (int idx = r; idx < nb * nb; idx += SNB) T[idx] = Ts[(idx / nb) * (SNB + 1) + (idx % nb)];
 }
 
 // AB[i][d] = A[i][i - 2*NB + d] for NB <= d <= 2*NB (0 <= i-j <= NB), zero bulge room for d < NB
@@ -297,9 +288,10 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     // S = Vt Vt^T, T = larft(S, tau)
     st = gemm_launch(LAY_K, LAY_K, Vt, Vt, ws.S, SNB, SNB, mp, n, n, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    larft_kernel<<<1, 128, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
-    // Pt = Vt A22                      [SNB x mp]   (A22 symmetric: B operand k-major = A22 itself)
-    st = gemm_launch(LAY_K, LAY_M, Vt, A22, Wt, SNB, mp, mp, n, lda, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    larft_kernel<<<1, SNB, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
+    // Pt = Vt A22 = Vt A22^T           [SNB x mp]   (A22 exactly symmetric: read it K-contiguous, the NT form,
+    // whose operand fragments are ds_read_b128 on both sides)
+    st = gemm_launch(LAY_K, LAY_K, Vt, A22, Wt, SNB, mp, mp, n, lda, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     // Xt = T^T Pt  (in place is not possible for a GEMM: go through the third stack block as scratch)
     float *Xt = ws.stack + (int64_t)2 * SNB * n + gi0;

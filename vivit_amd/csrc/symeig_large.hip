@@ -31,28 +31,21 @@ __global__ __launch_bounds__(256) void bt_extract_kernel(const float *__restrict
   Yt[(int64_t)t * n + i] = v;
 }
 
-// T (upper triangular, forward/columnwise larft) from S = Y^T Y and tau
+// T (upper triangular, forward/columnwise larft) from S = Y^T Y and tau: one thread per column
+// (device_utils.h:tfactor_column), S and T staged in LDS (2 x 66 KB, dynamic)
+constexpr int BT_LD = KB + 1;
+constexpr int BT_TF_LDS = (2 * KB * BT_LD + KB) * 4;
 __global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict__ S, const float *__restrict__ tau, int jmax,
                                                         int a, float *__restrict__ T) {
-  __shared__ float Ts[KB][KB + 1];
-  __shared__ float col[KB];
+  extern __shared__ float tf_lds[];
+  float *Ss = tf_lds, *Ts = Ss + KB * BT_LD, *taus = Ts + KB * BT_LD;
   const int r = threadIdx.x;
-  for (int c = 0; c < KB; ++c) Ts[r][c] = 0.f;
+  for (int idx = r; idx < KB * KB; idx += KB) Ss[(idx / KB) * BT_LD + (idx % KB)] = S[idx];
+  taus[r] = (a + r <= jmax) ? tau[a + r] : 0.f;
   __syncthreads();
-  for (int i = 0; i < KB; ++i) {
-    const int j = a + i;
-    const float ti = (j <= jmax) ? tau[j] : 0.f;
-    // col[r] = -tau_i * sum_{c=r}^{i-1} T[r][c] S[c][i]   for r < i
-    float acc = 0.f;
-    if (r < i)
-      for (int c = r; c < i; ++c) acc += Ts[r][c] * S[c * KB + i];
-    col[r] = -ti * acc;
-    __syncthreads();
-    if (r < i) Ts[r][i] = col[r];
-    if (r == i) Ts[i][i] = ti;
-    __syncthreads();
-  }
-  for (int c = 0; c < KB; ++c) T[r * KB + c] = Ts[r][c];
+  tfactor_column(Ss, taus, Ts, BT_LD, KB, r);
+  __syncthreads();
+  for (int idx = r; idx < KB * KB; idx += KB) T[idx] = Ts[(idx / KB) * BT_LD + (idx % KB)];
 }
 
 static size_t bt_workspace_bytes(int64_t n) {
@@ -81,12 +74,19 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
   const size_t gws2_bytes = gemm_workspace_bytes(n, KB, n, false);
   void *gws2 = take(gws2_bytes);
   if (jmax < 0) return VIVIT_OK;
+  static bool tf_attr = false;
+  if (!tf_attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(bt_tfactor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            BT_TF_LDS) != hipSuccess)
+      return VIVIT_E_LAUNCH;
+    tf_attr = true;
+  }
   int st;
   for (int64_t a = (jmax / KB) * KB; a >= 0; a -= KB) {
     bt_extract_kernel<<<dim3((unsigned)cdiv(n, 256), KB), 256, 0, stream>>>(A, lda, ni, (int)a, Yt, shift, (int)jmax);
     st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KB, KB, n, n, n, KB, 1.f, 0.f, false, gws1, gws1_bytes, stream);
     if (st != VIVIT_OK) return st;
-    bt_tfactor_kernel<<<1, KB, 0, stream>>>(S, tau, (int)jmax, (int)a, T);
+    bt_tfactor_kernel<<<1, KB, BT_TF_LDS, stream>>>(S, tau, (int)jmax, (int)a, T);
     const int64_t m = n - a;  // components a+shift .. n-1 carry the block's reflectors (the columns before are
                               // zero in Yt: starting at the 128-aligned offset a keeps the operands 16-byte aligned)
     // W1[n x KB] = Zt[:, a:] * Yt[:, a:]^T
@@ -186,7 +186,6 @@ int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, in
     p += align_up(bytes, 256);
     return r;
   };
-  const int ni = (int)n;
 
   if (!vectors && use_two_stage(n, false)) return symeig_two_stage_values(A, n, lda, w, ws, info, stream);
 

@@ -541,7 +541,6 @@ int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, 
     for (int jj = 0; jj < bb; ++jj) {
       const int j = (int)(j0 + jj);
       const int g1 = (int)cdiv(n - j, 256);      // rows i >= j
-      const int g2 = (int)cdiv(n - j - 1, 256);  // rows i >= j+1
       const int nprev = (int)cdiv(n - j, 64);    // finish-kernel grid of column j-1 (rows >= j, 64 per block)
       trd_col_kernel<<<g1, 256, 0, stream>>>(A, lda, ni, j, jj, 0, ws, nprev);
       const int64_t mtrail = n - j - 1;

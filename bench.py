@@ -9,10 +9,11 @@ HBM before the timed region starts; they are synthetic (random-init MLP, uniform
 
 Multi-GPU (`torchrun --nproc-per-node N bench.py --gpus N ...`): the SAME global problem, the
 contraction (parameter) dimension of V is sharded across ranks, every rank builds a partial Gram
-matrix, the partial Grams are summed with one RCCL all-reduce over xGMI, and the eigensolver runs
-replicated (it is deterministic, so all ranks hold identical results).  That is strong scaling of
-the Gram build; `phases` reports the Gram / all-reduce / symeig split so the Gram-build scaling
-can be read off directly.
+matrix, the partial Grams are summed with one RCCL all-reduce over xGMI; the eigensolver's reduction
+and tridiagonal solve run replicated (deterministic: all ranks hold identical intermediates), its
+back-transformations (independent per eigenvector) are sharded and the eigenvector slices all-gathered.
+That is strong scaling; `phases` reports the Gram / all-reduce / symeig split so the Gram-build
+scaling can be read off directly.
 
 Prints ONE JSON line on rank 0 (contract: see DESIGN.md section "Measurement").
 """
@@ -130,16 +131,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # (functional testing on a 1-GPU box: VIVIT_DIST_BACKEND=gloo lets several ranks share device 0)
+    backend = os.environ.get("VIVIT_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from vivit_amd import _lib, kernels
+    from vivit_amd import distributed as vdist
 
     dims, batch, C = WORKLOADS[args.workload]
     n = C * batch
@@ -161,7 +169,11 @@ def main():
         if dist is not None:
             dist.all_reduce(G)
         e[2].record()
-        w, Z = kernels.symeig(G, eigenvectors=vectors, overwrite=True)
+        if dist is not None and vectors:
+            # reduction + tridiagonal solve replicated, back-transformations sharded by eigenvector, all-gather
+            w, Z = vdist.symeig(G, overwrite=True)
+        else:
+            w, Z = kernels.symeig(G, eigenvectors=vectors, overwrite=True)
         e[3].record()
         return w, Z
 
@@ -236,7 +248,8 @@ def main():
                 "workload": args.workload,
                 "n": n, "P": P_total, "P_local_rank0": p_local, "eigenvectors": vectors,
                 "pairs_per_step": n,
-                "parallelism": f"parameter-sharded Gram x{world} + RCCL all-reduce, replicated symeig" if world > 1 else "single GPU",
+                "parallelism": (f"parameter-sharded Gram x{world} + RCCL all-reduce; symeig: replicated reduction/D&C, "
+                                f"back-transformations sharded x{world} + all-gather") if world > 1 else "single GPU",
             },
             "phases": {"gram_s": gram_s, "allreduce_s": ar_s, "symeig_s": eig_s},
             "roofline": roofline,

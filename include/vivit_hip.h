@@ -110,6 +110,16 @@ size_t vivit_symeig_f32_workspace_bytes(int64_t n, int want_vectors);
 int vivit_symeig_f32(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz,
                      void *workspace, size_t workspace_bytes, int32_t *info, void *stream);
 
+/* Row-range variant for the multi-GPU path: all n eigenvalues (ascending) plus the eigenvectors
+ * row_begin .. row_end-1 (in that order) as ROWS of Zt: [row_end - row_begin, n], ldz >= n.  Reduction and
+ * tridiagonal solve run in full on every caller; only the back-transformations, which act on each eigenvector
+ * independently, are restricted to the requested range - R ranks that hold the same A (after the all-reduce
+ * of the partial Gram matrices) each pay 1/R of that stage and exchange their slices.
+ * Same workspace as vivit_symeig_f32(want_vectors = 1).  n <= 192: VIVIT_E_UNSUPPORTED (use vivit_symeig_f32).
+ * Replaces the same Tensor.symeig(eigenvectors=True) call sites as vivit_symeig_f32. */
+int vivit_symeig_rows_f32(float *A, int64_t n, int64_t lda, float *w, float *Zt, int64_t ldz, int64_t row_begin,
+                          int64_t row_end, void *workspace, size_t workspace_bytes, int32_t *info, void *stream);
+
 /* Stage 1 of vivit_symeig_f32, exported for testing: Householder tridiagonalisation
  * A = Q T Q^T (lower triangle read).  d: [n], e: [n-1], tau: [n]; on return row j of A's upper
  * triangle, A[j][j+1:], holds reflector v_j (v_j[j+1] = 1), Q = H_0 ... H_{n-3},

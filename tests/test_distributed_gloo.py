@@ -34,7 +34,21 @@ def _worker(rank, world, port, ret):
     same = all(torch.equal(gathered[0], g) for g in gathered)
     sl = column_slices(10, 3)
     ok_slices = sl == [(0, 3), (3, 6), (6, 10)]
-    ret[rank] = bool(ok and same and ok_slices)
+    # eigensolver with the back-transformation sharded by eigenvector rows + all-gather
+    from vivit_amd.distributed import row_slices, symeig as dist_symeig
+
+    w2, Z2 = dist_symeig(G)
+    w_ref, Z_ref = kernels.symeig(G, eigenvectors=True)
+    ok_eig = torch.equal(w2, w_ref) and torch.equal(Z2, Z_ref) and Z2.shape == Z_ref.shape
+    # n not divisible by the world size: padded last slice
+    g = torch.Generator().manual_seed(3)
+    M = torch.randn(7, 7, generator=g)
+    S7 = (M + M.T) / 2
+    w7, Z7 = dist_symeig(S7)
+    w7r, Z7r = kernels.symeig(S7, eigenvectors=True)
+    ok_eig = ok_eig and torch.equal(w7, w7r) and torch.equal(Z7, Z7r) and Z7.shape == (7, 7)
+    ok_rows = row_slices(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)] and row_slices(4, 8)[-1] == (4, 4)
+    ret[rank] = bool(ok and same and ok_slices and ok_eig and ok_rows)
     dist.destroy_process_group()
 
 

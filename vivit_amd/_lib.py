@@ -30,6 +30,7 @@ SIGNATURES = {
     "vivit_gram_hadamard_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _ptr]),
     "vivit_symeig_f32_workspace_bytes": (_sz, [_i64, _int]),
     "vivit_symeig_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
+    "vivit_symeig_rows_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr, _sz, _ptr, _ptr]),
     "vivit_sytrd_f32_workspace_bytes": (_sz, [_i64]),
     "vivit_sytrd_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     "vivit_sy2sb_f32_workspace_bytes": (_sz, [_i64]),

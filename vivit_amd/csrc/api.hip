@@ -8,6 +8,8 @@ int symeig_small_launch(const float *A, int64_t lda, int n, float *w, float *Z, 
 size_t symeig_large_workspace_bytes(int64_t n, bool vectors);
 int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *ws, size_t ws_bytes,
                         int32_t *info, hipStream_t stream);
+int symeig_large_rows_launch(float *A, int64_t n, int64_t lda, float *w, float *Zt, int64_t ldz, int64_t r0, int64_t r1,
+                             void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream);
 } // namespace vivit
 
 using namespace vivit;
@@ -42,6 +44,18 @@ int vivit_symeig_f32(float *A, int64_t n, int64_t lda, float *w, float *Z, int64
   if (!A || !w || lda < n || (Z && ldz < n)) return VIVIT_E_BADARG;
   if (n <= SMALL_N_MAX) return symeig_small_launch(A, lda, (int)n, w, Z, ldz, info, s);
   return symeig_large_launch(A, n, lda, w, Z, ldz, workspace, workspace_bytes, info, s);
+}
+
+// Eigenvalues (all n, ascending) and the eigenvectors row_begin .. row_end-1 as ROWS of Zt [row_end-row_begin][ldz].
+// Reduction and tridiagonal solve run in full; only the back-transformations are restricted to the requested
+// eigenvectors, so R ranks holding the same A each pay 1/R of them (vivit_amd/distributed.py gathers the slices).
+int vivit_symeig_rows_f32(float *A, int64_t n, int64_t lda, float *w, float *Zt, int64_t ldz, int64_t row_begin,
+                          int64_t row_end, void *workspace, size_t workspace_bytes, int32_t *info, void *stream) {
+  if (n < 0 || !info) return VIVIT_E_BADARG;
+  if (!A || !w || !Zt || lda < n || ldz < n || row_begin < 0 || row_end < row_begin || row_end > n) return VIVIT_E_BADARG;
+  if (n <= SMALL_N_MAX) return VIVIT_E_UNSUPPORTED;  // single-workgroup sizes: use vivit_symeig_f32 and slice
+  return symeig_large_rows_launch(A, n, lda, w, Zt, ldz, row_begin, row_end, workspace, workspace_bytes, info,
+                                  static_cast<hipStream_t>(stream));
 }
 
 } // extern "C"

@@ -29,6 +29,11 @@ int stedc_dc_launch(const float *d, const float *e, int64_t n, void *wsbase, flo
 // w[m] = m-th smallest eigenvalue of (d, e) by bisection, divided by scal[1] when scal != nullptr
 int stebz_launch(const float *d, const float *e, int64_t n, float *w, const float *scal, hipStream_t stream);
 // w = sorted(dcur) / sigma;  Z[i][p] = Qt[order[p]][i];  info = n if the input was non-finite
+int symeig_large_rows_launch(float *A, int64_t n, int64_t lda, float *w, float *Zt, int64_t ldz, int64_t r0, int64_t r1,
+                             void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream);
+int dc_rows_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *w, float *Zs,
+                   int64_t ldz, int64_t r0, int64_t r1, const float *scal, hipStream_t stream);
+int info_scal_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream);
 int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *w, float *Z,
                      int64_t ldz, const float *scal, int32_t *info, hipStream_t stream);
 

@@ -594,6 +594,31 @@ int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq,
   return launch_status();
 }
 
+// Zs[s][:] = Qt[order[r0 + s]][:]   (rows = eigenvectors r0 .. r0+rows-1 in ascending eigenvalue order)
+__global__ __launch_bounds__(256) void dc_gather_rows_kernel(int n, const float *__restrict__ Qt, int64_t ldq,
+                                                             const int *__restrict__ order, int r0, float *__restrict__ Zs,
+                                                             int64_t ldz) {
+  const int s = blockIdx.y;
+  const float *src = Qt + (int64_t)order[r0 + s] * ldq;
+  float *dst = Zs + (int64_t)s * ldz;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+// sort + scaled eigenvalues (all n) and the sorted eigenvector rows [r0, r1) of Qt copied to Zs
+int dc_rows_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *w, float *Zs,
+                   int64_t ldz, int64_t r0, int64_t r1, const float *scal, hipStream_t stream) {
+  dc_final_rank_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>((int)n, dcur, order, w, scal);
+  if (r1 > r0)
+    dc_gather_rows_kernel<<<dim3((unsigned)(cdiv(n, 1024) < 64 ? cdiv(n, 1024) : 64), (unsigned)(r1 - r0)), 256, 0, stream>>>(
+        (int)n, Qt, ldq, order, (int)r0, Zs, ldz);
+  return launch_status();
+}
+
+int info_scal_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream) {
+  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal);
+  return launch_status();
+}
+
 } // namespace vivit
 
 using namespace vivit;

@@ -60,9 +60,11 @@ static size_t bt_workspace_bytes(int64_t n) {
 
 // Zt[n x n] (ld n) <- Zt * Q^T for Q = H_0 H_1 ... (reflector j in row j of A, support i >= j + shift,
 // j <= jmax), compact-WY blocks of KB reflectors, last block first.
+// Qt: nrows x n (ld ldq); every row is transformed independently (nrows = n for the full eigenvector matrix,
+// a slice of the rows when the back-transformation is sharded over GPUs).
 template <class Take>
 static int backtransform_launch(const float *A, int64_t n, int64_t lda, const float *tau, int shift, int64_t jmax,
-                                float *Qt, Take &take, hipStream_t stream) {
+                                float *Qt, int64_t ldq, int64_t nrows, Take &take, hipStream_t stream) {
   const int ni = (int)n;
   float *Yt = (float *)take(sizeof(float) * KB * n);
   float *W1 = (float *)take(sizeof(float) * n * KB);
@@ -73,7 +75,7 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
   void *gws1 = take(gws1_bytes);
   const size_t gws2_bytes = gemm_workspace_bytes(n, KB, n, false);
   void *gws2 = take(gws2_bytes);
-  if (jmax < 0) return VIVIT_OK;
+  if (jmax < 0 || nrows <= 0) return VIVIT_OK;
   static bool tf_attr = false;
   if (!tf_attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(bt_tfactor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -90,13 +92,13 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
     const int64_t m = n - a;  // components a+shift .. n-1 carry the block's reflectors (the columns before are
                               // zero in Yt: starting at the 128-aligned offset a keeps the operands 16-byte aligned)
     // W1[n x KB] = Zt[:, a:] * Yt[:, a:]^T
-    st = gemm_launch(LAY_K, LAY_K, Qt + a, Yt + a, W1, n, KB, m, n, n, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
+    st = gemm_launch(LAY_K, LAY_K, Qt + a, Yt + a, W1, nrows, KB, m, ldq, n, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
     if (st != VIVIT_OK) return st;
     // W2 = W1 * T^T
-    st = gemm_launch(LAY_K, LAY_K, W1, T, W2, n, KB, KB, KB, KB, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
+    st = gemm_launch(LAY_K, LAY_K, W1, T, W2, nrows, KB, KB, KB, KB, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
     if (st != VIVIT_OK) return st;
     // Zt[:, a:] -= W2 * Yt[:, a:]
-    st = gemm_launch(LAY_K, LAY_M, W2, Yt + a, Qt + a, n, m, KB, KB, n, n, -1.f, 1.f, false, gws2, gws2_bytes, stream);
+    st = gemm_launch(LAY_K, LAY_M, W2, Yt + a, Qt + a, nrows, m, KB, KB, n, ldq, -1.f, 1.f, false, gws2, gws2_bytes, stream);
     if (st != VIVIT_OK) return st;
   }
   return VIVIT_OK;
@@ -174,9 +176,13 @@ static int symeig_two_stage_values(float *A, int64_t n, int64_t lda, float *w, v
   return info_finalize_launch(info, n, scal, stream);
 }
 
-int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *ws, size_t ws_bytes,
-                        int32_t *info, hipStream_t stream) {
+// rows mode (r1 >= 0): Z receives the eigenvectors r0 .. r1-1 (ascending eigenvalue order) as ROWS, [r1-r0][ldz];
+// reduction and divide & conquer are done in full, only the back-transformations are restricted to those rows
+// (rows of Zt are independent: this is what the multi-GPU path shards).  Default mode: Z = column eigenvectors.
+static int symeig_large_impl(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, int64_t r0, int64_t r1,
+                             void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream) {
   const bool vectors = Z != nullptr;
+  const bool rows_mode = r1 >= 0;
   if (n > 0x7fffffffLL / 8) return VIVIT_E_UNSUPPORTED;
   if (!ws || ws_bytes < symeig_large_workspace_bytes(n, vectors)) return VIVIT_E_WORKSPACE;
   if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return VIVIT_E_LAUNCH;
@@ -219,9 +225,18 @@ int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, in
     st = stedc_dc_launch(d, e, n, dc_base, &Qt, &dd, &order, info, stream);
     if (st != VIVIT_OK) return st;
     void *q2ws = take(q2_workspace_bytes(n));
+    if (rows_mode) {
+      st = dc_rows_launch(n, dd, Qt, n, order, w, Z, ldz, r0, r1, scal, stream);
+      if (st != VIVIT_OK) return st;
+      st = q2_apply_launch(Z, ldz, r1 - r0, n, R2, n, tau2, q2ws, stream);
+      if (st != VIVIT_OK) return st;
+      st = backtransform_launch(A, n, lda, tau1, TS_NB, n - TS_NB - 1, Z, ldz, r1 - r0, take, stream);
+      if (st != VIVIT_OK) return st;
+      return info_scal_launch(info, n, scal, stream);
+    }
     st = q2_apply_launch(Qt, n, n, n, R2, n, tau2, q2ws, stream);
     if (st != VIVIT_OK) return st;
-    st = backtransform_launch(A, n, lda, tau1, TS_NB, n - TS_NB - 1, Qt, take, stream);
+    st = backtransform_launch(A, n, lda, tau1, TS_NB, n - TS_NB - 1, Qt, n, n, take, stream);
     if (st != VIVIT_OK) return st;
     return dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, scal, info, stream);
   }
@@ -246,12 +261,31 @@ int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, in
   st = stedc_dc_launch(tw.d, tw.e, n, dc_base, &Qt, &dd, &order, info, stream);
   if (st != VIVIT_OK) return st;
 
+  if (rows_mode) {
+    st = dc_rows_launch(n, dd, Qt, n, order, w, Z, ldz, r0, r1, tw.scal, stream);
+    if (st != VIVIT_OK) return st;
+    st = backtransform_launch(A, n, lda, tw.tau, 1, n - 3, Z, ldz, r1 - r0, take, stream);
+    if (st != VIVIT_OK) return st;
+    return info_scal_launch(info, n, tw.scal, stream);
+  }
+
   // ---- stage 3: Zt = Qt * Q_H^T
-  st = backtransform_launch(A, n, lda, tw.tau, 1, n - 3, Qt, take, stream);
+  st = backtransform_launch(A, n, lda, tw.tau, 1, n - 3, Qt, n, n, take, stream);
   if (st != VIVIT_OK) return st;
 
   // ---- sort ascending, undo the scaling, deliver column eigenvectors
   return dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, tw.scal, info, stream);
+}
+
+int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *ws, size_t ws_bytes,
+                        int32_t *info, hipStream_t stream) {
+  return symeig_large_impl(A, n, lda, w, Z, ldz, 0, -1, ws, ws_bytes, info, stream);
+}
+
+int symeig_large_rows_launch(float *A, int64_t n, int64_t lda, float *w, float *Zt, int64_t ldz, int64_t r0, int64_t r1,
+                             void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream) {
+  if (!Zt || r0 < 0 || r1 < r0 || r1 > n) return VIVIT_E_BADARG;
+  return symeig_large_impl(A, n, lda, w, Zt, ldz, r0, r1, ws, ws_bytes, info, stream);
 }
 
 } // namespace vivit

@@ -176,6 +176,43 @@ def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False)
     return w, Z
 
 
+SYMEIG_ROWS_MIN_N = 193  # below: single-workgroup solver, no row-range entry point
+
+
+def symeig_rows(G: torch.Tensor, row_begin: int, row_end: int, overwrite: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All eigenvalues (ascending) of symmetric ``G`` and the eigenvectors ``row_begin .. row_end-1`` as ROWS
+    ``[row_end - row_begin, n]`` (``vivit_symeig_rows_f32``): the unit of work of one rank in the multi-GPU
+    eigensolver (``vivit_amd.distributed.symeig``)."""
+    if _TEST_BACKEND is not None:
+        w, Z = _TEST_BACKEND.symeig(G, True)
+        return w, Z.T[row_begin:row_end].contiguous()
+    _require_device(G)
+    if G.dim() != 2 or G.shape[0] != G.shape[1]:
+        raise ValueError(f"Input must be a square matrix. Got shape {tuple(G.shape)}.")
+    n = G.shape[0]
+    if not (0 <= row_begin <= row_end <= n):
+        raise ValueError(f"invalid eigenvector range [{row_begin}, {row_end}) for n = {n}")
+    if n < SYMEIG_ROWS_MIN_N:  # same HIP solver, slice afterwards
+        w, Z = symeig(G, eigenvectors=True, overwrite=overwrite)
+        return w, Z.T[row_begin:row_end].contiguous()
+    A = _as2d(G)
+    if A.data_ptr() == G.data_ptr() and not overwrite:
+        A = A.clone()
+    w = torch.empty(n, dtype=torch.float32, device=G.device)
+    Zt = torch.empty((max(row_end - row_begin, 1), n), dtype=torch.float32, device=G.device)
+    info = torch.zeros(1, dtype=torch.int32, device=G.device)
+    lib = _lib.load()
+    ws, wsb = _workspace(lib.vivit_symeig_f32_workspace_bytes(n, 1), G)
+    st = lib.vivit_symeig_rows_f32(
+        A.data_ptr(), n, _ld(A), w.data_ptr(), Zt.data_ptr(), n, row_begin, row_end, ws, wsb, info.data_ptr(), _stream(G)
+    )
+    _lib.check(st, "vivit_symeig_rows_f32")
+    nfail = int(info.item())
+    if nfail != 0:
+        raise RuntimeError(f"symeig: {nfail} eigenvalues did not converge")
+    return w, Zt[: row_end - row_begin]
+
+
 def stedc(d: torch.Tensor, e: torch.Tensor, eigenvectors: bool = False):
     """Eigen-decomposition of the symmetric tridiagonal (d, e) -- stage 2 of ``symeig`` (testing)."""
     _require_device(d, e)

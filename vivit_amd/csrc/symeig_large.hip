@@ -48,13 +48,21 @@ __global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict_
   for (int idx = r; idx < KB * KB; idx += KB) T[idx] = Ts[(idx / KB) * BT_LD + (idx % KB)];
 }
 
+// split-K slab of the [nrows x KB] products for ANY nrows <= n (row-range mode): a one-tile-wide output gets
+// up to 2048 / tiles splits, so splits * nrows <= 2048 * 128 and the slab is bounded by 2048 * 128 * KB floats
+static size_t bt_gemm_ws_bytes(int64_t n) {
+  const size_t full = gemm_workspace_bytes(n, KB, n, false);
+  const size_t bound = (size_t)2048 * 128 * KB * sizeof(float);
+  return full > bound ? full : bound;
+}
+
 static size_t bt_workspace_bytes(int64_t n) {
   size_t b = 0;
   b += align_up(sizeof(float) * KB * n, 256);      // Yt
   b += align_up(sizeof(float) * n * KB, 256) * 2;  // W1, W2
   b += align_up(sizeof(float) * KB * KB, 256) * 2; // S, T
   b += align_up(gemm_workspace_bytes(KB, KB, n, false), 256);
-  b += align_up(gemm_workspace_bytes(n, KB, n, false), 256);
+  b += align_up(bt_gemm_ws_bytes(n), 256);
   return b + 512;
 }
 
@@ -73,7 +81,7 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
   float *T = (float *)take(sizeof(float) * KB * KB);
   const size_t gws1_bytes = gemm_workspace_bytes(KB, KB, n, false);
   void *gws1 = take(gws1_bytes);
-  const size_t gws2_bytes = gemm_workspace_bytes(n, KB, n, false);
+  const size_t gws2_bytes = bt_gemm_ws_bytes(n);
   void *gws2 = take(gws2_bytes);
   if (jmax < 0 || nrows <= 0) return VIVIT_OK;
   static bool tf_attr = false;

@@ -11,7 +11,7 @@
 // Task (s, k) only depends on (s, k-1) and (s-1, k+1), so all tasks with equal t = 2 s + k are
 // independent: the host launches one kernel per wavefront step t (about 2 n launches of up to
 // n / (2 NB - 1) workgroups; a dependent launch boundary costs less than an in-kernel grid barrier
-// and cannot deadlock).  Each task is one 256-thread workgroup with E and D resident in LDS.
+// and cannot deadlock).  Each task is one 256-thread workgroup: cooperative load/store, one wave computes.
 //
 // The reflectors are kept for the back-transformation: v(s,k) at R2[s][R_k], tau at tau2[s][k].
 #include "common.h"
@@ -23,119 +23,130 @@ namespace vivit {
 constexpr int NB = 64;             // half bandwidth
 constexpr int LDAB = 2 * NB + 1;   // band row length
 
-__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of a quad
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  return v;
+// value of lane `l` (compile-time constant) as a wave-uniform scalar
+__device__ __forceinline__ float rl(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+constexpr int LDT = NB + 4;  // LDS row stride: 16-byte aligned rows, conflict-free row-per-lane ds_read_b128
+
+// One task per 256-thread workgroup.  The four waves load the two 64 x 64 blocks from the band (one
+// coalesced 256-byte segment per band row: row r of the band holds [E row r | lower D row r]
+// contiguously) into LDS; wave 0 then takes row `lane` of E and of D and column `lane` of E into
+// registers and runs the whole task without a single barrier - every cross-row quantity is a
+// v_readlane broadcast or a wave reduction - and the four waves store the blocks back.  (The first
+// version kept E and D in LDS and needed ten barrier-separated phases: 12 us per wavefront step, most
+// of it synchronisation latency.)
 __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB, int n, int t, int s_lo,
                                                          float *__restrict__ R2, int64_t ldr, float *__restrict__ tau2,
                                                          int nk, int rmod) {
-  __shared__ float E[NB][NB + 1];
-  __shared__ float D[NB][NB + 1];
-  __shared__ float v[NB], pv[NB], z[NB], pw[NB];
-  __shared__ float sc[4];  // 0: tau  1: ptau
-  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float sE[NB * LDT];
+  __shared__ __attribute__((aligned(16))) float sD[NB * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = s_lo + blockIdx.x;
   const int k = t - 2 * s;
   const int c0 = s + 1 + k * NB;
   const int L = (n - c0) < NB ? (n - c0) : NB;
   if (k < 0 || L <= 0 || s > n - 3) return;
-  const int r4 = tid >> 2, q4 = tid & 3;  // 4 threads per row, 16 columns each
 
-  // ---- load D (lower part mirrored) and, for k > 0, E and the previous reflector
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx - r * NB;
-    float dv = 0.f, ev = 0.f;
-    if (r < L && c < L) {
-      const int rr = r >= c ? r : c, cc = r >= c ? c : r;
-      dv = AB[(int64_t)(c0 + rr) * LDAB + (cc - rr + 2 * NB)];
+  // ---- load: wave w takes band rows r = w, w + 4, ...
+#pragma unroll
+  for (int rr = 0; rr < NB / 4; ++rr) {
+    const int r = 4 * rr + wave;
+    const float *row = AB + (int64_t)(c0 + (r < L ? r : 0)) * LDAB;
+    const bool in = r < L;
+    const float ev = (in && k > 0) ? row[NB - r + lane] : 0.f;           // E[r][lane]
+    const float dv = (in && lane <= r) ? row[2 * NB - r + lane] : 0.f;   // D[r][lane], lane <= r
+    sE[r * LDT + lane] = ev;
+    if (lane <= r) {
+      sD[r * LDT + lane] = dv;
+      sD[lane * LDT + r] = dv;
     }
-    if (k > 0 && r < L) ev = AB[(int64_t)(c0 + r) * LDAB + (NB + c - r)];
-    D[r][c] = dv;
-    E[r][c] = ev;
-  }
-  if (tid < NB) {
-    pv[tid] = (k > 0) ? R2[(int64_t)(s % rmod) * ldr + (c0 - NB + tid)] : 0.f;
-    v[tid] = 0.f;
-  }
-  if (tid == 0) sc[1] = (k > 0) ? tau2[(int64_t)s * nk + (k - 1)] : 0.f;
-  __syncthreads();
-
-  // ---- (i) E <- E (I - ptau pv pv^T)
-  if (k > 0) {
-    const float ptau = sc[1];
-    float dot = 0.f;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) dot += E[r4][q4 * 16 + c] * pv[q4 * 16 + c];
-    dot = quad_sum(dot) * ptau;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) E[r4][q4 * 16 + c] -= dot * pv[q4 * 16 + c];
   }
   __syncthreads();
 
-  // ---- (ii) Householder reflector from x = first column of E (k = 0: column s of the band)
-  if (tid < 64) {  // one wavefront
-    float x = 0.f;
-    if (tid < L) x = (k > 0) ? E[tid][0] : AB[(int64_t)(c0 + tid) * LDAB + (s - c0 - tid + 2 * NB)];
-    const float ssq = wave_sum(tid >= 1 ? x * x : 0.f);
-    const float alpha = __shfl(x, 0, 64);
+  if (wave == 0) {
+    float er[NB], ec[NB], d[NB];
+#pragma unroll
+    for (int c4 = 0; c4 < NB / 4; ++c4) {
+      const float4 a = *reinterpret_cast<const float4 *>(sE + lane * LDT + 4 * c4);
+      er[4 * c4] = a.x; er[4 * c4 + 1] = a.y; er[4 * c4 + 2] = a.z; er[4 * c4 + 3] = a.w;
+      const float4 b = *reinterpret_cast<const float4 *>(sD + lane * LDT + 4 * c4);
+      d[4 * c4] = b.x; d[4 * c4 + 1] = b.y; d[4 * c4 + 2] = b.z; d[4 * c4 + 3] = b.w;
+    }
+    float x;
+    float pv = 0.f;
+    if (k > 0) {
+#pragma unroll
+      for (int r = 0; r < NB; ++r) ec[r] = sE[r * LDT + lane];
+      pv = R2[(int64_t)(s % rmod) * ldr + (c0 - NB + lane)];
+      const float ptau = tau2[(int64_t)s * nk + (k - 1)];
+      // (i) E <- E (I - ptau pv pv^T): row copy and column copy
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) dot += er[c] * rl(pv, c);
+      const float g = dot * ptau;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) er[c] -= g * rl(pv, c);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) ec[r] -= rl(g, r) * pv;
+      x = er[0];
+    } else {
+      x = lane < L ? AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] : 0.f;  // column s of the band
+    }
+    // (ii) Householder reflector from x
+    const float ssq = wave_sum(lane >= 1 ? x * x : 0.f);
+    const float alpha = rl(x, 0);
     float tau = 0.f, beta = alpha, scal = 0.f;
     if (ssq > 0.f) {
       beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
       tau = (beta - alpha) / beta;
       scal = 1.f / (alpha - beta);
     }
-    if (tid < L) v[tid] = (tid == 0) ? 1.f : x * scal;
-    if (tid == 0) sc[0] = tau;
-    if (k == 0 && tid < L) AB[(int64_t)(c0 + tid) * LDAB + (s - c0 - tid + 2 * NB)] = (tid == 0) ? beta : 0.f;
-    if (k > 0 && tid == 0) sc[2] = beta;
-  }
-  __syncthreads();
-  const float tau = sc[0];
-  if (k > 0) {
-    // z[c] = sum_r v[r] E[r][c]  (4 threads per column, 16 rows each), then E -= tau v z^T
-    const int c = tid >> 2;
-    float acc = 0.f;
+    const float v = lane < L ? (lane == 0 ? 1.f : x * scal) : 0.f;
+    if (k > 0) {
+      // z[c] = tau sum_r v[r] E[r][c] (lane c, column copy); E <- E - v z^T (row copy)
+      float z = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc += v[q4 * 16 + r] * E[q4 * 16 + r][c];
-    acc = quad_sum(acc) * tau;
+      for (int r = 0; r < NB; ++r) z += rl(v, r) * ec[r];
+      z *= tau;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) E[q4 * 16 + r][c] -= v[q4 * 16 + r] * acc;
-    __syncthreads();
-    if (tid < L) E[tid][0] = (tid == 0) ? sc[2] : 0.f;  // exact zeros below the new sub-band entry
-  }
-  // ---- (iii) D <- H D H:  p = tau D v;  w = p - tau/2 (p.v) v;  D -= v w^T + w v^T
-  {
-    float acc = 0.f;
+      for (int c = 0; c < NB; ++c) er[c] -= v * rl(z, c);
+      if (lane < L) er[0] = (lane == 0) ? beta : 0.f;  // exact zeros below the new sub-band entry
+    } else if (lane < L) {
+      AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] = (lane == 0) ? beta : 0.f;
+    }
+    // (iii) D <- H D H:  p = tau D v;  w = p - tau/2 (p.v) v;  D -= v w^T + w v^T
+    float p = 0.f;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc += D[r4][q4 * 16 + c] * v[q4 * 16 + c];
-    acc = quad_sum(acc) * tau;
-    if (q4 == 0) z[r4] = acc;  // p
-  }
-  __syncthreads();
-  if (tid < 64) {
-    const float p = z[tid], vv = v[tid];
-    const float pdotv = wave_sum(p * vv);
-    pw[tid] = p - 0.5f * tau * pdotv * vv;
-  }
-  __syncthreads();
-  {
-    const float vr = v[r4], wr = pw[r4];
+    for (int c = 0; c < NB; ++c) p += d[c] * rl(v, c);
+    p *= tau;
+    const float pdotv = wave_sum(p * v);
+    const float w = p - 0.5f * tau * pdotv * v;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) D[r4][q4 * 16 + c] -= vr * pw[q4 * 16 + c] + wr * v[q4 * 16 + c];
+    for (int c = 0; c < NB; ++c) d[c] -= v * rl(w, c) + w * rl(v, c);
+    // results back to LDS (rows), reflector to global memory
+#pragma unroll
+    for (int c4 = 0; c4 < NB / 4; ++c4) {
+      if (k > 0)
+        *reinterpret_cast<float4 *>(sE + lane * LDT + 4 * c4) = make_float4(er[4 * c4], er[4 * c4 + 1], er[4 * c4 + 2], er[4 * c4 + 3]);
+      *reinterpret_cast<float4 *>(sD + lane * LDT + 4 * c4) = make_float4(d[4 * c4], d[4 * c4 + 1], d[4 * c4 + 2], d[4 * c4 + 3]);
+    }
+    if (lane < L) R2[(int64_t)(s % rmod) * ldr + c0 + lane] = v;
+    if (lane == 0) tau2[(int64_t)s * nk + k] = tau;
   }
   __syncthreads();
 
-  // ---- write back the lower part of D, E, and the reflector
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx - r * NB;
-    if (r < L && c <= r) AB[(int64_t)(c0 + r) * LDAB + (c - r + 2 * NB)] = D[r][c];
-    if (k > 0 && r < L) AB[(int64_t)(c0 + r) * LDAB + (NB + c - r)] = E[r][c];
+  // ---- store: lower part of D and E, same segments as loaded
+#pragma unroll
+  for (int rr = 0; rr < NB / 4; ++rr) {
+    const int r = 4 * rr + wave;
+    if (r < L) {
+      float *row = AB + (int64_t)(c0 + r) * LDAB;
+      if (k > 0) row[NB - r + lane] = sE[r * LDT + lane];
+      if (lane <= r) row[2 * NB - r + lane] = sD[r * LDT + lane];
+    }
   }
-  if (tid < L) R2[(int64_t)(s % rmod) * ldr + c0 + tid] = v[tid];
-  if (tid == 0) tau2[(int64_t)s * nk + k] = tau;
 }
 
 __global__ __launch_bounds__(256) void sb2st_extract_kernel(const float *__restrict__ AB, int n, float *__restrict__ d,

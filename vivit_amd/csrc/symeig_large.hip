@@ -31,58 +31,68 @@ __global__ __launch_bounds__(256) void bt_extract_kernel(const float *__restrict
   Yt[(int64_t)t * n + i] = v;
 }
 
-// T (upper triangular, forward/columnwise larft) from S = Y^T Y and tau: one thread per column
-// (device_utils.h:tfactor_column), S and T staged in LDS (2 x 66 KB, dynamic)
+// T (upper triangular, forward/columnwise larft) of ONE block of KB reflectors from its Gram block
+// S (ld lds) and tau, written into the diagonal block of the super-block factor (ld ldt): one thread per
+// column (device_utils.h:tfactor_column), S and T staged in LDS (2 x 66 KB, dynamic)
 constexpr int BT_LD = KB + 1;
 constexpr int BT_TF_LDS = (2 * KB * BT_LD + KB) * 4;
-__global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict__ S, const float *__restrict__ tau, int jmax,
-                                                        int a, float *__restrict__ T) {
+__global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict__ S, int64_t lds_, const float *__restrict__ tau,
+                                                        int jmax, int a, float *__restrict__ T, int64_t ldt) {
   extern __shared__ float tf_lds[];
   float *Ss = tf_lds, *Ts = Ss + KB * BT_LD, *taus = Ts + KB * BT_LD;
   const int r = threadIdx.x;
-  for (int idx = r; idx < KB * KB; idx += KB) Ss[(idx / KB) * BT_LD + (idx % KB)] = S[idx];
+  for (int idx = r; idx < KB * KB; idx += KB) Ss[(idx / KB) * BT_LD + (idx % KB)] = S[(int64_t)(idx / KB) * lds_ + (idx % KB)];
   taus[r] = (a + r <= jmax) ? tau[a + r] : 0.f;
   __syncthreads();
   tfactor_column(Ss, taus, Ts, BT_LD, KB, r);
   __syncthreads();
-  for (int idx = r; idx < KB * KB; idx += KB) T[idx] = Ts[(idx / KB) * BT_LD + (idx % KB)];
+  for (int idx = r; idx < KB * KB; idx += KB) T[(int64_t)(idx / KB) * ldt + (idx % KB)] = Ts[(idx / KB) * BT_LD + (idx % KB)];
 }
 
-// split-K slab of the [nrows x KB] products for ANY nrows <= n (row-range mode): a one-tile-wide output gets
-// up to 2048 / tiles splits, so splits * nrows <= 2048 * 128 and the slab is bounded by 2048 * 128 * KB floats
+// Blocks of KB reflectors are merged into super-blocks of `nsub` blocks (a power of two, up to 8: 1024
+// reflectors) so that the three products of the back-transformation have a long contraction / wide
+// output (the 256 x 256 tile kernel; Zt is streamed once per 1024 instead of once per 128 reflectors):
+//   H_1 H_2 = I - [Y1 Y2] [[T1, -T1 (Y1^T Y2) T2], [0, T2]] [Y1 Y2]^T        (applied recursively).
+static int bt_nsub(int64_t n) { return n >= 8192 ? 8 : (n >= 2048 ? 2 : 1); }
+
+// split-K slab of the products for ANY nrows <= n (row-range mode): a one-tile-wide output gets up to
+// 2048 / tiles splits, so splits * nrows <= 2048 * 128 and the slab is bounded by 2048 * 128 * KS floats
 static size_t bt_gemm_ws_bytes(int64_t n) {
-  const size_t full = gemm_workspace_bytes(n, KB, n, false);
-  const size_t bound = (size_t)2048 * 128 * KB * sizeof(float);
-  return full > bound ? full : bound;
+  const int64_t KS = (int64_t)KB * bt_nsub(n);
+  size_t b = gemm_workspace_bytes(n, KS, n, false);
+  const size_t b2 = gemm_workspace_bytes(KS, KS, n, false);
+  const size_t bound = (size_t)2048 * 128 * KS * sizeof(float);
+  if (b2 > b) b = b2;
+  return b > bound ? b : bound;
 }
 
 static size_t bt_workspace_bytes(int64_t n) {
+  const int64_t KS = (int64_t)KB * bt_nsub(n);
   size_t b = 0;
-  b += align_up(sizeof(float) * KB * n, 256);      // Yt
-  b += align_up(sizeof(float) * n * KB, 256) * 2;  // W1, W2
-  b += align_up(sizeof(float) * KB * KB, 256) * 2; // S, T
-  b += align_up(gemm_workspace_bytes(KB, KB, n, false), 256);
+  b += align_up(sizeof(float) * KS * n, 256);      // Yt
+  b += align_up(sizeof(float) * n * KS, 256) * 2;  // W1, W2
+  b += align_up(sizeof(float) * KS * KS, 256) * 3; // S, T, X
   b += align_up(bt_gemm_ws_bytes(n), 256);
   return b + 512;
 }
 
-// Zt[n x n] (ld n) <- Zt * Q^T for Q = H_0 H_1 ... (reflector j in row j of A, support i >= j + shift,
-// j <= jmax), compact-WY blocks of KB reflectors, last block first.
-// Qt: nrows x n (ld ldq); every row is transformed independently (nrows = n for the full eigenvector matrix,
-// a slice of the rows when the back-transformation is sharded over GPUs).
+// Zt[nrows x n] (ld ldq) <- Zt * Q^T for Q = H_0 H_1 ... (reflector j in row j of A, support i >= j + shift,
+// j <= jmax), compact-WY super-blocks, last one first.  Every row is transformed independently (nrows = n for
+// the full eigenvector matrix, a slice of the rows when the back-transformation is sharded over GPUs).
 template <class Take>
 static int backtransform_launch(const float *A, int64_t n, int64_t lda, const float *tau, int shift, int64_t jmax,
                                 float *Qt, int64_t ldq, int64_t nrows, Take &take, hipStream_t stream) {
   const int ni = (int)n;
-  float *Yt = (float *)take(sizeof(float) * KB * n);
-  float *W1 = (float *)take(sizeof(float) * n * KB);
-  float *W2 = (float *)take(sizeof(float) * n * KB);
-  float *S = (float *)take(sizeof(float) * KB * KB);
-  float *T = (float *)take(sizeof(float) * KB * KB);
-  const size_t gws1_bytes = gemm_workspace_bytes(KB, KB, n, false);
-  void *gws1 = take(gws1_bytes);
-  const size_t gws2_bytes = bt_gemm_ws_bytes(n);
-  void *gws2 = take(gws2_bytes);
+  const int nsub = bt_nsub(n);
+  const int64_t KS = (int64_t)KB * nsub;
+  float *Yt = (float *)take(sizeof(float) * KS * n);
+  float *W1 = (float *)take(sizeof(float) * n * KS);
+  float *W2 = (float *)take(sizeof(float) * n * KS);
+  float *S = (float *)take(sizeof(float) * KS * KS);
+  float *T = (float *)take(sizeof(float) * KS * KS);
+  float *X = (float *)take(sizeof(float) * KS * KS);
+  const size_t gws_bytes = bt_gemm_ws_bytes(n);
+  void *gws = take(gws_bytes);
   if (jmax < 0 || nrows <= 0) return VIVIT_OK;
   static bool tf_attr = false;
   if (!tf_attr) {
@@ -92,21 +102,34 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
     tf_attr = true;
   }
   int st;
-  for (int64_t a = (jmax / KB) * KB; a >= 0; a -= KB) {
-    bt_extract_kernel<<<dim3((unsigned)cdiv(n, 256), KB), 256, 0, stream>>>(A, lda, ni, (int)a, Yt, shift, (int)jmax);
-    st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KB, KB, n, n, n, KB, 1.f, 0.f, false, gws1, gws1_bytes, stream);
+  for (int64_t a = (jmax / KS) * KS; a >= 0; a -= KS) {
+    // reflector rows of the super-block (zero rows for indices beyond jmax), their Gram matrix, block T factors
+    bt_extract_kernel<<<dim3((unsigned)cdiv(n, 256), (unsigned)KS), 256, 0, stream>>>(A, lda, ni, (int)a, Yt, shift, (int)jmax);
+    st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KS, KS, n, n, n, KS, 1.f, 0.f, false, gws, gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    bt_tfactor_kernel<<<1, KB, BT_TF_LDS, stream>>>(S, tau, (int)jmax, (int)a, T);
-    const int64_t m = n - a;  // components a+shift .. n-1 carry the block's reflectors (the columns before are
-                              // zero in Yt: starting at the 128-aligned offset a keeps the operands 16-byte aligned)
-    // W1[n x KB] = Zt[:, a:] * Yt[:, a:]^T
-    st = gemm_launch(LAY_K, LAY_K, Qt + a, Yt + a, W1, nrows, KB, m, ldq, n, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
+    if (nsub > 1 && hipMemsetAsync(T, 0, sizeof(float) * KS * KS, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    for (int b = 0; b < nsub; ++b)
+      bt_tfactor_kernel<<<1, KB, BT_TF_LDS, stream>>>(S + (int64_t)b * KB * (KS + 1), KS, tau, (int)jmax, (int)(a + b * KB),
+                                                      T + (int64_t)b * KB * (KS + 1), KS);
+    // merge tree: T12 = -T1 S12 T2 for halves of size h = KB, 2 KB, ...
+    for (int64_t h = KB; h < KS; h *= 2)
+      for (int64_t o = 0; o < KS; o += 2 * h) {
+        const float *T1 = T + o * (KS + 1), *T2 = T + (o + h) * (KS + 1), *S12 = S + o * KS + (o + h);
+        st = gemm_launch(LAY_K, LAY_M, T1, S12, X, h, h, h, KS, KS, h, 1.f, 0.f, false, gws, gws_bytes, stream);
+        if (st != VIVIT_OK) return st;
+        st = gemm_launch(LAY_K, LAY_M, X, T2, T + o * KS + (o + h), h, h, h, h, KS, KS, -1.f, 0.f, false, gws, gws_bytes, stream);
+        if (st != VIVIT_OK) return st;
+      }
+    const int64_t m = n - a;  // components a+shift .. n-1 carry the super-block's reflectors (the columns before
+                              // are zero in Yt: starting at the aligned offset a keeps the operands 16-byte aligned)
+    // W1[nrows x KS] = Zt[:, a:] * Yt[:, a:]^T
+    st = gemm_launch(LAY_K, LAY_K, Qt + a, Yt + a, W1, nrows, KS, m, ldq, n, KS, 1.f, 0.f, false, gws, gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     // W2 = W1 * T^T
-    st = gemm_launch(LAY_K, LAY_K, W1, T, W2, nrows, KB, KB, KB, KB, KB, 1.f, 0.f, false, gws2, gws2_bytes, stream);
+    st = gemm_launch(LAY_K, LAY_K, W1, T, W2, nrows, KS, KS, KS, KS, KS, 1.f, 0.f, false, gws, gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     // Zt[:, a:] -= W2 * Yt[:, a:]
-    st = gemm_launch(LAY_K, LAY_M, W2, Yt + a, Qt + a, nrows, m, KB, KB, n, ldq, -1.f, 1.f, false, gws2, gws2_bytes, stream);
+    st = gemm_launch(LAY_K, LAY_M, W2, Yt + a, Qt + a, nrows, m, KS, KS, n, ldq, -1.f, 1.f, false, gws, gws_bytes, stream);
     if (st != VIVIT_OK) return st;
   }
   return VIVIT_OK;

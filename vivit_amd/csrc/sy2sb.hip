@@ -25,14 +25,19 @@ namespace vivit {
 constexpr int SNB = 64;     // half bandwidth = panel width (must equal sb2st.hip's NB)
 constexpr int QT = 128;     // rows per workgroup tile in the panel QR
 
+struct QrPart {
+  float *ssq;   // [2][nwg]
+  float *u;     // [2][nwg][SNB]
+  float *diag;  // [2][SNB]
+};
+
 struct Sy2sbWs {
   float *pan;      // [n][SNB]   compact copy of the current panel block
   float *stack;    // [3*SNB][n] Vt | Wt | Vt   (k-major, ld = n)
-  float *zpart;    // [nwg][SNB]
-  float *ssqpart;  // [nwg]
   float *S, *T, *Y3, *S2;  // [SNB*SNB] each
   float *tau1;     // [n]
   float *betas;    // [SNB] diagonal of R of the current panel
+  QrPart qp;       // partials of the fused panel QR
   void *gws;       // split-K workspace
   size_t gws_bytes;
 };
@@ -45,41 +50,26 @@ __global__ __launch_bounds__(256) void sb_panel_load_kernel(const float *__restr
   pan[idx] = A[(j0 + SNB + r) * lda + j0 + c];
 }
 
-// partial sum of squares of column c below row c (rows r > c): used for column 0 of a panel
-__global__ __launch_bounds__(256) void qr_ssq_kernel(const float *__restrict__ pan, int64_t mp, int c, float *__restrict__ ssqpart) {
-  __shared__ float red[4];
-  const int64_t r = (int64_t)blockIdx.x * QT + (threadIdx.x >> 1);
-  float s = 0.f;
-  if ((threadIdx.x & 1) == 0 && r < mp && r > c) {
-    const float x = pan[r * SNB + c];
-    s = x * x;
-  }
-  s = block_sum(s, red, threadIdx.x);
-  if (threadIdx.x == 0) ssqpart[blockIdx.x] = s;
-}
+// ---- fused panel QR step: ONE launch per column (the dependent kernel boundary is what a column costs).
+// Launch c (c = -1: prologue) does, per 128-row workgroup tile held in LDS:
+//   1. sums the per-workgroup partials of column c left by launch c-1:  ssq = sum_{r>c} x_r^2 and
+//      u[cc] = sum_{r>c} x_r pan[r][cc]  (x = column c);  with the diagonal row (handed over in `diag`)
+//      that gives the reflector scalars and  z = tau v^T P = tau (pan[c][:] + scal u)  without a second pass
+//   2. writes v for its rows (k-major stack copies, reflector row of A) and updates its rows of the panel
+//   3. produces the partials (and, if it owns row c+1, the diagonal row) for column c+1 from the updated tile.
+// Partials and diagonal row are double-buffered by column parity (a fast workgroup may already write the
+// partials of column c+1 while a slow one still reads those of column c).
 
-// Column c, launch 1: reflector scalars (redundantly per workgroup), v for this tile's rows, partial
-// z[cc] = sum_r v_r pan[r][cc] (cc > c).
-__global__ __launch_bounds__(256) void qr_col1_kernel(float *__restrict__ pan, int64_t mp, int c, int npart,
-                                                      const float *__restrict__ ssqpart, float *__restrict__ zpart,
+__global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, int64_t mp, int c, int ncol, int nwg, QrPart pt,
                                                       float *__restrict__ stack, int64_t lds_, int64_t gi0,
                                                       float *__restrict__ A, int64_t lda, int64_t j0,
                                                       float *__restrict__ tau1, float *__restrict__ betas) {
   __shared__ float tile[QT][SNB + 1];
   __shared__ float vs[QT];
+  __shared__ float zs[SNB];
   __shared__ float zq[4][SNB];
   __shared__ float red[4];
   const int tid = threadIdx.x;
-  float s = 0.f;
-  for (int t = tid; t < npart; t += 256) s += ssqpart[t];
-  const float ssq = block_sum(s, red, tid);
-  const float alpha = pan[(int64_t)c * SNB + c];
-  float tau = 0.f, beta = alpha, scal = 0.f;
-  if (ssq > 0.f) {
-    beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
-    tau = (beta - alpha) / beta;
-    scal = 1.f / (alpha - beta);
-  }
   const int64_t r0 = (int64_t)blockIdx.x * QT;
   for (int idx = tid; idx < QT * (SNB / 4); idx += 256) {
     const int rl = idx / (SNB / 4), c4 = (idx - rl * (SNB / 4)) * 4;
@@ -91,87 +81,91 @@ __global__ __launch_bounds__(256) void qr_col1_kernel(float *__restrict__ pan, i
     tile[rl][c4 + 2] = ok ? x.z : 0.f;
     tile[rl][c4 + 3] = ok ? x.w : 0.f;
   }
-  __syncthreads();
-  if (tid < QT) {
-    const int64_t r = r0 + tid;
-    float v = 0.f;
-    if (r < mp) {
-      if (r == c) v = 1.f;
-      else if (r > c) v = tile[tid][c] * scal;
-      // k-major copies for the GEMMs and the reflector row for the back-transformation
-      stack[(int64_t)c * lds_ + gi0 + r] = v;
-      stack[(int64_t)(2 * SNB + c) * lds_ + gi0 + r] = v;
-      if (r >= c) A[(j0 + c) * lda + gi0 + r] = v;
+  if (c >= 0) {
+    const int par = c & 1;
+    const float *ssqin = pt.ssq + (int64_t)par * nwg;
+    const float *uin = pt.u + (int64_t)par * nwg * SNB;
+    const float *din = pt.diag + par * SNB;
+    float sacc = 0.f;
+    for (int w = tid; w < nwg; w += 256) sacc += ssqin[w];
+    const float ssq = block_sum(sacc, red, tid);
+    {
+      const int cc = tid & 63, q = tid >> 6;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int w = q;
+      for (; w + 12 < nwg; w += 16) {
+        a0 += uin[(int64_t)w * SNB + cc];
+        a1 += uin[(int64_t)(w + 4) * SNB + cc];
+        a2 += uin[(int64_t)(w + 8) * SNB + cc];
+        a3 += uin[(int64_t)(w + 12) * SNB + cc];
+      }
+      for (; w < nwg; w += 4) a0 += uin[(int64_t)w * SNB + cc];
+      zq[q][cc] = (a0 + a1) + (a2 + a3);
     }
-    vs[tid] = v;
-  }
-  __syncthreads();
-  {
-    const int cc = tid & 63, q = tid >> 6;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int rl = q * 32; rl < q * 32 + 32; ++rl) acc += vs[rl] * tile[rl][cc];
-    zq[q][cc] = acc;
-  }
-  __syncthreads();
-  if (tid < SNB) zpart[(int64_t)blockIdx.x * SNB + tid] = (zq[0][tid] + zq[1][tid]) + (zq[2][tid] + zq[3][tid]);
-  // (pan[c][c] itself is left alone: other workgroups of this launch still read it as alpha)
-  if (blockIdx.x == 0 && tid == 0) { tau1[j0 + c] = tau; betas[c] = beta; }
-}
-
-// Column c, launch 2: z = sum of partials; pan[r][cc] -= tau v_r z[cc] (cc > c, r >= c); partial
-// sum of squares of column c+1 below row c+1.
-__global__ __launch_bounds__(256) void qr_col2_kernel(float *__restrict__ pan, int64_t mp, int c, int nwg,
-                                                      const float *__restrict__ zpart, const float *__restrict__ stack,
-                                                      int64_t lds_, int64_t gi0, const float *__restrict__ tau1, int64_t j0,
-                                                      float *__restrict__ ssqpart) {
-  __shared__ float zs[SNB];
-  __shared__ float zq[4][SNB];
-  __shared__ float red[4];
-  const int tid = threadIdx.x;
-  {
-    const int cc = tid & 63, q = tid >> 6;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int w = q;
-    for (; w + 12 < nwg; w += 16) {
-      a0 += zpart[(int64_t)w * SNB + cc];
-      a1 += zpart[(int64_t)(w + 4) * SNB + cc];
-      a2 += zpart[(int64_t)(w + 8) * SNB + cc];
-      a3 += zpart[(int64_t)(w + 12) * SNB + cc];
+    const float alpha = din[c];
+    float tau = 0.f, beta = alpha, scal = 0.f;
+    if (ssq > 0.f) {
+      beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
+      tau = (beta - alpha) / beta;
+      scal = 1.f / (alpha - beta);
     }
-    for (; w < nwg; w += 4) a0 += zpart[(int64_t)w * SNB + cc];
-    zq[q][cc] = (a0 + a1) + (a2 + a3);
-  }
-  __syncthreads();
-  if (tid < SNB) zs[tid] = (zq[0][tid] + zq[1][tid]) + (zq[2][tid] + zq[3][tid]);
-  __syncthreads();
-  const float tau = tau1[j0 + c];
-  const int64_t r = (int64_t)blockIdx.x * QT + (tid >> 1);
-  const int half = tid & 1;
-  float sq = 0.f;
-  if (r < mp && r >= c) {
-    const float tv = tau * stack[(int64_t)c * lds_ + gi0 + r];
-    float *row = pan + r * SNB + half * 32;
-#pragma unroll
-    for (int g4 = 0; g4 < 8; ++g4) {
-      const int cc = half * 32 + 4 * g4;
-      if (cc + 3 > c) {
-        float4 x = *reinterpret_cast<float4 *>(row + 4 * g4);
-        if (cc + 0 > c) x.x -= tv * zs[cc + 0];
-        if (cc + 1 > c) x.y -= tv * zs[cc + 1];
-        if (cc + 2 > c) x.z -= tv * zs[cc + 2];
-        if (cc + 3 > c) x.w -= tv * zs[cc + 3];
-        *reinterpret_cast<float4 *>(row + 4 * g4) = x;
-        if (r > c + 1) {
-          const int d = c + 1 - cc;  // position of column c+1 inside this float4, if any
-          const float xs = d == 0 ? x.x : d == 1 ? x.y : d == 2 ? x.z : d == 3 ? x.w : 0.f;
-          sq += xs * xs;
-        }
+    __syncthreads();  // tile and zq complete
+    if (tid < SNB) {
+      const float u = (zq[0][tid] + zq[1][tid]) + (zq[2][tid] + zq[3][tid]);
+      zs[tid] = tid > c ? tau * (din[tid] + scal * u) : 0.f;
+    }
+    if (tid < QT) {
+      const int64_t r = r0 + tid;
+      float v = 0.f;
+      if (r < mp) {
+        if (r == c) v = 1.f;
+        else if (r > c) v = tile[tid][c] * scal;
+        // k-major copies for the GEMMs and the reflector row for the back-transformation
+        stack[(int64_t)c * lds_ + gi0 + r] = v;
+        stack[(int64_t)(2 * SNB + c) * lds_ + gi0 + r] = v;
+        if (r >= c) A[(j0 + c) * lda + gi0 + r] = v;
+      }
+      vs[tid] = v;
+    }
+    __syncthreads();
+    // pan[r][cc] -= v_r z[cc]   (cc > c; rows above c have v = 0)
+    for (int idx = tid; idx < QT * SNB; idx += 256) {
+      const int rl = idx >> 6, cc = idx & 63;
+      const float v = vs[rl];
+      if (cc > c && v != 0.f) {
+        const float x = tile[rl][cc] - v * zs[cc];
+        tile[rl][cc] = x;
+        if (r0 + rl < mp) pan[(r0 + rl) * SNB + cc] = x;
       }
     }
+    if (blockIdx.x == 0 && tid == 0) { tau1[j0 + c] = tau; betas[c] = beta; }
   }
-  sq = block_sum(sq, red, tid);
-  if (tid == 0) ssqpart[blockIdx.x] = sq;
+  __syncthreads();
+  // ---- partials for column cn = c + 1
+  const int cn = c + 1;
+  if (cn >= ncol) return;
+  {
+    const int par = cn & 1;
+    if (tid < QT) {
+      const int64_t r = r0 + tid;
+      vs[tid] = (r > cn && r < mp) ? tile[tid][cn] : 0.f;   // x (unscaled column cn below its diagonal)
+    }
+    __syncthreads();
+    float sq = 0.f;
+    if (tid < QT) sq = vs[tid] * vs[tid];
+    sq = block_sum(sq, red, tid);
+    if (tid == 0) pt.ssq[(int64_t)par * nwg + blockIdx.x] = sq;
+    {
+      const int cc = tid & 63, q = tid >> 6;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int rl = q * 32; rl < q * 32 + 32; ++rl) acc += vs[rl] * tile[rl][cc];
+      zq[q][cc] = acc;
+    }
+    __syncthreads();
+    if (tid < SNB) pt.u[((int64_t)par * nwg + blockIdx.x) * SNB + tid] = (zq[0][tid] + zq[1][tid]) + (zq[2][tid] + zq[3][tid]);
+    if (cn >= r0 && cn < r0 + QT && tid < SNB) pt.diag[par * SNB + tid] = tile[cn - r0][tid];
+  }
 }
 
 // R (upper triangular, rows 0..min(NB, mp)-1 of the factored panel) back into A; zeros below it inside
@@ -231,8 +225,9 @@ size_t sy2sb_workspace_bytes(int64_t n) {
   size_t b = 0;
   b += align_up(sizeof(float) * n * SNB, 256);          // pan
   b += align_up(sizeof(float) * 3 * SNB * n, 256);      // stack
-  b += align_up(sizeof(float) * nwg * SNB, 256);        // zpart
-  b += align_up(sizeof(float) * nwg, 256);              // ssqpart
+  b += align_up(sizeof(float) * 2 * nwg * SNB, 256);    // QR partials u (double-buffered)
+  b += align_up(sizeof(float) * 2 * nwg, 256);          // QR partials ssq
+  b += align_up(sizeof(float) * 2 * SNB, 256);          // QR diagonal row
   b += align_up(sizeof(float) * SNB * SNB, 256) * 4;    // S T Y3 S2
   b += align_up(sizeof(float) * n, 256);                // tau1
   b += align_up(sizeof(float) * SNB, 256);              // betas
@@ -253,8 +248,9 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
   Sy2sbWs ws;
   ws.pan = (float *)take(sizeof(float) * n * SNB);
   ws.stack = (float *)take(sizeof(float) * 3 * SNB * n);
-  ws.zpart = (float *)take(sizeof(float) * nwg * SNB);
-  ws.ssqpart = (float *)take(sizeof(float) * nwg);
+  ws.qp.u = (float *)take(sizeof(float) * 2 * nwg * SNB);
+  ws.qp.ssq = (float *)take(sizeof(float) * 2 * nwg);
+  ws.qp.diag = (float *)take(sizeof(float) * 2 * SNB);
   ws.S = (float *)take(sizeof(float) * SNB * SNB);
   ws.T = (float *)take(sizeof(float) * SNB * SNB);
   ws.Y3 = (float *)take(sizeof(float) * SNB * SNB);
@@ -273,11 +269,8 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     const int g = (int)cdiv(mp, QT);
     if (hipMemsetAsync(ws.stack, 0, sizeof(float) * 3 * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
     sb_panel_load_kernel<<<(unsigned)cdiv(mp * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan);
-    qr_ssq_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, 0, ws.ssqpart);
-    for (int c = 0; c < ncol; ++c) {
-      qr_col1_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, g, ws.ssqpart, ws.zpart, ws.stack, n, gi0, A, lda, j0, ws.tau1, ws.betas);
-      qr_col2_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, g, ws.zpart, ws.stack, n, gi0, ws.tau1, j0, ws.ssqpart);
-    }
+    for (int c = -1; c < ncol; ++c)  // c = -1: partials of column 0
+      qr_step_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, ncol, g, ws.qp, ws.stack, n, gi0, A, lda, j0, ws.tau1, ws.betas);
     sb_panel_store_kernel<<<(unsigned)cdiv(SNB * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan, ws.betas);
 
     // ---- two-sided update of A22 = A[gi0:, gi0:]  (mp x mp), all operands k-major with ld = n

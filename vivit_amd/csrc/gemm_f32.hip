@@ -212,6 +212,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
+  // C prefetch (accumulating GEMMs on interior tiles): the second-level accumulator starts as (beta/alpha) C,
+  // read while the K loop runs, instead of reading C after it with nothing left to hide the latency
+  // (the rank-128 updates of the band reduction and the back-transformation have K = 128: 8 K tiles).
+  const bool prefetch_c = p.ksplit <= 1 && p.beta != 0.f && p.alpha != 0.f && row0 + BM <= p.M && col0 + BN <= p.N;
+  if (prefetch_c) {
+    const float ba = p.beta / p.alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        gcptr cbase = (gcptr)p.C + (row0 + wm * 64 + i * 32 + 4 * h) * p.ldc + col0 + wn * 64 + j * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[i][j][e] = ba * cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * p.ldc];
+      }
+  }
 
   // One K tile of MFMA work from LDS buffer `cur`.
   auto compute = [&](int cur) {
@@ -248,6 +263,54 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     constexpr bool FAST = MODE < 2;
     // modes 0/1 cover the full K tiles; a ragged last K tile goes through the scalar loader.
     const int nt_fast = FAST ? (int)((kend - kbeg) / BK) : 0;
+    if constexpr (WM == 1) {
+      // 64-row outputs stream their big operand once from HBM (the panel products of the band reduction):
+      // two register sets keep the global loads TWO K tiles ahead (2 x 20 KB per workgroup in flight; with
+      // one tile ahead the kernel was latency-bound at 1.4 TB/s)
+      const int nt_fast = FAST ? (int)((kend - kbeg) / BK) : 0;
+      float4 sA[2][BM / 64], sB[2][BN / 64];
+      auto load2 = [&](int t, auto par) __attribute__((always_inline)) {
+        constexpr int P = decltype(par)::value;
+        const int64_t k0 = kbeg + (int64_t)t * BK;
+        if (FAST && t < nt_fast) {
+          tile_load<ALAY, MODE, BM>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, sA[P]);
+          tile_load<BLAY, MODE, BN>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, sB[P]);
+        } else {
+          tile_load<ALAY, 2, BM>((gcptr)p.A, p.lda, row0, p.M, k0, kend, tid, sA[P]);
+          tile_load<BLAY, 2, BN>((gcptr)p.B, p.ldb, col0, p.N, k0, kend, tid, sB[P]);
+        }
+      };
+      using P0 = std::integral_constant<int, 0>;
+      using P1 = std::integral_constant<int, 1>;
+      if (nt > 0) {
+        load2(0, P0{});
+        tile_store<ALAY, BM>(SA(0), tid, sA[0]);
+        tile_store<BLAY, BN>(SB_(0), tid, sB[0]);
+        if (nt > 1) load2(1, P1{});
+      }
+      __syncthreads();
+      int since_flush = 0;
+      // tile t: LDS buffer t & 1; register set t & 1 is free (tile t is in LDS) and receives tile t + 2;
+      // tile t + 1 waits in set (t + 1) & 1 and is written to LDS after the MFMAs
+      auto step = [&](int t, auto par) __attribute__((always_inline)) {
+        constexpr int P = decltype(par)::value;
+        if (t + 2 < nt) load2(t + 2, par);
+        compute(P);
+        if (++since_flush == FLUSH_TILES) { since_flush = 0; flush(); }
+        if (t + 1 < nt) {
+          tile_store<ALAY, BM>(SA(P ^ 1), tid, sA[P ^ 1]);
+          tile_store<BLAY, BN>(SB_(P ^ 1), tid, sB[P ^ 1]);
+        }
+        __syncthreads();
+      };
+      int t = 0;
+      for (; t + 1 < nt; t += 2) {
+        step(t, P0{});
+        step(t + 1, P1{});
+      }
+      if (t < nt) step(t, P0{});
+      return;
+    }
     float4 stA[BM / 64], stB[BN / 64];
     auto load = [&](int t) {
       const int64_t k0 = kbeg + (int64_t)t * BK;
@@ -305,14 +368,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j) {
         gptr cbase = Cout + (row0 + wm * 64 + i * 32 + 4 * h) * ldc + col0 + wn * 64 + j * 32 + r;
         float old[16];
-        if (beta != 0.f) {
+        const bool rd = beta != 0.f && !prefetch_c;
+        if (rd) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) old[e] = cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc];
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           float v = alpha * tot[i][j][e];
-          if (beta != 0.f) v += beta * old[e];
+          if (rd) v += beta * old[e];
           cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc] = v;
           tot[i][j][e] = v;  // final value: the mirrored store below reuses it
         }
@@ -669,7 +733,9 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
     // one resident round (2 workgroups per CU x 256 CUs) for compute-bound shapes; a one-tile-wide
     // output streams its big operand once and is bandwidth-bound: more, shorter splits keep enough
     // bytes in flight
-    int64_t want = (tm == 1 || tn == 1) ? 2048 / tiles : 512 / tiles;
+    static int skinny_want = -1;
+    if (skinny_want < 0) { const char *e = getenv("VIVIT_SKINNY_WANT"); skinny_want = e ? atoi(e) : 2048; }
+    int64_t want = (tm == 1 || tn == 1) ? skinny_want / tiles : 512 / tiles;
     int64_t maxs = (tm == 1 || tn == 1) ? ktiles / 8 : ktiles / 32;
     int64_t s = want < maxs ? want : maxs;
     if (s > 64) s = 64;

@@ -16,6 +16,8 @@
 //
 // Outputs: band entries stay in A (A[i][j], 0 <= i-j <= NB), reflector c of panel p goes to the
 // dead upper-triangle row j0+c: A[j0+c][j0+NB+c ..] (v[j0+NB+c] = 1), tau1[j0+c].
+#include <cstdlib>
+
 #include "common.h"
 #include "device_utils.h"
 #include "eig_internal.h"
@@ -284,7 +286,7 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     larft_kernel<<<1, SNB, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
     // Pt = Vt A22 = Vt A22^T           [SNB x mp]   (A22 exactly symmetric: read it K-contiguous, the NT form,
     // whose operand fragments are ds_read_b128 on both sides)
-    st = gemm_launch(LAY_K, LAY_K, Vt, A22, Wt, SNB, mp, mp, n, lda, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    st = gemm_launch(LAY_K, getenv("VIVIT_PT_NN") ? LAY_M : LAY_K, Vt, A22, Wt, SNB, mp, mp, n, lda, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     // Xt = T^T Pt  (in place is not possible for a GEMM: go through the third stack block as scratch)
     float *Xt = ws.stack + (int64_t)2 * SNB * n + gi0;

@@ -16,7 +16,9 @@ def _rel(a, b):
 @pytest.mark.parametrize(
     "m,n,k",
     [(1, 1, 1), (5, 7, 3), (128, 128, 16), (130, 250, 37), (64, 300, 1000), (257, 129, 515), (10, 10, 5000), (300, 300, 70000),
-     (64, 1024, 4096), (33, 515, 129), (64, 2051, 20000), (17, 260, 64)],
+     (64, 1024, 4096), (33, 515, 129), (64, 2051, 20000), (17, 260, 64),
+     # 64-row streaming kernel (gemm64_dma_kernel): N, K >= 2048, K % 16 == 0; ragged N, M < 64, deep K (splits)
+     (64, 2048, 2048), (36, 2100, 6400), (4, 4096, 40000), (64, 2304, 33 * 1024)],
 )
 def test_gemm_variants(m, n, k):
     from vivit_amd import kernels

@@ -455,7 +455,7 @@ constexpr int STG2 = 2 * T2;                        // one stage: A tile, B tile
 constexpr int GEMM256_LDS_BYTES = 3 * STG2 * 4;     // 96 KB
 constexpr int FLUSH2_TILES = 8192 / BK;             // second-level accumulation period of this kernel
 
-template <int LAY>
+template <int LAY, int ROWS = B2>
 __device__ __forceinline__ void frag_half(const float *__restrict__ s, int row, int q, int h, float (&fr)[4]) {
   if (LAY == LAY_K) {
     const int c = (2 * q + h) ^ ((row >> 2) & 3);
@@ -463,22 +463,23 @@ __device__ __forceinline__ void frag_half(const float *__restrict__ s, int row, 
     fr[0] = v.x; fr[1] = v.y; fr[2] = v.z; fr[3] = v.w;
   } else {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) fr[t] = s[(8 * q + 4 * h + t) * B2 + row];
+    for (int t = 0; t < 4; ++t) fr[t] = s[(8 * q + 4 * h + t) * ROWS + row];
   }
 }
 
 // this lane's global source for 1 KB block `blk` (0..15) of an operand tile at K offset 0
-template <int LAY>
+template <int LAY, int ROWS = B2>
 __device__ __forceinline__ gcptr dma_src(const float *P, int64_t ld, int64_t row0, int64_t nrows, int blk, int lane) {
   if (LAY == LAY_K) {  // block = 16 rows x 16 k; lane -> (row, swizzled 16-byte chunk)
     const int rl = lane >> 2, pos = lane & 3;
     int64_t row = row0 + 16 * blk + rl;
     row = row < nrows ? row : nrows - 1;
     return (gcptr)(P + row * ld + 4 * (pos ^ ((rl >> 2) & 3)));
-  } else {             // block = k row `blk` x 256 rows; lane -> rows 4 lane .. 4 lane + 3
-    int64_t row = row0 + 4 * lane;
+  } else {             // tile [16 k][ROWS]; block = its floats [256 blk, 256 blk + 256); lane -> 4 of them
+    const int f = 256 * blk + 4 * lane, kr = f / ROWS;
+    int64_t row = row0 + (f - kr * ROWS);
     row = row + 4 <= nrows ? row : nrows - 4;  // nrows % 4 == 0 and nrows >= 4 (host)
-    return (gcptr)(P + (int64_t)blk * ld + row);
+    return (gcptr)(P + (int64_t)kr * ld + row);
   }
 }
 
@@ -699,6 +700,146 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming variant for outputs with at most 64 rows (the panel product P^T = V^T A22 of the band
+// reduction: 64 x m x m, its big operand read exactly once from HBM, 32 flop/byte).  Such a product is
+// HBM-bound and needs ~100 KB in flight per CU; the register-staged tile has 20-40.  Same global -> LDS
+// DMA and swizzled tiles as gemm256_kernel, 64 x 256 tile (four waves of 64 x 64), SEVEN LDS stages of
+// 20 KB: six K tiles (120 KB) are in flight while one is being multiplied.  Accumulators are 64 registers,
+// nothing spills, so the waits are plain asm `s_waitcnt vmcnt(20)` (all but the four newest tiles landed).
+constexpr int G64_NST = 7;
+constexpr int G64_TA = 64 * BK, G64_TB = 256 * BK, G64_STG = G64_TA + G64_TB;  // floats
+constexpr int GEMM64_LDS_BYTES = G64_NST * G64_STG * 4;                        // 140 KB
+constexpr int G64_NDMA = 5;                                                    // DMA instructions per wave and tile
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(256, 1) void gemm64_dma_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem3[];
+  const int tj = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t col0 = (int64_t)tj * 256;
+  const int64_t kbeg = (int64_t)blockIdx.y * p.kchunk;
+  const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  const int nt = (int)((kend - kbeg) / BK);  // K and kchunk are multiples of 16 (host)
+
+  f32x16 acc[2][2];
+  auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+  clear_acc();
+
+  const bool partial = p.ksplit > 1;
+  gptr Cout = (gptr)(partial ? p.slab + (int64_t)blockIdx.y * p.M * p.N : p.C);
+  const int64_t ldc = partial ? p.N : p.ldc;
+  const float alpha = partial ? 1.f : p.alpha;
+  const float beta0 = partial ? 0.f : p.beta;
+  auto flush_to_c = [&](bool first) __attribute__((always_inline)) {
+    const float beta = first ? beta0 : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t col = col0 + wave * 64 + j * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < p.M && col < p.N) {
+            gptr c = Cout + row * ldc + col;
+            float v = alpha * acc[i][j][e];
+            if (beta != 0.f) v += beta * *c;
+            *c = v;
+          }
+        }
+      }
+  };
+
+  float fa[2][2][4], fb[2][2][4];  // [half parity][tile][k pair]
+  auto frags = [&](int st, int q, int par) __attribute__((always_inline)) {
+    const float *sa = smem3 + st * G64_STG, *sb = sa + G64_TA;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) frag_half<ALAY, 64>(sa, i * 32 + r, q, h, fa[par][i]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) frag_half<BLAY, 256>(sb, wave * 64 + j * 32 + r, q, h, fb[par][j]);
+  };
+  auto mfma_half = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][i][tt], fb[par][j][tt], acc[i][j], 0, 0, 0);
+  };
+
+  // DMA sources: wave w moves block w of the A tile and blocks w, w+4, w+8, w+12 of the B tile
+  gcptr srcA = dma_src<ALAY, 64>(p.A, p.lda, 0, p.M, wave, lane) + (ALAY == LAY_K ? kbeg : kbeg * p.lda);
+  gcptr srcB[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    srcB[u] = dma_src<BLAY, 256>(p.B, p.ldb, col0, p.N, wave + 4 * u, lane) + (BLAY == LAY_K ? kbeg : kbeg * p.ldb);
+  const int64_t stepA = (ALAY == LAY_K) ? BK : (int64_t)BK * p.lda, stepB = (BLAY == LAY_K) ? BK : (int64_t)BK * p.ldb;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem3 +
+                                                       (unsigned)(wave * 256 * 4));
+  auto issue = [&](int st) __attribute__((always_inline)) {
+    const unsigned base = lds0 + (unsigned)(st * G64_STG * 4);
+    dma16(srcA, base);
+    srcA += stepA;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      dma16(srcB[u], base + (unsigned)((G64_TA + 4 * u * 256) * 4));
+      srcB[u] += stepB;
+    }
+  };
+
+  bool first_flush = true;
+  constexpr int FL = 8192 / BK;
+  for (int c0 = 0; c0 < nt; c0 += FL) {
+    const int c1 = c0 + FL < nt ? c0 + FL : nt;
+    if (c0 > 0) clear_acc();
+    __syncthreads();
+    // tiles c0 .. c0+NST-2 requested up front; tile t lives in stage (t - c0) % NST
+    int issued = c0;
+    for (; issued < c1 && issued < c0 + G64_NST - 1; ++issued) issue((issued - c0) % G64_NST);
+    // first tile landed (everything but the younger requests)
+    if (issued - c0 >= 2) {
+      // wait for tile c0 only if enough tiles are in flight to express it with a constant; else wait for all
+      if (issued - c0 == G64_NST - 1) __asm__ volatile("s_waitcnt vmcnt(25)" ::: "memory");  // (NST-2) * 5
+      else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    frags(0, 0, 0);
+    for (int t = c0; t < c1; ++t) {
+      const int st = (t - c0) % G64_NST, st1 = (t + 1 - c0) % G64_NST;
+      // own part of tile t+1 landed: at most tiles t+2 .. t+NST-2 (NST-3 of them) may still be in flight
+      if (issued - (t + 2) >= G64_NST - 3) __asm__ volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (issued < c1) {  // request tile t+NST-1 into the stage tile t-1 has left
+        issue((issued - c0) % G64_NST);
+        ++issued;
+      }
+      frags(st, 1, 1);
+      mfma_half(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < c1) {
+        __syncthreads();  // every wave's part of tile t+1 is in LDS; tile t-1's stage is free for the next request
+        frags(st1, 0, 0);
+      }
+      mfma_half(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    flush_to_c(first_flush);
+    first_flush = false;
+  }
+}
+
 // C = alpha * sum_z slab[z] + beta * C  (fixed summation order); SYRK slabs hold the lower
 // tiles only, the upper triangle is read from the transposed position.
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ slab, float *__restrict__ C,
@@ -747,12 +888,19 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
   }
 }
 
+static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out);
+
 size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int ksplit;
   int64_t kchunk;
   choose_split(M, N, K, syrk, ksplit, kchunk);
-  return ksplit > 1 ? (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) : 0;
+  size_t b = ksplit > 1 ? (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (!syrk && M <= 64 && N >= 2048 && K >= 2048) {  // the streaming kernel may be chosen instead (gemm64_launch)
+    const size_t b64 = gemm64_workspace_bytes(M, N, K / BK * BK, nullptr, nullptr);
+    if (b64 > b) b = b64;
+  }
+  return b;
 }
 
 __global__ __launch_bounds__(256) void scale_c_kernel(float *__restrict__ C, int64_t M, int64_t N, int64_t ldc, float beta) {
@@ -818,6 +966,73 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, hipStream_t
   return launch_status();
 }
 
+// 64-row streaming kernel: split-K so that ~2 workgroups per CU exist (one resident at a time: 140 KB LDS)
+static bool use_gemm64(int alay, int blay, const float *A, const float *B, int64_t M, int64_t N, int64_t K, int64_t lda,
+                       int64_t ldb) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char *e = getenv("VIVIT_GEMM64");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced == 0) return false;
+  const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
+                   (ldb & 3) == 0 && (alay == LAY_K || ((M & 3) == 0 && M >= 4)) && (blay == LAY_K || ((N & 3) == 0 && N >= 4));
+  return vec && M <= 64 && N >= 2048 && K >= 2048 && (K % BK) == 0;
+}
+
+static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out) {
+  const int64_t tiles = cdiv(N, 256), ktiles = K / BK;
+  int64_t s = cdiv(512, tiles);
+  if (s > ktiles / 32) s = ktiles / 32;
+  if (s < 1) s = 1;
+  const int64_t kchunk = cdiv(ktiles, s) * BK;
+  const int ksplit = (int)cdiv(K, kchunk);
+  if (ksplit_out) *ksplit_out = ksplit;
+  if (kchunk_out) *kchunk_out = kchunk;
+  return ksplit > 1 ? (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+static int gemm64_launch(int alay, int blay, GemmArgs p, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    const void *fns[4] = {reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_K, LAY_K>),
+                          reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_K, LAY_M>),
+                          reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_M, LAY_K>),
+                          reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_M, LAY_M>)};
+    for (const void *f : fns)
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS_BYTES) != hipSuccess)
+        return VIVIT_E_LAUNCH;
+    attr = true;
+  }
+  const size_t need = gemm64_workspace_bytes(p.M, p.N, p.K, &p.ksplit, &p.kchunk);
+  p.slab = nullptr;
+  if (p.ksplit > 1) {
+    if (!workspace || workspace_bytes < need) return VIVIT_E_WORKSPACE;
+    p.slab = static_cast<float *>(workspace);
+  }
+  p.tiles_m = 1;
+  p.tiles_n = (int)cdiv(p.N, 256);
+  p.syrk = 0;
+  p.desc = nullptr;
+  dim3 grid((unsigned)p.tiles_n, (unsigned)p.ksplit, 1);
+  if (alay == LAY_K && blay == LAY_K)
+    gemm64_dma_kernel<LAY_K, LAY_K><<<grid, 256, GEMM64_LDS_BYTES, stream>>>(p);
+  else if (alay == LAY_K && blay == LAY_M)
+    gemm64_dma_kernel<LAY_K, LAY_M><<<grid, 256, GEMM64_LDS_BYTES, stream>>>(p);
+  else if (alay == LAY_M && blay == LAY_K)
+    gemm64_dma_kernel<LAY_M, LAY_K><<<grid, 256, GEMM64_LDS_BYTES, stream>>>(p);
+  else
+    gemm64_dma_kernel<LAY_M, LAY_M><<<grid, 256, GEMM64_LDS_BYTES, stream>>>(p);
+  int st = launch_status();
+  if (st != VIVIT_OK) return st;
+  if (p.ksplit > 1) {
+    gemm_reduce_kernel<<<(unsigned)cdiv(p.M * p.N, 256), 256, 0, stream>>>(p.slab, p.C, p.M, p.N, p.ldc, p.ksplit, p.alpha,
+                                                                           p.beta, 0);
+    st = launch_status();
+  }
+  return st;
+}
+
 int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, int64_t M, int64_t N,
                 int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, float beta, bool syrk,
                 void *workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -849,6 +1064,7 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
       return gemm_launch(alay, blay, At, Bt, C, M, N, K - Kmain, lda, ldb, ldc, alpha, 1.f, syrk, workspace, workspace_bytes, stream);
     }
   }
+  if (!syrk && use_gemm64(alay, blay, A, B, M, N, K, lda, ldb)) return gemm64_launch(alay, blay, p, workspace, workspace_bytes, stream);
   choose_split(M, N, K, syrk, p.ksplit, p.kchunk);
   p.slab = nullptr;
   if (p.ksplit > 1) {

@@ -284,9 +284,9 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     st = gemm_launch(LAY_K, LAY_K, Vt, Vt, ws.S, SNB, SNB, mp, n, n, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     larft_kernel<<<1, SNB, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
-    // Pt = Vt A22 = Vt A22^T           [SNB x mp]   (A22 exactly symmetric: read it K-contiguous, the NT form,
-    // whose operand fragments are ds_read_b128 on both sides)
-    st = gemm_launch(LAY_K, getenv("VIVIT_PT_NN") ? LAY_M : LAY_K, Vt, A22, Wt, SNB, mp, mp, n, lda, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    // Pt = Vt A22                      [SNB x mp]   (A22 symmetric: B operand k-major = A22 itself; the big
+    // operand is streamed exactly once: gemm64_dma_kernel, 2.4-2.9 TB/s)
+    st = gemm_launch(LAY_K, LAY_M, Vt, A22, Wt, SNB, mp, mp, n, lda, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     // Xt = T^T Pt  (in place is not possible for a GEMM: go through the third stack block as scratch)
     float *Xt = ws.stack + (int64_t)2 * SNB * n + gi0;

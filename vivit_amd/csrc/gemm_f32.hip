@@ -404,15 +404,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   if (WM == 2 && p.syrk == 1 && !partial && ti != tj) {
     // Mirror image: C[col][row] = same value, transposed through LDS (32x33 floats per wave)
     // so that the second store is also 128-B coalesced.
+    // (each wave transposes through its own LDS patch: wave-local ordering suffices, no workgroup barrier
+    // per block; all waves left the K loop through its final barrier)
     float *ts = smem + wave * (32 * 33);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int e = 0; e < 16; ++e) ts[r * 33 + (e & 3) + 8 * (e >> 2) + 4 * h] = tot[i][j][e];
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int64_t mrow0 = col0 + wn * 64 + j * 32;  // rows of the mirrored block
         const int64_t mcol = row0 + wm * 64 + i * 32 + r;
 #pragma unroll
@@ -677,15 +679,16 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
 
   if (p.syrk == 1 && ti != tj) {
     // Mirror image through LDS (32 x 33 floats per wave), as in the small-tile kernel
+    __syncthreads();  // the last K tile has no barrier: every wave must be done reading the LDS stages
     float *ts = smem2 + wave * (32 * 33);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // own patch: wave-local ordering suffices
 #pragma unroll
         for (int e = 0; e < 16; ++e) ts[r * 33 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[i][j][e];
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int64_t mrow0 = col0 + wn * 128 + j * 32;
         const int64_t mcol = row0 + wm * 128 + i * 32 + r;
 #pragma unroll

@@ -48,6 +48,7 @@ void run(const char *name, int wgs_per_cu) {
   hipFree(out);
 }
 int main() {
+  run<0, 1>("32x32x2", 1); run<0, 1>("32x32x2", 2); run<0, 2>("32x32x2", 1); run<0, 2>("32x32x2", 2);
   run<0, 4>("32x32x2", 1); run<0, 4>("32x32x2", 2); run<0, 16>("32x32x2", 1);
   run<1, 4>("16x16x4", 1); run<1, 4>("16x16x4", 2); run<1, 16>("16x16x4", 1);
   return 0;

@@ -79,7 +79,7 @@ def test_gemm_large_tile(m, n, k):
     assert _rel(Cd, 0.5 * ref - 2.0 * C0.double()) < tol
 
 
-@pytest.mark.parametrize("n,p", [(5120, 1040), (5000, 9117)])
+@pytest.mark.parametrize("n,p", [(5120, 1040), (5000, 9117), (1280, 40000), (1024, 70016), (2000, 12345)])  # last three: split-K slabs
 def test_gram_syrk_large_tile(n, p):
     from vivit_amd import kernels
 

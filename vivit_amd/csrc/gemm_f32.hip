@@ -18,6 +18,7 @@
 // SYRK mode (the Gram build, K1): B == A, only super-blocks/tiles with tile_i >= tile_j are
 // computed (n(n+1)p flops instead of 2n^2p) and off-diagonal tiles are stored twice, the mirror
 // image transposed through LDS so that both stores are coalesced.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -500,7 +501,11 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)ti * B2, col0 = (int64_t)tj * B2;
-  const int nt = (int)(p.K / BK);  // K % 16 == 0 (host)
+  // split-K (few tiles, deep K: Gram matrices of small batches): blockIdx.y owns [kbeg, kend) and writes a slab
+  const int64_t kbeg = (int64_t)blockIdx.y * p.kchunk;
+  const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  const int nt = (int)((kend - kbeg) / BK);  // K and kchunk are multiples of 16 (host)
+  const bool partial = p.ksplit > 1;
 
 #define S2A(st) (smem2 + (st) * STG2)
 #define S2B(st) (smem2 + (st) * STG2 + T2)
@@ -513,12 +518,13 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  gptr Cout = (gptr)p.C;
-  const int64_t ldc = p.ldc;
+  gptr Cout = (gptr)(partial ? p.slab + (int64_t)blockIdx.y * p.M * p.N : p.C);
+  const int64_t ldc = partial ? p.N : p.ldc;
+  const float alpha_ = partial ? 1.f : p.alpha, beta_ = partial ? 0.f : p.beta;
   const bool full_tile = row0 + B2 <= p.M && col0 + B2 <= p.N;
   // C <- C' + alpha * acc with C' = beta * C on the first flush and C afterwards; acc <- final value
   auto flush_to_c = [&](bool first) __attribute__((always_inline)) {
-    const float beta = first ? p.beta : 1.f;
+    const float beta = first ? beta_ : 1.f;
     // the 256 output addresses are loop-invariant: without an opaque term LICM hoists them out of the
     // K loop (512 registers of addresses -> scratch spills in the hot loop)
     int opaque = 0;
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            float v = p.alpha * acc[i][j][e];
+            float v = alpha_ * acc[i][j][e];
             if (beta != 0.f) v += beta * old[e];
             cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc] = v;
             acc[i][j][e] = v;
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
-            float v = p.alpha * acc[i][j][e];
+            float v = alpha_ * acc[i][j][e];
             if (row < p.M && col < p.N) {
               gptr c = Cout + row * ldc + col;
               if (beta != 0.f) v += beta * *c;
@@ -578,8 +584,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
   gcptr srcA[4], srcB[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    srcA[u] = dma_src<ALAY>(p.A, p.lda, row0, p.M, wave + 4 * u, lane);
-    srcB[u] = dma_src<BLAY>(p.B, p.ldb, col0, p.N, wave + 4 * u, lane);
+    srcA[u] = dma_src<ALAY>(p.A, p.lda, row0, p.M, wave + 4 * u, lane) + (ALAY == LAY_K ? kbeg : kbeg * p.lda);
+    srcB[u] = dma_src<BLAY>(p.B, p.ldb, col0, p.N, wave + 4 * u, lane) + (BLAY == LAY_K ? kbeg : kbeg * p.ldb);
   }
   const int64_t stepA = (ALAY == LAY_K) ? BK : (int64_t)BK * p.lda, stepB = (BLAY == LAY_K) ? BK : (int64_t)BK * p.ldb;
   // LDS byte address of this wave's first block (wave-uniform: SGPR for M0)
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
     first_flush = false;
   }
 
-  if (p.syrk == 1 && ti != tj) {
+  if (p.syrk == 1 && ti != tj && !partial) {
     // Mirror image through LDS (32 x 33 floats per wave), as in the small-tile kernel
     __syncthreads();  // the last K tile has no barrier: every wave must be done reading the LDS stages
     float *ts = smem2 + wave * (32 * 33);
@@ -847,12 +853,12 @@ __global__ __launch_bounds__(256, 1) void gemm64_dma_kernel(GemmArgs p) {
 // tiles only, the upper triangle is read from the transposed position.
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ slab, float *__restrict__ C,
                                                           int64_t M, int64_t N, int64_t ldc, int ksplit,
-                                                          float alpha, float beta, int syrk) {
+                                                          float alpha, float beta, int syrk, int tile = BM) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * N) return;
   const int64_t i = idx / N, j = idx - i * N;
   int64_t src = idx;
-  if (syrk && (j / BN) > (i / BM)) src = j * N + i;
+  if (syrk && (j / tile) > (i / tile)) src = j * N + i;
   float s = 0.f;
   for (int z = 0; z < ksplit; ++z) s += slab[(int64_t)z * M * N + src];
   float v = alpha * s;
@@ -892,6 +898,7 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
 }
 
 static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out);
+static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit_out, int64_t *kchunk_out, int max_split = 32);
 
 size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -899,6 +906,14 @@ size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
   int64_t kchunk;
   choose_split(M, N, K, syrk, ksplit, kchunk);
   size_t b = ksplit > 1 ? (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) : 0;
+  {
+    int s256;
+    int64_t kc256;
+    if (gemm256_plan(M, N, K / BK * BK, syrk, &s256, &kc256) && s256 > 1) {
+      const size_t b256 = (size_t)s256 * (size_t)M * (size_t)N * sizeof(float);
+      if (b256 > b) b = b256;
+    }
+  }
   if (!syrk && M <= 64 && N >= 2048 && K >= 2048) {  // the streaming kernel may be chosen instead (gemm64_launch)
     const size_t b64 = gemm64_workspace_bytes(M, N, K / BK * BK, nullptr, nullptr);
     if (b64 > b) b = b64;
@@ -914,21 +929,52 @@ __global__ __launch_bounds__(256) void scale_c_kernel(float *__restrict__ C, int
 }
 
 // The 256 x 256 tile pays off once the output has enough of them to fill the chip (one per CU).
-static bool use_gemm256(int64_t M, int64_t N, int64_t K, bool syrk) {
-  static int forced = -2;
+// Split-K (slabs + fixed-order reduce) is implemented for small outputs with a deep contraction, but stays
+// opt-in (VIVIT_GEMM256_SPLIT=1): measured on the Gram matrices of small batches (n = 1280, P = 4e5) the
+// streamed K-major operand then reaches only 0.2 TB/s - 17 splits x 1280 row streams 1.6 MB apart - and the
+// 128 x 128 tile with its 2 workgroups per CU is twice as fast (27 ms vs 59 ms); to be revisited with the
+// seven-stage pipeline of gemm64_dma_kernel.
+static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit_out, int64_t *kchunk_out, int max_split) {
+  static int forced = -2, split = 0;
   if (forced == -2) {
     const char *e = getenv("VIVIT_GEMM256");
     forced = e ? atoi(e) : -1;
+    const char *e2 = getenv("VIVIT_GEMM256_SPLIT");
+    split = e2 ? atoi(e2) : 0;
   }
-  if (forced == 0) return false;
+  if (ksplit_out) *ksplit_out = 1;
+  if (kchunk_out) *kchunk_out = cdiv(K, BK) * BK;
+  if (forced == 0 || K < 1024) return false;
   const int64_t tm = cdiv(M, B2), tn = cdiv(N, B2);
   const int64_t tiles = syrk ? tm * (tm + 1) / 2 : tm * tn;
   // one workgroup per CU: prologue (first DMA round trip) and epilogue (256 KB of C) are not overlapped with
   // another workgroup's main loop, so the contraction must be long enough to amortise them
-  return tiles >= 200 && K >= 1024;
+  if (!split) return tiles >= 200;
+  if (M < 512 || N < 512) return false;
+  const int64_t ktiles = K / BK;
+  const double flops = (syrk ? 1.0 : 2.0) * (double)M * (double)N * (double)K;
+  const double t_mfma = flops / 140e12;
+  double best = 0.0;
+  int best_s = 0;
+  for (int s = 1; s <= max_split; ++s) {
+    if (s > 1 && ktiles / s < 128) break;  // every split keeps >= 2048 k
+    if ((size_t)s * (size_t)M * (size_t)N * 4 > ((size_t)1 << 30)) break;
+    const int64_t wgs = tiles * s;
+    const double fill = (double)wgs / (double)(256 * cdiv(wgs, 256));
+    const double t_slab = s > 1 ? 2.0 * s * (double)M * (double)N * 4.0 / 3e12 : 0.0;
+    const double eff = fill / (1.0 + t_slab / t_mfma);
+    if (eff > best + 1e-9) { best = eff; best_s = s; }
+  }
+  if (best_s == 0 || best < 0.6) return false;
+  if (ksplit_out && best_s > 1) {
+    const int64_t kchunk = cdiv(ktiles, best_s) * BK;
+    *kchunk_out = kchunk;
+    *ksplit_out = (int)cdiv(K, kchunk);
+  }
+  return true;
 }
 
-static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, hipStream_t stream) {
+static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
     const void *fns[4] = {reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_K>),
@@ -940,9 +986,15 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, hipStream_t
         return VIVIT_E_LAUNCH;
     attr = true;
   }
-  p.ksplit = 1;
-  p.kchunk = cdiv(p.K, BK) * BK;
-  p.slab = nullptr;
+  // never more splits than the caller's workspace holds (callers size it for their largest problem; the plan
+  // of a smaller one may differ)
+  const size_t slab1 = (size_t)p.M * (size_t)p.N * sizeof(float);
+  const int max_split = workspace ? (int)(workspace_bytes / slab1 < 32 ? workspace_bytes / slab1 : 32) : 1;
+  gemm256_plan(p.M, p.N, p.K, syrk, &p.ksplit, &p.kchunk, max_split < 1 ? 1 : max_split);
+  p.slab = p.ksplit > 1 ? static_cast<float *>(workspace) : nullptr;
+  if (getenv("VIVIT_GEMM_DEBUG"))
+    fprintf(stderr, "gemm256: M=%lld N=%lld K=%lld syrk=%d ksplit=%d kchunk=%lld max_split=%d\n", (long long)p.M, (long long)p.N,
+            (long long)p.K, (int)syrk, p.ksplit, (long long)p.kchunk, max_split);
   p.tiles_m = (int)cdiv(p.M, B2);
   p.tiles_n = (int)cdiv(p.N, B2);
   p.syrk = syrk ? 1 : 0;
@@ -954,7 +1006,7 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, hipStream_t
   const int64_t sbm = cdiv(p.tiles_m, sbh), sbn = cdiv(p.tiles_n, sbw);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
   if (nsb * 256 > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
-  dim3 grid((unsigned)(nsb * 256), 1, 1);
+  dim3 grid((unsigned)(nsb * 256), (unsigned)p.ksplit, 1);
   const bool prof = syrk && p.A == p.B && prof_enabled();
   if (prof) prof_begin(0, (double)p.M * (double)(p.M + 1) * (double)p.K, stream);
   if (alay == LAY_K && blay == LAY_K)
@@ -965,8 +1017,14 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, hipStream_t
     gemm256_kernel<LAY_M, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(p);
   else
     gemm256_kernel<LAY_M, LAY_M><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(p);
+  int st = launch_status();
+  if (st == VIVIT_OK && p.ksplit > 1) {
+    gemm_reduce_kernel<<<(unsigned)cdiv(p.M * p.N, 256), 256, 0, stream>>>(p.slab, p.C, p.M, p.N, p.ldc, p.ksplit, p.alpha,
+                                                                           p.beta, p.syrk, B2);
+    st = launch_status();
+  }
   if (prof) prof_end(0, stream);
-  return launch_status();
+  return st;
 }
 
 // 64-row streaming kernel: split-K so that ~2 workgroups per CU exist (one resident at a time: 140 KB LDS)
@@ -1058,9 +1116,9 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
     const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
                      (ldb & 3) == 0 && (alay == LAY_K || (M & 3) == 0) && (blay == LAY_K || (N & 3) == 0);
     const int64_t Kmain = K / BK * BK;
-    if (vec && use_gemm256(M, N, Kmain, syrk)) {
+    if (vec && gemm256_plan(M, N, Kmain, syrk, nullptr, nullptr)) {
       p.K = Kmain;
-      int st = gemm256_launch(alay, blay, p, syrk, stream);
+      int st = gemm256_launch(alay, blay, p, syrk, workspace, workspace_bytes, stream);
       if (st != VIVIT_OK || Kmain == K) return st;
       // ragged K tail (< 16) through the small-tile kernel, accumulating
       const float *At = A + (alay == LAY_K ? Kmain : Kmain * lda), *Bt = B + (blay == LAY_K ? Kmain : Kmain * ldb);

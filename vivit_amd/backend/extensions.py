@@ -213,6 +213,10 @@ def _materialised_closures(V_t: Tensor):
         "V_mat_prod": lambda mat: Vmp(V_t, mat, 2),
         "V_t_mat_prod": lambda mat: mVp(V_t, mat, 2),
         "gram_mat": gram_mat,
+        # explicit factor [C, N, *param] and its leading shape: used when the parameter side of a group is the
+        # smaller one (vivit_amd.linalg.utils.parameter_side_symeig)
+        "factor": lambda: V_t,
+        "shape_cn": tuple(V_t.shape[:2]),
     }
 
 
@@ -243,7 +247,11 @@ def _linear_weight_closures(s: Tensor, z: Tensor):
         U = kernels.gemm_nt(mat.reshape(Fdim * O, -1), z).view(Fdim, O, N)
         return torch.einsum("cno,von->vcn", s, U)
 
-    return {"V_mat_prod": V_mat_prod, "V_t_mat_prod": V_t_mat_prod, "gram_mat": gram_mat}
+    def factor():  # the explicit V_t[c,n,o,i] = s[c,n,o] z[n,i]; only asked for when O*I is small
+        return torch.einsum("cno,ni->cnoi", s, z)
+
+    return {"V_mat_prod": V_mat_prod, "V_t_mat_prod": V_t_mat_prod, "gram_mat": gram_mat, "factor": factor,
+            "shape_cn": (C, N)}
 
 
 class _ViViTGGN(_SqrtGGN):

@@ -6,7 +6,14 @@ from torch import Tensor
 from torch.nn import Module, Parameter
 
 from vivit_amd import kernels
-from vivit_amd.linalg.utils import get_closures, get_hook_store_batch_size, get_vivit_extension, normalize
+from vivit_amd.linalg.utils import (
+    get_closures,
+    get_hook_store_batch_size,
+    get_vivit_extension,
+    normalize,
+    parameter_side_symeig,
+    use_parameter_side,
+)
 from vivit_amd.utils import delete_savefield
 from vivit_amd.utils.checks import check_key_exists, check_subsampling_unique, check_unique_params
 from vivit_amd.utils.gram import reshape_as_square
@@ -27,8 +34,13 @@ class EighComputation:
         mc_samples: int = 0,
         verbose: bool = False,
         warn_small_eigvals: float = 1e-4,
+        side: str = "auto",
     ):
+        """``side`` (not in the reference): ``"auto"`` solves a group on its parameter side (``P x P``, eigenvectors
+        directly in parameter space) when it has fewer parameters than Gram rows; ``"gram"`` = reference path."""
         check_subsampling_unique(subsampling)
+        use_parameter_side([], 1, side)  # validates ``side``
+        self._side = side
         self._subsampling = subsampling
         self._mc_samples = mc_samples
         self._verbose = verbose
@@ -83,13 +95,47 @@ class EighComputation:
     def get_group_hook(self) -> Callable[[ParameterGroupsHook, None, Dict[str, Any]], None]:
         batch_sizes, subsampling, savefield = self._batch_size, self._subsampling, self._savefield
         evals, evecs, verbose = self._evals, self._evecs, self._verbose
-        warn_small_eigvals = self._warn_small_eigvals
+        warn_small_eigvals, side = self._warn_small_eigvals, self._side
+        small_warning = (
+            "Some eigenvectors have small eigenvalues."
+            + " Their parameter space transformation is numerically unstable."
+            + " This can spoil orthogonality of eigenvectors."
+            + " Maybe use a more restrictive eigenvalue filter criterion."
+        )
 
         def group_hook(self: ParameterGroupsHook, accumulation: None, group: Dict[str, Any]) -> None:
             group_id = id(group)
             if verbose:
                 print(f"Group {group_id}: Delete 'batch_size'")
             batch_size = batch_sizes.pop(group_id)
+
+            C, N = get_closures(group["params"][0], savefield)["shape_cn"]
+            if use_parameter_side(group["params"], C * N, side):
+                # P x P block of the GGN: its eigenvectors are the parameter-space eigenvectors themselves
+                import torch
+
+                all_evals, Q, n_zero = parameter_side_symeig(group["params"], savefield, eigenvectors=True)
+                if subsampling is not None:
+                    all_evals *= batch_size / len(subsampling)
+                keep = group["criterion"](all_evals)
+                keep_t = torch.as_tensor(keep, dtype=torch.long, device=all_evals.device)
+                kept_evals = all_evals[keep_t]
+                if (kept_evals.abs() < warn_small_eigvals).any():
+                    warn(small_warning)
+                # indices below n_zero address the Gram matrix' exact zeros: no GGN eigenvector belongs to them
+                vecs = torch.zeros((len(keep), Q.shape[0]), dtype=Q.dtype, device=Q.device)
+                valid = keep_t >= n_zero
+                if bool(valid.any()):
+                    vecs[valid] = Q[:, keep_t[valid] - n_zero].T
+                group_evecs, off = [], 0
+                for param in group["params"]:
+                    numel = param.numel()
+                    group_evecs.append(vecs[:, off : off + numel].reshape(len(keep), *param.shape).contiguous())
+                    off += numel
+                    delete_savefield(param, savefield, verbose=verbose)
+                evals[group_id] = kept_evals
+                evecs[group_id] = group_evecs
+                return
 
             # Gram matrix, accumulated over the group's parameters inside the kernel (eigh.py:239-242)
             gram_mat = None
@@ -106,12 +152,7 @@ class EighComputation:
             gram_evals, gram_evecs = gram_evals[keep], gram_evecs[:, keep]
 
             if (gram_evals.abs() < warn_small_eigvals).any():
-                warn(
-                    "Some eigenvectors have small eigenvalues."
-                    + " Their parameter space transformation is numerically unstable."
-                    + " This can spoil orthogonality of eigenvectors."
-                    + " Maybe use a more restrictive eigenvalue filter criterion."
-                )
+                warn(small_warning)
 
             # eigenvectors selectable via the first axis: [K, C, N] (eigh.py:265)
             gram_evecs = gram_evecs.transpose(0, 1).reshape(-1, C, N)

@@ -5,7 +5,13 @@ from torch import Tensor
 from torch.nn import Module, Parameter
 
 from vivit_amd import kernels
-from vivit_amd.linalg.utils import get_closures, get_hook_store_batch_size, get_vivit_extension
+from vivit_amd.linalg.utils import (
+    get_closures,
+    get_hook_store_batch_size,
+    get_vivit_extension,
+    parameter_side_symeig,
+    use_parameter_side,
+)
 from vivit_amd.utils import delete_savefield
 from vivit_amd.utils.checks import check_key_exists, check_subsampling_unique, check_unique_params
 from vivit_amd.utils.gram import reshape_as_square
@@ -21,8 +27,12 @@ class EigvalshComputation:
     in place into the group's ``[n, n]`` Gram (beta = 1), then one values-only ``symeig``.
     """
 
-    def __init__(self, subsampling: List[int] = None, mc_samples: int = 0, verbose: bool = False):
+    def __init__(self, subsampling: List[int] = None, mc_samples: int = 0, verbose: bool = False, side: str = "auto"):
+        """``side`` (not in the reference): ``"auto"`` solves a group on its parameter side (``P x P``) when it has
+        fewer parameters than Gram rows, ``"gram"`` always decomposes the Gram matrix like the reference."""
         check_subsampling_unique(subsampling)
+        use_parameter_side([], 1, side)  # validates ``side``
+        self._side = side
         self._subsampling = subsampling
         self._mc_samples = mc_samples
         self._verbose = verbose
@@ -63,11 +73,19 @@ class EigvalshComputation:
         return extension_hook
 
     def get_param_computation(self) -> Callable[[ParameterGroupsHook, Parameter], Tensor]:
-        verbose, savefield = self._verbose, self._savefield
+        verbose, savefield, side = self._verbose, self._savefield, self._side
 
-        def param_computation(self: ParameterGroupsHook, param: Parameter) -> Tensor:
-            """Gram of this parameter, added in-kernel to the group accumulator if there is one."""
-            gram_fn = get_closures(param, savefield)["gram_mat"]
+        def param_computation(self: ParameterGroupsHook, param: Parameter):
+            """Gram of this parameter, added in-kernel to the group accumulator if there is one.
+
+            Groups solved on the parameter side keep their factors alive instead (a list of parameters is
+            accumulated) until the group hook forms the ``P x P`` block."""
+            closures = get_closures(param, savefield)
+            group = self.get_group(self._param_to_group[id(param)])
+            C, N = closures["shape_cn"]
+            if use_parameter_side(group["params"], C * N, side):
+                return [param]
+            gram_fn = closures["gram_mat"]
             existing = self.current_accumulation(param)
             if existing is None:
                 gram = gram_fn()
@@ -80,7 +98,9 @@ class EigvalshComputation:
         return param_computation
 
     def get_accumulate(self) -> Callable[[ParameterGroupsHook, Tensor, Tensor], Tensor]:
-        def accumulate(self: ParameterGroupsHook, existing: Tensor, update: Tensor) -> Tensor:
+        def accumulate(self: ParameterGroupsHook, existing, update):
+            if isinstance(existing, list):  # parameter-side group: collect the parameters
+                return existing + update
             # ``update`` already is ``existing`` (+= done by the kernel's beta = 1) on the fused path
             return update if update is existing else existing.add_(update)
 
@@ -88,15 +108,20 @@ class EigvalshComputation:
 
     def get_group_hook(self) -> Callable[[ParameterGroupsHook, Tensor, Dict[str, Any]], None]:
         batch_sizes, subsampling = self._batch_size, self._subsampling
-        evals, verbose = self._evals, self._verbose
+        evals, verbose, savefield = self._evals, self._verbose, self._savefield
 
         def group_hook(self: ParameterGroupsHook, accumulation: Tensor, group: Dict):
             group_id = id(group)
             if verbose:
                 print(f"Group {group_id}: Delete 'batch_size'")
             batch_size = batch_sizes.pop(group_id)
-            gram_mat = reshape_as_square(accumulation)
-            gram_evals, _ = kernels.symeig(gram_mat, eigenvectors=False, overwrite=True)
+            if isinstance(accumulation, list):  # parameter side: P x P block of the GGN, zero-padded spectrum
+                gram_evals, _, _ = parameter_side_symeig(group["params"], savefield, eigenvectors=False)
+                for param in accumulation:
+                    delete_savefield(param, savefield, verbose=verbose)
+            else:
+                gram_mat = reshape_as_square(accumulation)
+                gram_evals, _ = kernels.symeig(gram_mat, eigenvectors=False, overwrite=True)
             # scale fix for curvature sub-sampling (eigvalsh.py:217-219); eigenvalues are
             # homogeneous of degree one, so the O(n) vector is scaled instead of the n x n Gram
             if subsampling is not None:

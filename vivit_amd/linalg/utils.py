@@ -46,6 +46,48 @@ def get_closures(param, savefield: str) -> Dict[str, Callable]:
     return _materialised_closures(value)
 
 
+def use_parameter_side(params, n: int, side: str) -> bool:
+    """``True`` if the group's eigenproblem should be solved on the parameter side.
+
+    The GGN block ``V^T V`` (``P x P``) and the Gram matrix ``V V^T`` (``n x n``) share their non-zero
+    spectrum; the reference always decomposes the Gram matrix (vivit/linalg/eigvalsh.py:215-225).  When a
+    group has fewer parameters than Gram rows (LeNet's conv1: P = 456 against n = N*C = 20 480) the
+    ``P x P`` problem is the cheap one and its eigenvectors already live in parameter space.
+    ``side``: ``"auto"`` (smaller side), ``"gram"`` (reference behaviour), ``"param"``.
+    """
+    if side not in ("auto", "gram", "param"):
+        raise ValueError(f"side must be 'auto', 'gram' or 'param', got {side!r}")
+    if side != "auto":
+        return side == "param"
+    return sum(int(p.numel()) for p in params) < n
+
+
+def parameter_side_symeig(params, savefield: str, eigenvectors: bool):
+    """Eigen-decomposition of the group's ``P x P`` GGN block ``H = V^T V``, padded to the Gram spectrum.
+
+    Returns ``(evals [n] ascending, Q [P, P] or None, n - P_eff)``: the first ``n - P`` entries of ``evals``
+    are the exact zeros the (rank-deficient) Gram matrix has in their place; ``Q[:, i]`` is the unit
+    parameter-space eigenvector of ``evals[n - P + i]`` (concatenated over ``params`` in order).
+    If ``P >= n`` the top ``n`` eigenvalues are returned (the remaining ``P - n`` are zero up to rounding).
+    """
+    import torch
+
+    facs = []
+    for prm in params:
+        c = get_closures(prm, savefield)
+        C, N = c["shape_cn"]
+        facs.append(c["factor"]().reshape(C * N, -1))
+    n = facs[0].shape[0]
+    Vcat = facs[0] if len(facs) == 1 else torch.cat(facs, dim=1)  # [n, P]
+    P = Vcat.shape[1]
+    H = kernels.gemm_tn(Vcat, Vcat)                                 # [P, P] = V^T V, contraction over the n rows
+    w, Q = kernels.symeig(H, eigenvectors=eigenvectors, overwrite=True)
+    if P >= n:
+        return w[P - n:], (Q[:, P - n:] if eigenvectors else None), 0
+    evals = torch.cat([torch.zeros(n - P, dtype=w.dtype, device=w.device), w])
+    return evals, Q, n - P
+
+
 def get_hook_store_batch_size(
     param_groups: List[Dict], destination: Dict[int, int], verbose: bool = False
 ) -> Callable[[Module], None]:

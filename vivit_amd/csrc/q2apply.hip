@@ -324,7 +324,7 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     q2_prepare_kernel<<<2 * nblk, 256, 0, stream>>>(a, Tbuf);
     // a workgroup walks over several slabs (V, T stay in LDS); ~2000 workgroups keep the tail short
     int64_t gx = cdiv(2048, nblk);
-    if (gx > nslab) gx = nslab;
+    if (gx > cdiv(nslab, 4)) gx = cdiv(nslab, 4);  // at least ~4 slabs per V/T load (matters in row-range mode)
     if (vec)
       q2_apply_kernel<true><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, Tbuf, Zt, ldz, (int)nrows);
     else

@@ -6,7 +6,7 @@ L.LIB_PATH = os.path.abspath(sys.argv[1])
 import torch
 from vivit_amd import kernels
 dev = torch.device("cuda:0")
-m = n = k = 8192
+m = n = k = 16384
 A = torch.randn(m, k, device=dev); B = torch.randn(n, k, device=dev)
 kernels.gemm_nt(A, B); torch.cuda.synchronize()
 t0 = time.perf_counter()

@@ -964,7 +964,8 @@ static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit
   const int64_t tiles = syrk ? tm * (tm + 1) / 2 : tm * tn;
   // one workgroup per CU: prologue (first DMA round trip) and epilogue (256 KB of C) are not overlapped with
   // another workgroup's main loop, so the contraction must be long enough to amortise them
-  if (!split) return tiles >= 200;
+  if (!split && tiles < 200) return false;
+  if (!split) max_split = max_split < 4 ? max_split : 4;  // large outputs: only to fill the last round of workgroups
   if (M < 512 || N < 512) return false;
   const int64_t ktiles = K / BK;
   const double flops = (syrk ? 1.0 : 2.0) * (double)M * (double)N * (double)K;
@@ -1058,9 +1059,17 @@ static bool use_gemm64(int alay, int blay, const float *A, const float *B, int64
 
 static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out) {
   const int64_t tiles = cdiv(N, 256), ktiles = K / BK;
-  int64_t s = cdiv(512, tiles);
-  if (s > ktiles / 32) s = ktiles / 32;
-  if (s < 1) s = 1;
+  // one workgroup per CU: pick the split count (>= 2 rounds of work, every split >= 64 K tiles) whose last
+  // round of 256 workgroups is fullest
+  int64_t s = 1;
+  double best = 0.0;
+  for (int64_t c = 1; c <= 24; ++c) {
+    if (c > 1 && ktiles / c < 64) break;
+    const int64_t wgs = tiles * c;
+    const double fill = (double)wgs / (double)(256 * cdiv(wgs, 256));
+    const double score = wgs >= 512 ? fill : fill * 0.5 * (double)wgs / 512.0;  // too few workgroups: latency-bound
+    if (score > best + 1e-9) { best = score; s = c; }
+  }
   const int64_t kchunk = cdiv(ktiles, s) * BK;
   const int ksplit = (int)cdiv(K, kchunk);
   if (ksplit_out) *ksplit_out = ksplit;

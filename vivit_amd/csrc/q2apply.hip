@@ -323,8 +323,21 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     const unsigned nblk = (unsigned)(G_hi - G_lo + 1);
     q2_prepare_kernel<<<2 * nblk, 256, 0, stream>>>(a, Tbuf);
     // a workgroup walks over several slabs (V, T stay in LDS); ~2000 workgroups keep the tail short
-    int64_t gx = cdiv(2048, nblk);
-    if (gx > cdiv(nslab, 4)) gx = cdiv(nslab, 4);  // at least ~4 slabs per V/T load (matters in row-range mode)
+    // workgroups = gx * nblk, one per CU at a time: pick the row split whose last round of 256 workgroups is
+    // fullest and whose slabs divide evenly, with at least ~4 slabs per V/T load (matters in row-range mode)
+    int64_t gx = 1;
+    {
+      const int64_t hi = cdiv(nslab, 4) < cdiv(4096, nblk) ? cdiv(nslab, 4) : cdiv(4096, nblk);
+      double best = -1.0;
+      for (int64_t c = 1; c <= (hi < 1 ? 1 : hi); ++c) {
+        const int64_t wgs = c * nblk;
+        const double fill = (double)wgs / (double)(256 * cdiv(wgs, 256));
+        const double even = ((double)nslab / (double)c) / (double)cdiv(nslab, c);
+        const double enough = wgs >= 512 ? 1.0 : (double)wgs / 512.0;
+        const double score = fill * even * enough;
+        if (score > best + 1e-9) { best = score; gx = c; }
+      }
+    }
     if (vec)
       q2_apply_kernel<true><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, Tbuf, Zt, ldz, (int)nrows);
     else

@@ -161,20 +161,35 @@ __device__ __forceinline__ bool map_tile(int syrk, int SBW, int tiles_m, int til
     J = sb - I * sbn;
   }
   const int xcd = slot & 7, w = slot >> 3;
+  // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), so every super-block must hand each XCD
+  // the same number of tiles or the busiest XCD sets the kernel time.  Full rectangular super-blocks do
+  // (32 tiles per XCD in a compact sub-block).  The others - the lower triangles on the diagonal of a SYRK
+  // and the partial super-blocks at the bottom/right edge - are dealt out evenly instead: XCD x takes the
+  // c = ceil(v / 8) consecutive valid tiles [c x, c x + c) in row-major order.  (Config-2 Gram matrix before
+  // this: 26/10/0/0/32/32/26/10 tiles of every diagonal super-block per XCD, busiest XCD 1760 tiles against
+  // a mean of 1610, kernel 9 % over its MFMA time.)
+  const int vr = tiles_m - I * SBH < SBH ? tiles_m - I * SBH : SBH;  // valid rows / columns of this super-block
+  const int vc = tiles_n - J * SBW < SBW ? tiles_n - J * SBW : SBW;
   if (syrk && I == J) {
-    // Diagonal super-block: only the 136 tiles of its lower triangle exist.  With the rectangular sub-blocks
-    // the XCDs would own 26/10/0/0/32/32/26/10 of them - workgroups are dealt round-robin to the XCDs, so over
-    // the 10 diagonal super-blocks of the config-2 Gram matrix the busiest XCD gets 1760 tiles against a mean
-    // of 1610 and the kernel runs 9 % longer than its MFMA time.  Deal the triangle out evenly instead: XCD x
-    // takes the 17 consecutive tiles [17x, 17x + 17) of the row-major lower triangle.
-    if (w >= 17) return false;
-    const int idx = 17 * xcd + w;
+    const int d = vr < vc ? vr : vc;  // triangle edge
+    const int v = d * (d + 1) / 2, c = (v + 7) >> 3;
+    const int idx = c * xcd + w;
+    if (w >= c || idx >= v) return false;
     int a = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
     while ((a + 1) * (a + 2) / 2 <= idx) ++a;
     while (a * (a + 1) / 2 > idx) --a;
     ti = I * SBH + a;
     tj = J * SBW + (idx - a * (a + 1) / 2);
-    return ti < tiles_m && tj < tiles_n;
+    return true;
+  }
+  if (vr < SBH || vc < SBW) {
+    if (vr <= 0 || vc <= 0) return false;
+    const int v = vr * vc, c = (v + 7) >> 3;
+    const int idx = c * xcd + w;
+    if (w >= c || idx >= v) return false;
+    ti = I * SBH + idx / vc;
+    tj = J * SBW + idx % vc;
+    return true;
   }
   int xw = SBW < 4 ? SBW : 4, xh = 32 / xw;          // XCD sub-block: xh x xw tiles
   if (xh > SBH) { xh = SBH; xw = 32 / xh; }

@@ -989,7 +989,7 @@ static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit
   int best_s = 0;
   for (int s = 1; s <= max_split; ++s) {
     if (s > 1 && ktiles / s < 128) break;  // every split keeps >= 2048 k
-    if ((size_t)s * (size_t)M * (size_t)N * 4 > ((size_t)1 << 30)) break;
+    if (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ((size_t)1 << 30)) break;  // slab cap (no slab for s = 1)
     const int64_t wgs = tiles * s;
     const double fill = (double)wgs / (double)(256 * cdiv(wgs, 256));
     const double t_slab = s > 1 ? 2.0 * s * (double)M * (double)N * 4.0 / 3e12 : 0.0;

@@ -918,7 +918,13 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
     int64_t want = (tm == 1 || tn == 1) ? skinny_want / tiles : 512 / tiles;
     int64_t maxs = (tm == 1 || tn == 1) ? ktiles / 8 : ktiles / 32;
     int64_t s = want < maxs ? want : maxs;
-    if (s > 64) s = 64;
+    // a single-tile output (the 64 x 64 Gram blocks of the band reduction's panels: both operands stream 64 rows
+    // x m) is cheapest with few, long splits (measured over a whole band reduction at n = 40 960: cap 8 / 16 / 32 /
+    // 64 / 256 -> 2.27 / 2.00 / 2.03 / 2.07 / 2.17 s): the slab reduce and the per-workgroup prologue dominate
+    static int cap1 = -1;
+    if (cap1 < 0) { const char *e = getenv("VIVIT_SPLIT_CAP1"); cap1 = e ? atoi(e) : 16; }
+    const int64_t cap = tiles <= 2 ? cap1 : 64;
+    if (s > cap) s = cap;
     while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ((size_t)1 << 30)) --s;
     if (s > 1) {
       kchunk = cdiv(ktiles, s) * BK;

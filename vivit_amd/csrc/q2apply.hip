@@ -5,12 +5,12 @@
 // Reflectors are grouped into blocks (g, k): the QW = 64 consecutive sweeps s in [g*QW, (g+1)*QW)
 // at chase level k.  Their vectors are NB = 64 long and shifted by one position per sweep, so a
 // block touches a 128-column window of Zt and is applied in compact-WY form
-//   S <- S - ((S V^T) T^T) V          S: 128 rows x 128 window columns of Zt,  V: 64 x 128
-// by one 256-thread workgroup per 128-row slab of Zt: three MFMA products with S, V, T and the
-// intermediate W all resident in LDS (154 KB; one workgroup per CU).
+//   S <- S - ((S V^T) T^T) V          S: rows x 128 window columns of Zt,  V: 64 x 128
+// with the slab S held in registers through two chained MFMA products (see q2_apply_kernel).
 // Blocks only conflict with their neighbours in (g, k); with G the group index counted from the
-// last group, all blocks with equal tau = G + k are independent (validated in scripts/sb2st_proto.py),
-// so the host issues one prepare (T factors) + one apply launch per wavefront step.
+// last group, all blocks with equal tau = G + k are independent (validated in scripts/sb2st_proto.py);
+// two consecutive levels are paired into a super-block, and the host issues one prepare (T V per block)
+// + one apply launch per wavefront step of super-blocks.
 #include <type_traits>
 
 #include "common.h"
@@ -22,7 +22,6 @@ namespace vivit {
 constexpr int QB = 64;            // reflector length (= half bandwidth NB)
 constexpr int QW = 64;            // sweeps per block
 constexpr int QWIN = QB + QW;     // window width (128)
-constexpr int LDS_W = QW + 4;     // 68
 
 struct Q2Step {
   const float *R2;
@@ -49,8 +48,8 @@ __device__ __forceinline__ float q2_v(const Q2Step &a, int g0, int c_start, int 
   return a.R2[(int64_t)s * a.ldr + c_start + i];
 }
 
-// ---- T factor of every block of the step ------------------------------------------------------
-__global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__restrict__ Tbuf) {
+// ---- T V (T = compact-WY factor) of every block of the step ------------------------------------
+__global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__restrict__ TVbuf) {
   __shared__ float V[QW][QWIN + 1];
   __shared__ float S[QW][QW + 1];
   __shared__ float Ts[QW][QW + 1];
@@ -86,8 +85,15 @@ __global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__rest
   // T factor, one thread per column (device_utils.h:tfactor_column)
   if (tid < QW) tfactor_column(&S[0][0], taus, &Ts[0][0], QW + 1, QW, tid);
   __syncthreads();
-  float *T = Tbuf + (int64_t)blockIdx.x * QW * QW;
-  for (int idx = tid; idx < QW * QW; idx += 256) T[idx] = Ts[idx / QW][idx % QW];
+  // TV = T V (T upper triangular): the apply kernel multiplies the slab by it directly,
+  //   (S V^T) T^T = S (T V)^T,  one MFMA product instead of two
+  float *TV = TVbuf + (int64_t)blockIdx.x * QW * QWIN;
+  for (int idx = tid; idx < QW * QWIN; idx += 256) {
+    const int tp = idx / QWIN, i = idx - tp * QWIN;
+    float acc = 0.f;
+    for (int t = tp; t < QW; ++t) acc += Ts[tp][t] * V[t][i];
+    TV[idx] = acc;
+  }
 }
 
 // ---- apply:  S <- S - ((S V^T) T^T) V  for the two blocks (g, 2K), (g, 2K+1) of a super-block ----
@@ -98,12 +104,13 @@ __global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__rest
 // MFMA the accumulator of  X^T = A * B  (lane (r, h) holds X[row r][4h + (e&3) + 8(e>>2)]) is, with
 // the k index permuted accordingly, exactly the B operand of the next product.  A wave owns 32 rows
 // of Zt (lane (r, h) keeps S[row r][8q + 4h .. +3], q = 0..23, as loaded by float4) and runs
-//     W1^T = V S^T,   W2^T = T W1^T,   U^T = V^T W2^T,   S -= U
-// per block with V and T read from LDS as A operands.  Structurally zero 32x32 tiles of V
-// (parallelogram) and T (upper triangular) are skipped: 240 instead of 320 MFMAs per block and wave.
+//     W2^T = (T V) S^T,   U^T = V^T W2^T,   S -= U
+// per block with V and T V (prepared per block by q2_prepare_kernel: (S V^T) T^T = S (T V)^T saves the
+// product with T) read from LDS as A operands.  Structurally zero 32x32 tiles of V (parallelogram) and
+// T V (trapezoid) are skipped: 208 MFMAs per block and wave (320 for the dense three-product form).
 // Pairing two levels reads/writes 192 instead of 2 x 128 columns of Zt per row (the kernel is close
 // to HBM-bound) and halves the number of launches.  A 512-thread workgroup (8 waves, 2 per SIMD)
-// keeps both blocks' V/T in LDS (102 KB) and walks over several 256-row slabs.
+// keeps both blocks' V and T V in LDS (135 KB) and walks over several 256-row slabs.
 constexpr int LDS_V = QWIN + 4;    // 132: conflict-free ds_read_b128 fragments
 constexpr int Q2_THREADS = 512;
 constexpr int Q2_SLAB = 32 * (Q2_THREADS / 64);  // 256 rows per workgroup iteration
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const fl
                                                               float *__restrict__ Zt, int64_t ldz, int nrows) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *sV = lds;                      // [2][64][LDS_V]   V[t][w]
-  float *sT = sV + 2 * QW * LDS_V;      // [2][64][LDS_W]   T[t'][t]
+  float *sTV = sV + 2 * QW * LDS_V;     // [2][64][LDS_V]   (T V)[t'][w]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   int g0, K;
@@ -128,8 +135,11 @@ __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const fl
     const int t = rem / QWIN, w = rem - t * QWIN;
     sV[(b * QW + t) * LDS_V + w] = (w >= 1) ? q2_v(a, g0, g0 + 1 + (2 * K + b) * QB, t, w - 1) : 0.f;
   }
-  const float *T = Tbuf + (int64_t)blockIdx.y * 2 * QW * QW;
-  for (int idx = tid; idx < 2 * QW * QW; idx += Q2_THREADS) sT[(idx / QW) * LDS_W + (idx % QW)] = T[idx];
+  const float *TV = Tbuf + (int64_t)blockIdx.y * 2 * QW * QWIN;  // [2][64][128], window index i = w - 1
+  for (int idx = tid; idx < 2 * QW * QWIN; idx += Q2_THREADS) {
+    const int bt = idx / QWIN, w = idx - bt * QWIN;  // bt = 64 b + t'
+    sTV[bt * LDS_V + w] = (w >= 1) ? TV[bt * QWIN + w - 1] : 0.f;
+  }
   __syncthreads();
 
   const int64_t colg = (int64_t)wstart + 4 * h;  // + 8 q
@@ -167,54 +177,33 @@ __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const fl
       }
     }
 
-    auto apply = [&](auto q0tag, const float *__restrict__ bV, const float *__restrict__ bT) {
+    auto apply = [&](auto q0tag, const float *__restrict__ bV, const float *__restrict__ bTV) {
       constexpr int Q0 = decltype(q0tag)::value;
       // LDS fragment reads are software-pipelined one MFMA group (4 x 64 cycles) ahead by hand.
-      // ---- W1^T = V S^T : tile jt covers w-tiles jt .. jt+2 (q = 4 jt .. 4 jt + 11)
-      f32x16 acc1[2];
-      const float *pV = bV + r * LDS_V + 4 * h;
+      // ---- W2^T = (T V) S^T.  (T V)[t'][w] is non-zero for w in [t' + 1, 127]: t'-tile 0 needs all four
+      // w-tiles (q = 0 .. 15), t'-tile 1 the last three (q = 4 .. 15)
+      f32x16 acc2[2];
+      const float *pV = bTV + r * LDS_V + 4 * h;
       float4 av = *reinterpret_cast<const float4 *>(pV);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // prologue fragment
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt) {
+      for (int jo = 0; jo < 2; ++jo) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[jt][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc2[jo][e] = 0.f;
 #pragma unroll
-        for (int q = 4 * jt; q < 4 * jt + 12; ++q) {
-          // next fragment: (jt, q + 1), or the first one of tile jt = 1
-          const int nj = (q + 1 < 4 * jt + 12) ? jt : jt + 1, nq = (q + 1 < 4 * jt + 12) ? q + 1 : 4;
+        for (int q = 4 * jo; q < 16; ++q) {
+          // next fragment: (jo, q + 1), or the first one of tile jo = 1
+          const int nj = (q + 1 < 16) ? jo : jo + 1, nq = (q + 1 < 16) ? q + 1 : 4;
           float4 an = av;
           if (nj < 2) an = *reinterpret_cast<const float4 *>(pV + 32 * nj * LDS_V + 8 * nq);
-          acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, s[Q0 + q].x, acc1[jt], 0, 0, 0);
-          acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, s[Q0 + q].y, acc1[jt], 0, 0, 0);
-          acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, s[Q0 + q].z, acc1[jt], 0, 0, 0);
-          acc1[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, s[Q0 + q].w, acc1[jt], 0, 0, 0);
+          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, s[Q0 + q].x, acc2[jo], 0, 0, 0);
+          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, s[Q0 + q].y, acc2[jo], 0, 0, 0);
+          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, s[Q0 + q].z, acc2[jo], 0, 0, 0);
+          acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, s[Q0 + q].w, acc2[jo], 0, 0, 0);
           av = an;
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next group's LDS fragment first,
           __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // then this group's 4 MFMAs
         }
-      }
-      // ---- W2^T = T W1^T : T[t'][t] = 0 for t' > t, so tile pair (jt' = 1, jt = 0) is skipped
-      f32x16 acc2[2];
-      const float *pT = bT + r * LDS_W + 4 * h;
-      // group order: (jo, jt, e4) = (0,0,*), (0,1,*), (1,1,*)
-      av = *reinterpret_cast<const float4 *>(pT);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { acc2[0][e] = 0.f; acc2[1][e] = 0.f; }
-#pragma unroll
-      for (int g = 0; g < 12; ++g) {
-        const int jo = g < 8 ? 0 : 1, jt = g < 4 ? 0 : 1, e4 = g & 3;
-        const int gn = g + 1, njo = gn < 8 ? 0 : 1, njt = gn < 4 ? 0 : 1, ne4 = gn & 3;
-        float4 an = av;
-        if (gn < 12) an = *reinterpret_cast<const float4 *>(pT + 32 * njo * LDS_W + 32 * njt + 8 * ne4);
-        acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, acc1[jt][4 * e4 + 0], acc2[jo], 0, 0, 0);
-        acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, acc1[jt][4 * e4 + 1], acc2[jo], 0, 0, 0);
-        acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, acc1[jt][4 * e4 + 2], acc2[jo], 0, 0, 0);
-        acc2[jo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, acc1[jt][4 * e4 + 3], acc2[jo], 0, 0, 0);
-        av = an;
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next group's LDS fragment first,
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // then this group's 4 MFMAs
       }
       // ---- U^T = V^T W2^T, one w-tile at a time; w-tile ji needs t'-tiles max(0, ji-2) .. min(1, ji).
       // A operand V[t'][w = 32 ji + r]: four ds_read_b32 per MFMA group from the t-major copy.
@@ -256,8 +245,8 @@ __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const fl
         }
       }
     };
-    apply(std::integral_constant<int, 0>{}, sV, sT);
-    if (haveB) apply(std::integral_constant<int, 8>{}, sV + QW * LDS_V, sT + QW * LDS_W);
+    apply(std::integral_constant<int, 0>{}, sV, sTV);
+    if (haveB) apply(std::integral_constant<int, 8>{}, sV + QW * LDS_V, sTV + QW * LDS_V);
 
     // ---- store the slab back (same addresses as loaded)
     if (rok) {
@@ -283,11 +272,11 @@ __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const fl
   }
 }
 
-constexpr int Q2_LDS_BYTES = (2 * QW * LDS_V + 2 * QW * LDS_W) * 4;
+constexpr int Q2_LDS_BYTES = 4 * QW * LDS_V * 4;  // V and T V of both blocks: 135 KB
 
 size_t q2_workspace_bytes(int64_t n) {
   const int64_t ngroups = cdiv(n - 2 > 0 ? n - 2 : 1, QW);
-  return (size_t)2 * (ngroups + 2) * QW * QW * sizeof(float) + 256;
+  return (size_t)2 * (ngroups + 2) * QW * QWIN * sizeof(float) + 256;
 }
 
 // Zt[nrows x n] (ldz) <- Zt * Q2^T

@@ -282,40 +282,56 @@ __global__ __launch_bounds__(256) void dc_rotate_kernel(int n, int nl, int level
 }
 
 // ------------------------------------------------------------------------------------------
-// merge step 6: secular equation  1 + rho sum_j z_j^2 / (d_j - lambda) = 0, one root per thread
+// merge step 6: secular equation  1 + rho sum_j z_j^2 / (d_j - lambda) = 0, one root per WAVEFRONT: the 64 lanes
+// split every pole sum (one root per thread left a top-level merge of 2e4 roots with 2e4 threads on 256 CUs:
+// 134 ms of 100 % latency); all lanes see bit-identical reduced values (xor butterfly, commutative adds), so the
+// bracketing / Newton control flow stays wave-uniform.
 // (fp64; bracket by geometric search from the nearer pole, then safeguarded Newton/bisection)
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 __device__ inline void secular_eval(const float *__restrict__ dk, const float *__restrict__ zk, int k, double dorg,
-                                    double rho, double x, double &g, double &gp) {
+                                    double rho, double x, int lane, double &g, double &gp) {
   double s = 0.0, sp = 0.0;
-  for (int j = 0; j < k; ++j) {
+  for (int j = lane; j < k; j += 64) {
     const double zz = (double)zk[j];
     const double den = ((double)dk[j] - dorg) - x;
     const double t = zz / den;
     s += zz * t;
     sp += t * t;
   }
+  s = wave_sum_f64(s);
+  sp = wave_sum_f64(sp);
   g = 1.0 + rho * s;
   gp = rho * sp;
 }
+
+constexpr int SEC_ROOTS_PER_WG = 4;  // 256 threads = 4 wavefronts = 4 roots
 
 __global__ __launch_bounds__(256) void dc_secular_kernel(int n, int nl, int level, DcWs ws) {
   const int q = blockIdx.y;
   const int64_t lo = node_bound(q, level, n, nl);
   const int k = ws.kcount[q];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * SEC_ROOTS_PER_WG + (threadIdx.x >> 6);
   if (i >= k) return;
   const float *dk = ws.dk + lo, *zk = ws.zk + lo;
   const double rho = (double)ws.rho[q];
   double z2sum = 0.0;
-  if (i == k - 1)
-    for (int j = 0; j < k; ++j) z2sum += (double)zk[j] * (double)zk[j];
+  if (i == k - 1) {
+    for (int j = lane; j < k; j += 64) z2sum += (double)zk[j] * (double)zk[j];
+    z2sum = wave_sum_f64(z2sum);
+  }
   const double lo_pole = (double)dk[i];
   const double hi_pole = (i + 1 < k) ? (double)dk[i + 1] : lo_pole + rho * z2sum;
   int o = i;
   double g, gp;
   if (i + 1 < k) {
-    secular_eval(dk, zk, k, 0.0, rho, 0.5 * (lo_pole + hi_pole), g, gp);
+    secular_eval(dk, zk, k, 0.0, rho, 0.5 * (lo_pole + hi_pole), lane, g, gp);
     o = (g >= 0.0) ? i : i + 1;
   }
   const double dorg = (double)dk[o];
@@ -323,43 +339,45 @@ __global__ __launch_bounds__(256) void dc_secular_kernel(int n, int nl, int leve
   if (o == i) {
     const double top = hi_pole - dorg;
     double x = (i + 1 < k) ? 0.5 * top : top;
-    secular_eval(dk, zk, k, dorg, rho, x, g, gp);
+    secular_eval(dk, zk, k, dorg, rho, x, lane, g, gp);
     b = (i + 1 < k) ? top : x;
     bool found_hi = false;
     int guard = 0;
     while (g > 0.0 && x > 0.0 && guard++ < 1100) {
       b = x; found_hi = true;
       x *= 0.5;
-      secular_eval(dk, zk, k, dorg, rho, x, g, gp);
+      secular_eval(dk, zk, k, dorg, rho, x, lane, g, gp);
     }
     a = x;
     if (!found_hi && !(i + 1 < k)) b = top;
   } else {
     const double bot = lo_pole - dorg;  // < 0
     double x = 0.5 * bot;
-    secular_eval(dk, zk, k, dorg, rho, x, g, gp);
+    secular_eval(dk, zk, k, dorg, rho, x, lane, g, gp);
     a = bot;
     int guard = 0;
     while (g < 0.0 && x < 0.0 && guard++ < 1100) {
       a = x;
       x *= 0.5;
-      secular_eval(dk, zk, k, dorg, rho, x, g, gp);
+      secular_eval(dk, zk, k, dorg, rho, x, lane, g, gp);
     }
     b = x;
   }
   // safeguarded Newton inside [a, b]
   double x = 0.5 * (a + b);
   for (int it = 0; it < 100; ++it) {
-    secular_eval(dk, zk, k, dorg, rho, x, g, gp);
+    secular_eval(dk, zk, k, dorg, rho, x, lane, g, gp);
     if (g > 0.0) b = x; else a = x;
     double xn = x - g / gp;
     if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
     if (xn == x || (b - a) <= 4.4e-16 * fmax(fabs(a), fabs(b))) { x = xn; break; }
     x = xn;
   }
-  ws.org[lo + i] = o;
-  ws.mu[lo + i] = x;
-  ws.dnew[lo + i] = (float)(dorg + x);
+  if (lane == 0) {
+    ws.org[lo + i] = o;
+    ws.mu[lo + i] = x;
+    ws.dnew[lo + i] = (float)(dorg + x);
+  }
 }
 
 // merge step 7: Loewner weights  zhat_j^2 = prod_i (lam_i - d_j) / (rho prod_{i != j} (d_i - d_j))
@@ -558,7 +576,7 @@ int stedc_dc_launch(const float *d, const float *e, int64_t n, void *wsbase, flo
     dc_deflate_kernel<<<nm, 64, 0, stream>>>(ni, nl, level, ws, ws.G, Qnxt, ldq);
     dc_gather_kernel<<<dim3(gx, (unsigned)smax, nm), 256, 0, stream>>>(ni, nl, level, Qcur, ldq, ws);
     dc_rotate_kernel<<<dim3(gx, nm), 256, 0, stream>>>(ni, nl, level, ws);
-    dc_secular_kernel<<<dim3(gx, nm), 256, 0, stream>>>(ni, nl, level, ws);
+    dc_secular_kernel<<<dim3((unsigned)cdiv(smax, SEC_ROOTS_PER_WG), nm), 256, 0, stream>>>(ni, nl, level, ws);
     dc_zhat_kernel<<<dim3(gx, nm), 256, 0, stream>>>(ni, nl, level, ws);
     dc_buildu_kernel<<<dim3(gx, nm), 256, 0, stream>>>(ni, nl, level, ws, smax);
     dc_plan_kernel<<<(unsigned)cdiv(nm, 64), 64, 0, stream>>>(ni, nl, level, ws, ws.G, Qnxt, ldq, smax, nm);

@@ -140,8 +140,8 @@ constexpr int TS_NB = 64;
 
 // 1 = use the two-stage tridiagonalisation.  Values-only solves switch at n >= 2048 (the band
 // reduction is MFMA-bound, the one-stage reduction HBM-bound).  With eigenvectors the second
-// back-transformation (Q2, q2apply.hip) has to be paid for: measured crossover between n = 8192
-// (one-stage 549 ms, two-stage 595 ms) and n = 16384 (1857 ms vs 1507 ms); n = 40960: 16.4 s vs 8.8 s.
+// back-transformation (Q2, q2apply.hip) has to be paid for: measured (one-stage / two-stage, ms) n = 4096:
+// 143 / 187, 6144: 267 / 290, 8192: 420 / 403, 10240: 625 / 539, 16384: 1857 / 1048, 40960: 16400 / 6480.
 // VIVIT_TWO_STAGE=0/1 overrides.
 static bool use_two_stage(int64_t n, bool vectors) {
   static int forced = -2;
@@ -150,7 +150,7 @@ static bool use_two_stage(int64_t n, bool vectors) {
     forced = e ? atoi(e) : -1;
   }
   if (forced >= 0) return forced != 0 && n > 2 * TS_NB;
-  return vectors ? n >= 12288 : n >= 2048;
+  return vectors ? n >= 8192 : n >= 2048;
 }
 
 static size_t two_stage_workspace_bytes(int64_t n, bool vectors) {

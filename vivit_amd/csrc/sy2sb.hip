@@ -35,7 +35,10 @@ struct QrPart {
 
 struct Sy2sbWs {
   float *pan;      // [n][SNB]   compact copy of the current panel block
-  float *stack;    // [3*SNB][n] Vt | Wt | Vt   (k-major, ld = n)
+  float *stackA;   // [4*SNB][n]  V1 | W1 | V2 | W2   (k-major, ld = n)
+  float *stackB;   // [4*SNB][n]  W1 | V1 | W2 | V2
+  float *xt;       // [SNB][n]    scratch (X^T)
+  float *G12;      // [SNB][2*SNB]
   float *S, *T, *Y3, *S2;  // [SNB*SNB] each
   float *tau1;     // [n]
   float *betas;    // [SNB] diagonal of R of the current panel
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void sb_panel_load_kernel(const float *__restr
 // partials of column c+1 while a slow one still reads those of column c).
 
 __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, int64_t mp, int c, int ncol, int nwg, QrPart pt,
-                                                      float *__restrict__ stack, int64_t lds_, int64_t gi0,
+                                                      float *__restrict__ vdst1, float *__restrict__ vdst2, int64_t lds_, int64_t gi0,
                                                       float *__restrict__ A, int64_t lda, int64_t j0,
                                                       float *__restrict__ tau1, float *__restrict__ betas) {
   __shared__ float tile[QT][SNB + 1];
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
         if (r == c) v = 1.f;
         else if (r > c) v = tile[tid][c] * scal;
         // k-major copies for the GEMMs and the reflector row for the back-transformation
-        stack[(int64_t)c * lds_ + gi0 + r] = v;
-        stack[(int64_t)(2 * SNB + c) * lds_ + gi0 + r] = v;
+        vdst1[(int64_t)c * lds_ + gi0 + r] = v;
+        vdst2[(int64_t)c * lds_ + gi0 + r] = v;
         if (r >= c) A[(j0 + c) * lda + gi0 + r] = v;
       }
       vs[tid] = v;
@@ -215,7 +218,10 @@ static size_t sy2sb_gemm_ws_bytes(int64_t n) {
     size_t a = gemm_workspace_bytes(SNB, SNB, q, false);
     size_t b = gemm_workspace_bytes(SNB, q, q, false);
     size_t c = gemm_workspace_bytes(SNB, q, SNB, false);
+    size_t d = gemm_workspace_bytes(SNB, 2 * SNB, q, false), e = gemm_workspace_bytes(SNB, q, 2 * SNB, false);
+    size_t f = gemm_workspace_bytes(q, SNB, 2 * SNB, false);
     m = a > m ? a : m; m = b > m ? b : m; m = c > m ? c : m;
+    m = d > m ? d : m; m = e > m ? e : m; m = f > m ? f : m;
   }
   size_t a = gemm_workspace_bytes(SNB, SNB, n, false), b = gemm_workspace_bytes(SNB, n, n, false);
   m = a > m ? a : m; m = b > m ? b : m;
@@ -226,7 +232,9 @@ size_t sy2sb_workspace_bytes(int64_t n) {
   const int64_t nwg = cdiv(n, QT) + 1;
   size_t b = 0;
   b += align_up(sizeof(float) * n * SNB, 256);          // pan
-  b += align_up(sizeof(float) * 3 * SNB * n, 256);      // stack
+  b += align_up(sizeof(float) * 4 * SNB * n, 256) * 2;  // stackA, stackB
+  b += align_up(sizeof(float) * SNB * n, 256);          // xt
+  b += align_up(sizeof(float) * SNB * 2 * SNB, 256);    // G12
   b += align_up(sizeof(float) * 2 * nwg * SNB, 256);    // QR partials u (double-buffered)
   b += align_up(sizeof(float) * 2 * nwg, 256);          // QR partials ssq
   b += align_up(sizeof(float) * 2 * SNB, 256);          // QR diagonal row
@@ -249,7 +257,10 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
   const int64_t nwg = cdiv(n, QT) + 1;
   Sy2sbWs ws;
   ws.pan = (float *)take(sizeof(float) * n * SNB);
-  ws.stack = (float *)take(sizeof(float) * 3 * SNB * n);
+  ws.stackA = (float *)take(sizeof(float) * 4 * SNB * n);
+  ws.stackB = (float *)take(sizeof(float) * 4 * SNB * n);
+  ws.xt = (float *)take(sizeof(float) * SNB * n);
+  ws.G12 = (float *)take(sizeof(float) * SNB * 2 * SNB);
   ws.qp.u = (float *)take(sizeof(float) * 2 * nwg * SNB);
   ws.qp.ssq = (float *)take(sizeof(float) * 2 * nwg);
   ws.qp.diag = (float *)take(sizeof(float) * 2 * SNB);
@@ -264,53 +275,111 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
   *tau1_out = ws.tau1;
   if (hipMemsetAsync(ws.tau1, 0, sizeof(float) * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
 
-  for (int64_t j0 = 0; j0 + SNB < n; j0 += SNB) {
-    const int64_t mp = n - j0 - SNB;      // rows of the block below the band
-    const int64_t gi0 = j0 + SNB;         // global index of block row 0
+  const int64_t ldn = n;
+  // Householder QR of the panel at column j0 (rows gi0 = j0 + SNB ..): reflector t in row t of v1 and v2
+  auto factor_panel = [&](int64_t j0, float *v1, float *v2) -> int {
+    const int64_t mp = n - j0 - SNB, gi0 = j0 + SNB;
     const int ncol = (int)(mp < SNB ? mp : SNB);
     const int g = (int)cdiv(mp, QT);
-    if (hipMemsetAsync(ws.stack, 0, sizeof(float) * 3 * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
     sb_panel_load_kernel<<<(unsigned)cdiv(mp * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan);
     for (int c = -1; c < ncol; ++c)  // c = -1: partials of column 0
-      qr_step_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, ncol, g, ws.qp, ws.stack, n, gi0, A, lda, j0, ws.tau1, ws.betas);
+      qr_step_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, ncol, g, ws.qp, v1, v2, ldn, gi0, A, lda, j0, ws.tau1, ws.betas);
     sb_panel_store_kernel<<<(unsigned)cdiv(SNB * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan, ws.betas);
-
-    // ---- two-sided update of A22 = A[gi0:, gi0:]  (mp x mp), all operands k-major with ld = n
-    float *Vt = ws.stack + gi0;                    // [SNB][mp]
-    float *Wt = ws.stack + (int64_t)SNB * n + gi0; // [SNB][mp]   (receives Pt, then Xt, then Wt)
+    return launch_status();
+  };
+  // W = X - 1/2 V (T^T V^T X) with X = A22 V T for the panel at j0; Vt, Wt: [SNB][mp] k-major at column offset gi0.
+  // fix_pt (optional) corrects P^T = V^T A22 for updates of A22 that have not been applied to memory yet.
+  auto compute_w = [&](int64_t j0, float *Vt, float *Wt, auto fix_pt) -> int {
+    const int64_t mp = n - j0 - SNB, gi0 = j0 + SNB;
+    const int ncol = (int)(mp < SNB ? mp : SNB);
     float *A22 = A + gi0 * lda + gi0;
     int st;
     // S = Vt Vt^T, T = larft(S, tau)
-    st = gemm_launch(LAY_K, LAY_K, Vt, Vt, ws.S, SNB, SNB, mp, n, n, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    st = gemm_launch(LAY_K, LAY_K, Vt, Vt, ws.S, SNB, SNB, mp, ldn, ldn, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     larft_kernel<<<1, SNB, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
     // Pt = Vt A22                      [SNB x mp]   (A22 symmetric: B operand k-major = A22 itself; the big
-    // operand is streamed exactly once: gemm64_dma_kernel, 2.4-2.9 TB/s)
-    st = gemm_launch(LAY_K, LAY_M, Vt, A22, Wt, SNB, mp, mp, n, lda, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    // operand is streamed exactly once: gemm64_dma_kernel)
+    st = gemm_launch(LAY_K, LAY_M, Vt, A22, Wt, SNB, mp, mp, ldn, lda, ldn, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    // Xt = T^T Pt  (in place is not possible for a GEMM: go through the third stack block as scratch)
-    float *Xt = ws.stack + (int64_t)2 * SNB * n + gi0;
-    st = gemm_launch(LAY_M, LAY_M, ws.T, Wt, Xt, SNB, mp, SNB, SNB, n, n, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    st = fix_pt(Wt);
+    if (st != VIVIT_OK) return st;
+    // Xt = T^T Pt  (in place is not possible for a GEMM: scratch block)
+    float *Xt = ws.xt + gi0;
+    st = gemm_launch(LAY_M, LAY_M, ws.T, Wt, Xt, SNB, mp, SNB, SNB, ldn, ldn, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     // S2^T = Xt Vt^T                   [SNB x SNB]
-    st = gemm_launch(LAY_K, LAY_K, Xt, Vt, ws.S2, SNB, SNB, mp, n, n, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    st = gemm_launch(LAY_K, LAY_K, Xt, Vt, ws.S2, SNB, SNB, mp, ldn, ldn, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     // Y3 = S2^T T
     st = gemm_launch(LAY_K, LAY_M, ws.S2, ws.T, ws.Y3, SNB, SNB, SNB, SNB, SNB, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    // Wt = Xt - 1/2 Y3 Vt  -> second stack block
-    if (hipMemcpy2DAsync(Wt, sizeof(float) * n, Xt, sizeof(float) * n, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
+    // Wt = Xt - 1/2 Y3 Vt
+    if (hipMemcpy2DAsync(Wt, sizeof(float) * ldn, Xt, sizeof(float) * ldn, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
                          stream) != hipSuccess)
       return VIVIT_E_LAUNCH;
-    st = gemm_launch(LAY_K, LAY_M, ws.Y3, Vt, Wt, SNB, mp, SNB, SNB, n, n, -0.5f, 1.f, false, ws.gws, ws.gws_bytes, stream);
+    return gemm_launch(LAY_K, LAY_M, ws.Y3, Vt, Wt, SNB, mp, SNB, SNB, ldn, ldn, -0.5f, 1.f, false, ws.gws, ws.gws_bytes, stream);
+  };
+  auto copy_rows = [&](float *dst, const float *src, int64_t cols) -> int {  // [SNB][cols] between k-major stacks
+    return hipMemcpy2DAsync(dst, sizeof(float) * ldn, src, sizeof(float) * ldn, sizeof(float) * cols, SNB,
+                            hipMemcpyDeviceToDevice, stream) == hipSuccess ? VIVIT_OK : VIVIT_E_LAUNCH;
+  };
+  auto no_fix = [](float *) -> int { return VIVIT_OK; };
+
+  // Panels are processed in PAIRS (A at j0, B at j0 + SNB) with one rank-256 update of the trailing matrix per
+  // pair instead of two rank-128 updates - the update is a read-modify-write of the whole trailing matrix and
+  // HBM-bound.  Panel A's update is applied at once only to the block column that becomes panel B; panel B's
+  // P^T = V2^T A22 is formed from the not yet updated trailing matrix and corrected,
+  //   V2^T (A22 - V1 W1^T - W1 V1^T) = V2^T A22 - (V2^T V1) W1^T - (V2^T W1) V1^T.
+  // stackA = [V1; W1; V2; W2], stackB = [W1; V1; W2; V2] (k-major): the update is stackA^T stackB.
+  float *sA = ws.stackA, *sB = ws.stackB;
+  for (int64_t j0 = 0; j0 + SNB < n;) {
+    const int64_t mpA = n - j0 - SNB, giA = j0 + SNB;
+    const bool pair = mpA > SNB;  // panel B (at j0 + SNB) exists
+    int st;
+    if (hipMemsetAsync(sA, 0, sizeof(float) * 4 * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (hipMemsetAsync(sB, 0, sizeof(float) * 4 * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    // ---- panel A: V1 -> sA rows 0.., sB rows SNB..;  W1 -> sA rows SNB.., sB rows 0..
+    st = factor_panel(j0, sA, sB + (int64_t)SNB * n);
     if (st != VIVIT_OK) return st;
-    // third block back to Vt:  [Vt; Wt] and [Wt; Vt] contiguous
-    if (hipMemcpy2DAsync(Xt, sizeof(float) * n, Vt, sizeof(float) * n, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
-                         stream) != hipSuccess)
-      return VIVIT_E_LAUNCH;
-    // A22 -= [V W] [W V]^T   (lower tiles on MFMA, mirrored store keeps A22 fully symmetric)
-    st = gemm_launch(LAY_M, LAY_M, Vt, Wt, A22, mp, mp, 2 * SNB, n, n, lda, -1.f, 1.f, true, ws.gws, ws.gws_bytes, stream);
+    st = compute_w(j0, sA + giA, sA + (int64_t)SNB * n + giA, no_fix);
     if (st != VIVIT_OK) return st;
+    st = copy_rows(sB + giA, sA + (int64_t)SNB * n + giA, mpA);
+    if (st != VIVIT_OK) return st;
+    if (!pair) {
+      // A22 -= [V W] [W V]^T   (lower tiles on MFMA, mirrored store keeps A22 fully symmetric)
+      st = gemm_launch(LAY_M, LAY_M, sA + giA, sB + giA, A + giA * lda + giA, mpA, mpA, 2 * SNB, ldn, ldn, lda, -1.f, 1.f, true,
+                       ws.gws, ws.gws_bytes, stream);
+      if (st != VIVIT_OK) return st;
+      j0 += SNB;
+      continue;
+    }
+    // ---- panel A's update on the block column that becomes panel B (all mpA rows x SNB columns)
+    st = gemm_launch(LAY_M, LAY_M, sA + giA, sB + giA, A + giA * lda + giA, mpA, SNB, 2 * SNB, ldn, ldn, lda, -1.f, 1.f, false,
+                     ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    // ---- panel B: V2 -> sA rows 2 SNB.., sB rows 3 SNB..;  W2 -> sA rows 3 SNB.., sB rows 2 SNB..
+    const int64_t j0B = j0 + SNB, giB = giA + SNB, mpB = mpA - SNB;
+    st = factor_panel(j0B, sA + (int64_t)2 * SNB * n, sB + (int64_t)3 * SNB * n);
+    if (st != VIVIT_OK) return st;
+    float *V2t = sA + (int64_t)2 * SNB * n + giB, *W2t = sA + (int64_t)3 * SNB * n + giB;
+    auto fix_b = [&](float *Pt) -> int {
+      // G12 = V2^T [V1 W1] (rows >= giB), Pt -= G12 [W1^T; V1^T]
+      int s2 = gemm_launch(LAY_K, LAY_K, V2t, sA + giB, ws.G12, SNB, 2 * SNB, mpB, ldn, ldn, 2 * SNB, 1.f, 0.f, false, ws.gws,
+                           ws.gws_bytes, stream);
+      if (s2 != VIVIT_OK) return s2;
+      return gemm_launch(LAY_K, LAY_M, ws.G12, sB + giB, Pt, SNB, mpB, 2 * SNB, 2 * SNB, ldn, ldn, -1.f, 1.f, false, ws.gws,
+                         ws.gws_bytes, stream);
+    };
+    st = compute_w(j0B, V2t, W2t, fix_b);
+    if (st != VIVIT_OK) return st;
+    st = copy_rows(sB + (int64_t)2 * SNB * n + giB, W2t, mpB);
+    if (st != VIVIT_OK) return st;
+    // ---- A22 (from giB) -= [V1 W1 V2 W2] [W1 V1 W2 V2]^T : one rank-256 update, lower tiles + mirror
+    st = gemm_launch(LAY_M, LAY_M, sA + giB, sB + giB, A + giB * lda + giB, mpB, mpB, 4 * SNB, ldn, ldn, lda, -1.f, 1.f, true,
+                     ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    j0 += 2 * SNB;
   }
   return launch_status();
 }

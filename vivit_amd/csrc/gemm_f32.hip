@@ -147,7 +147,10 @@ __host__ __device__ inline int sb_width(int tiles_m, int tiles_n) {
 // blockIdx.x -> (tile_i, tile_j); returns false for padding slots.
 __device__ __forceinline__ bool map_tile(int syrk, int SBW, int tiles_m, int tiles_n, int &ti, int &tj) {
   const int sb = blockIdx.x >> 8;
-  const int slot = blockIdx.x & 255;
+  // split-K: rotate the slots with the split index.  Workgroups go to XCD (linear id % 8) and every split's
+  // grid row starts at a multiple of 256, so without the rotation slot 0 of EVERY split - the only valid one of
+  // a single-tile output - lands on XCD 0 and the whole product runs on one eighth of the chip.
+  const int slot = (blockIdx.x - blockIdx.y) & 255;
   const int SBH = 256 / SBW;
   int I, J;
   if (syrk) {
@@ -749,7 +752,6 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
 constexpr int G64_NST = 7;
 constexpr int G64_TA = 64 * BK, G64_TB = 256 * BK, G64_STG = G64_TA + G64_TB;  // floats
 constexpr int GEMM64_LDS_BYTES = G64_NST * G64_STG * 4;                        // 140 KB
-constexpr int G64_NDMA = 5;                                                    // DMA instructions per wave and tile
 
 template <int ALAY, int BLAY>
 __global__ __launch_bounds__(256, 1) void gemm64_dma_kernel(GemmArgs p) {
@@ -919,10 +921,10 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
     int64_t maxs = (tm == 1 || tn == 1) ? ktiles / 8 : ktiles / 32;
     int64_t s = want < maxs ? want : maxs;
     // a single-tile output (the 64 x 64 Gram blocks of the band reduction's panels: both operands stream 64 rows
-    // x m) is cheapest with few, long splits (measured over a whole band reduction at n = 40 960: cap 8 / 16 / 32 /
-    // 64 / 256 -> 2.27 / 2.00 / 2.03 / 2.07 / 2.17 s): the slab reduce and the per-workgroup prologue dominate
+    // x m) has nothing but split-K to spread over the chip (with the slot rotation of map_tile: before it every
+    // split's only valid workgroup sat on XCD 0 and more splits bought nothing)
     static int cap1 = -1;
-    if (cap1 < 0) { const char *e = getenv("VIVIT_SPLIT_CAP1"); cap1 = e ? atoi(e) : 16; }
+    if (cap1 < 0) { const char *e = getenv("VIVIT_SPLIT_CAP1"); cap1 = e ? atoi(e) : 64; }
     const int64_t cap = tiles <= 2 ? cap1 : 64;
     if (s > cap) s = cap;
     while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ((size_t)1 << 30)) --s;

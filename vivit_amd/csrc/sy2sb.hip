@@ -28,7 +28,6 @@ constexpr int SNB = 64;     // half bandwidth = panel width (must equal sb2st.hi
 constexpr int QT = 128;     // rows per workgroup tile in the panel QR
 
 struct QrPart {
-  float *ssq;   // [2][nwg]
   float *u;     // [2][nwg][SNB]
   float *diag;  // [2][SNB]
 };
@@ -57,8 +56,8 @@ __global__ __launch_bounds__(256) void sb_panel_load_kernel(const float *__restr
 
 // ---- fused panel QR step: ONE launch per column (the dependent kernel boundary is what a column costs).
 // Launch c (c = -1: prologue) does, per 128-row workgroup tile held in LDS:
-//   1. sums the per-workgroup partials of column c left by launch c-1:  ssq = sum_{r>c} x_r^2 and
-//      u[cc] = sum_{r>c} x_r pan[r][cc]  (x = column c);  with the diagonal row (handed over in `diag`)
+//   1. sums the per-workgroup partials of column c left by launch c-1:  u[cc] = sum_{r>c} x_r pan[r][cc]
+//      (x = column c; u[c] is ||x||^2);  with the diagonal row (handed over in `diag`)
 //      that gives the reflector scalars and  z = tau v^T P = tau (pan[c][:] + scal u)  without a second pass
 //   2. writes v for its rows (k-major stack copies, reflector row of A) and updates its rows of the panel
 //   3. produces the partials (and, if it owns row c+1, the diagonal row) for column c+1 from the updated tile.
@@ -74,7 +73,6 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
   __shared__ float zs[SNB];
   __shared__ float zq[4][SNB];
   __shared__ __attribute__((aligned(16))) float zq16[16][SNB];
-  __shared__ float red[4];
   const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * QT;
   for (int idx = tid; idx < QT * (SNB / 4); idx += 256) {
@@ -89,12 +87,8 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
   }
   if (c >= 0) {
     const int par = c & 1;
-    const float *ssqin = pt.ssq + (int64_t)par * nwg;
     const float *uin = pt.u + (int64_t)par * nwg * SNB;
     const float *din = pt.diag + par * SNB;
-    float sacc = 0.f;
-    for (int w = tid; w < nwg; w += 256) sacc += ssqin[w];
-    const float ssq = block_sum(sacc, red, tid);
     {
       // u = sum over the nwg partial vectors: thread (group q of 16, column quad c4) takes partials q, q+16, ...
       // as float4, 20 independent loads in flight per batch (with 4 scalar loads in flight this reduction was
@@ -115,6 +109,11 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
       }
       *reinterpret_cast<float4 *>(&zq16[q][4 * c4]) = acc;
     }
+    __syncthreads();  // tile and zq16 complete
+    // ||x||^2 is the partial sum of column c itself: u[c] = sum_{r>c} x_r pan[r][c] = sum x_r^2
+    float ssq = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) ssq += zq16[g2][c];
     const float alpha = din[c];
     float tau = 0.f, beta = alpha, scal = 0.f;
     if (ssq > 0.f) {
@@ -122,7 +121,6 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
       tau = (beta - alpha) / beta;
       scal = 1.f / (alpha - beta);
     }
-    __syncthreads();  // tile and zq complete
     if (tid < SNB) {
       float u = 0.f;
 #pragma unroll
@@ -166,10 +164,6 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
       vs[tid] = (r > cn && r < mp) ? tile[tid][cn] : 0.f;   // x (unscaled column cn below its diagonal)
     }
     __syncthreads();
-    float sq = 0.f;
-    if (tid < QT) sq = vs[tid] * vs[tid];
-    sq = block_sum(sq, red, tid);
-    if (tid == 0) pt.ssq[(int64_t)par * nwg + blockIdx.x] = sq;
     {
       const int cc = tid & 63, q = tid >> 6;
       float acc = 0.f;
@@ -246,7 +240,6 @@ size_t sy2sb_workspace_bytes(int64_t n) {
   b += align_up(sizeof(float) * SNB * n, 256);          // xt
   b += align_up(sizeof(float) * SNB * 2 * SNB, 256);    // G12
   b += align_up(sizeof(float) * 2 * nwg * SNB, 256);    // QR partials u (double-buffered)
-  b += align_up(sizeof(float) * 2 * nwg, 256);          // QR partials ssq
   b += align_up(sizeof(float) * 2 * SNB, 256);          // QR diagonal row
   b += align_up(sizeof(float) * SNB * SNB, 256) * 4;    // S T Y3 S2
   b += align_up(sizeof(float) * n, 256);                // tau1
@@ -272,7 +265,6 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
   ws.xt = (float *)take(sizeof(float) * SNB * n);
   ws.G12 = (float *)take(sizeof(float) * SNB * 2 * SNB);
   ws.qp.u = (float *)take(sizeof(float) * 2 * nwg * SNB);
-  ws.qp.ssq = (float *)take(sizeof(float) * 2 * nwg);
   ws.qp.diag = (float *)take(sizeof(float) * 2 * SNB);
   ws.S = (float *)take(sizeof(float) * SNB * SNB);
   ws.T = (float *)take(sizeof(float) * SNB * SNB);

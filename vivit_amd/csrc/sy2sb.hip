@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
                                                       float *__restrict__ A, int64_t lda, int64_t j0,
                                                       float *__restrict__ tau1, float *__restrict__ betas) {
   __shared__ float tile[QT][SNB + 1];
-  __shared__ float vs[QT];
+  __shared__ float vs[QT], xs2[QT];
   __shared__ float zs[SNB];
   __shared__ float zq[4][SNB];
   __shared__ __attribute__((aligned(16))) float zq16[16][SNB];
@@ -140,38 +140,44 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
       }
       vs[tid] = v;
     }
-    __syncthreads();
-    // pan[r][cc] -= v_r z[cc]   (cc > c; rows above c have v = 0)
-    for (int idx = tid; idx < QT * SNB; idx += 256) {
-      const int rl = idx >> 6, cc = idx & 63;
+    if (blockIdx.x == 0 && tid == 0) { tau1[j0 + c] = tau; betas[c] = beta; }
+  } else {
+    if (tid < QT) vs[tid] = 0.f;   // prologue launch: nothing to apply
+    if (tid < SNB) zs[tid] = 0.f;
+  }
+  __syncthreads();  // vs, zs (and the tile) complete
+  // ---- update  pan[r][cc] -= v_r z[cc]  (cc > c; rows above c have v = 0)  fused with the partials of column
+  // cn = c + 1:  u[cc] = sum_{r > cn} x_r pan[r][cc]  with x = the UPDATED column cn (snapshot in xs2 first: the
+  // loop below overwrites that column of the tile while other threads would still read it)
+  const int cn = c + 1;
+  const bool has_next = cn < ncol;
+  if (tid < QT) {
+    const int64_t r = r0 + tid;
+    xs2[tid] = (has_next && r > cn && r < mp) ? tile[tid][cn] - vs[tid] * zs[cn] : 0.f;
+  }
+  __syncthreads();
+  {
+    const int cc = tid & 63, q = tid >> 6;
+    const float zc = zs[cc];
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < QT / 4; ++i) {
+      const int rl = q + 4 * i;
       const float v = vs[rl];
+      float x = tile[rl][cc];
       if (cc > c && v != 0.f) {
-        const float x = tile[rl][cc] - v * zs[cc];
+        x -= v * zc;
         tile[rl][cc] = x;
         if (r0 + rl < mp) pan[(r0 + rl) * SNB + cc] = x;
       }
+      acc += xs2[rl] * x;
     }
-    if (blockIdx.x == 0 && tid == 0) { tau1[j0 + c] = tau; betas[c] = beta; }
+    zq[q][cc] = acc;
   }
+  if (!has_next) return;
   __syncthreads();
-  // ---- partials for column cn = c + 1
-  const int cn = c + 1;
-  if (cn >= ncol) return;
   {
     const int par = cn & 1;
-    if (tid < QT) {
-      const int64_t r = r0 + tid;
-      vs[tid] = (r > cn && r < mp) ? tile[tid][cn] : 0.f;   // x (unscaled column cn below its diagonal)
-    }
-    __syncthreads();
-    {
-      const int cc = tid & 63, q = tid >> 6;
-      float acc = 0.f;
-#pragma unroll 8
-      for (int rl = q * 32; rl < q * 32 + 32; ++rl) acc += vs[rl] * tile[rl][cc];
-      zq[q][cc] = acc;
-    }
-    __syncthreads();
     if (tid < SNB) pt.u[((int64_t)par * nwg + blockIdx.x) * SNB + tid] = (zq[0][tid] + zq[1][tid]) + (zq[2][tid] + zq[3][tid]);
     if (cn >= r0 && cn < r0 + QT && tid < SNB) pt.diag[par * SNB + tid] = tile[cn - r0][tid];
   }

@@ -49,7 +49,18 @@ __device__ __forceinline__ float q2_v(const Q2Step &a, int g0, int c_start, int 
 }
 
 // ---- T V (T = compact-WY factor) of every block of the step ------------------------------------
-__global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, float *__restrict__ TVbuf) {
+constexpr int Q2_WIN = 16;  // wavefront steps prepared per launch
+struct Q2Win {
+  int tau[Q2_WIN], G_lo[Q2_WIN], nblk[Q2_WIN];
+  int64_t off[Q2_WIN];  // first block of the step in TVbuf
+};
+
+// blockIdx.y = step inside the window, blockIdx.x = 2 * block + level (blocks beyond the step's count exit)
+__global__ __launch_bounds__(256) void q2_prepare_kernel(Q2Step a, Q2Win win, float *__restrict__ TVbuf) {
+  if ((int)blockIdx.x >= 2 * win.nblk[blockIdx.y]) return;
+  a.tau = win.tau[blockIdx.y];
+  a.G_lo = win.G_lo[blockIdx.y];
+  TVbuf += win.off[blockIdx.y] * QW * QWIN;
   __shared__ float V[QW][QWIN + 1];
   __shared__ float S[QW][QW + 1];
   __shared__ float Ts[QW][QW + 1];
@@ -276,7 +287,7 @@ constexpr int Q2_LDS_BYTES = 4 * QW * LDS_V * 4;  // V and T V of both blocks: 1
 
 size_t q2_workspace_bytes(int64_t n) {
   const int64_t ngroups = cdiv(n - 2 > 0 ? n - 2 : 1, QW);
-  return (size_t)2 * (ngroups + 2) * QW * QWIN * sizeof(float) + 256;
+  return (size_t)Q2_WIN * 2 * (ngroups + 2) * QW * QWIN * sizeof(float) + 256;
 }
 
 // Zt[nrows x n] (ldz) <- Zt * Q2^T
@@ -302,35 +313,53 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
   a.R2 = R2; a.ldr = ldr; a.tau2 = tau2; a.nk = sb2st_num_levels(n); a.n = (int)n; a.ngroups = ngroups;
   const int tau_max = (ngroups - 1) + Kmax(0);
   const int64_t nslab = cdiv(nrows, Q2_SLAB);
+  // T V of the blocks is prepared for Q2_WIN wavefront steps per launch (the per-step prepare launches were 0.1 s
+  // of pure latency at n = 40 960), then the steps of the window are applied one launch each
   int G_lo = 0;
-  for (int tau = 0; tau <= tau_max; ++tau) {
-    // valid G: 0 <= G <= min(tau, ngroups-1) and tau - G <= Kmax(group of G); G + Kmax(G) grows with G
-    while (G_lo < ngroups && G_lo + Kmax(ngroups - 1 - G_lo) < tau) ++G_lo;
-    const int G_hi = tau < ngroups - 1 ? tau : ngroups - 1;
-    if (G_lo > G_hi) continue;
-    a.tau = tau; a.G_lo = G_lo;
-    const unsigned nblk = (unsigned)(G_hi - G_lo + 1);
-    q2_prepare_kernel<<<2 * nblk, 256, 0, stream>>>(a, Tbuf);
-    // a workgroup walks over several slabs (V, T stay in LDS); ~2000 workgroups keep the tail short
-    // workgroups = gx * nblk, one per CU at a time: pick the row split whose last round of 256 workgroups is
-    // fullest and whose slabs divide evenly, with at least ~4 slabs per V/T load (matters in row-range mode)
-    int64_t gx = 1;
-    {
-      const int64_t hi = cdiv(nslab, 4) < cdiv(4096, nblk) ? cdiv(nslab, 4) : cdiv(4096, nblk);
-      double best = -1.0;
-      for (int64_t c = 1; c <= (hi < 1 ? 1 : hi); ++c) {
-        const int64_t wgs = c * nblk;
-        const double fill = (double)wgs / (double)(256 * cdiv(wgs, 256));
-        const double even = ((double)nslab / (double)c) / (double)cdiv(nslab, c);
-        const double enough = wgs >= 512 ? 1.0 : (double)wgs / 512.0;
-        const double score = fill * even * enough;
-        if (score > best + 1e-9) { best = score; gx = c; }
-      }
+  for (int tau0 = 0; tau0 <= tau_max;) {
+    Q2Win win;
+    int nw = 0, maxblk = 0;
+    int64_t off = 0;
+    int tau = tau0;
+    for (; tau <= tau_max && nw < Q2_WIN; ++tau) {
+      // valid G: 0 <= G <= min(tau, ngroups-1) and tau - G <= Kmax(group of G); G + Kmax(G) grows with G
+      while (G_lo < ngroups && G_lo + Kmax(ngroups - 1 - G_lo) < tau) ++G_lo;
+      const int G_hi = tau < ngroups - 1 ? tau : ngroups - 1;
+      if (G_lo > G_hi) continue;
+      const int nblk = G_hi - G_lo + 1;
+      win.tau[nw] = tau; win.G_lo[nw] = G_lo; win.nblk[nw] = nblk; win.off[nw] = off;
+      off += 2 * nblk;
+      if (nblk > maxblk) maxblk = nblk;
+      ++nw;
     }
-    if (vec)
-      q2_apply_kernel<true><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, Tbuf, Zt, ldz, (int)nrows);
-    else
-      q2_apply_kernel<false><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, Tbuf, Zt, ldz, (int)nrows);
+    tau0 = tau;
+    if (nw == 0) continue;
+    for (int i = nw; i < Q2_WIN; ++i) { win.tau[i] = 0; win.G_lo[i] = 0; win.nblk[i] = 0; win.off[i] = 0; }
+    q2_prepare_kernel<<<dim3(2 * maxblk, nw), 256, 0, stream>>>(a, win, Tbuf);
+    for (int i = 0; i < nw; ++i) {
+      a.tau = win.tau[i]; a.G_lo = win.G_lo[i];
+      const unsigned nblk = (unsigned)win.nblk[i];
+      const float *TV = Tbuf + win.off[i] * QW * QWIN;
+      // workgroups = gx * nblk, one per CU at a time: pick the row split whose last round of 256 workgroups is
+      // fullest and whose slabs divide evenly, with at least ~4 slabs per V/T load (matters in row-range mode)
+      int64_t gx = 1;
+      {
+        const int64_t hi = cdiv(nslab, 4) < cdiv(4096, nblk) ? cdiv(nslab, 4) : cdiv(4096, nblk);
+        double best = -1.0;
+        for (int64_t c = 1; c <= (hi < 1 ? 1 : hi); ++c) {
+          const int64_t wgs = c * nblk;
+          const double fill = (double)wgs / (double)(256 * cdiv(wgs, 256));
+          const double even = ((double)nslab / (double)c) / (double)cdiv(nslab, c);
+          const double enough = wgs >= 512 ? 1.0 : (double)wgs / 512.0;
+          const double score = fill * even * enough;
+          if (score > best + 1e-9) { best = score; gx = c; }
+        }
+      }
+      if (vec)
+        q2_apply_kernel<true><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, TV, Zt, ldz, (int)nrows);
+      else
+        q2_apply_kernel<false><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, TV, Zt, ldz, (int)nrows);
+    }
   }
   return launch_status();
 }

@@ -26,6 +26,8 @@ namespace vivit {
 
 constexpr int SNB = 64;     // half bandwidth = panel width (must equal sb2st.hip's NB)
 constexpr int QT = 128;     // rows per workgroup tile in the panel QR
+constexpr int SGRP = 2;     // panels per delayed trailing-matrix update (measured at n = 40 960: 1 -> 2.00 s,
+                            // 2 -> 1.52 s, 4 -> 1.52 s: beyond pairs the update is MFMA-bound)
 
 struct QrPart {
   float *u;     // [2][nwg][SNB]
@@ -34,10 +36,10 @@ struct QrPart {
 
 struct Sy2sbWs {
   float *pan;      // [n][SNB]   compact copy of the current panel block
-  float *stackA;   // [4*SNB][n]  V1 | W1 | V2 | W2   (k-major, ld = n)
-  float *stackB;   // [4*SNB][n]  W1 | V1 | W2 | V2
+  float *stackA;   // [2*SGRP*SNB][n]  V1 | W1 | V2 | W2 ...  (k-major, ld = n)
+  float *stackB;   // [2*SGRP*SNB][n]  W1 | V1 | W2 | V2 ...
   float *xt;       // [SNB][n]    scratch (X^T)
-  float *G12;      // [SNB][2*SNB]
+  float *G12;      // [SNB][2*SNB*(SGRP-1)]
   float *S, *T, *Y3, *S2;  // [SNB*SNB] each
   float *tau1;     // [n]
   float *betas;    // [SNB] diagonal of R of the current panel
@@ -228,8 +230,12 @@ static size_t sy2sb_gemm_ws_bytes(int64_t n) {
     size_t a = gemm_workspace_bytes(SNB, SNB, q, false);
     size_t b = gemm_workspace_bytes(SNB, q, q, false);
     size_t c = gemm_workspace_bytes(SNB, q, SNB, false);
-    size_t d = gemm_workspace_bytes(SNB, 2 * SNB, q, false), e = gemm_workspace_bytes(SNB, q, 2 * SNB, false);
-    size_t f = gemm_workspace_bytes(q, SNB, 2 * SNB, false);
+    size_t d = 0, e = 0, f = 0;
+    for (int g = 1; g < SGRP; ++g) {
+      const size_t d1 = gemm_workspace_bytes(SNB, 2 * SNB * g, q, false), e1 = gemm_workspace_bytes(SNB, q, 2 * SNB * g, false);
+      const size_t f1 = gemm_workspace_bytes(q, SNB, 2 * SNB * g, false);
+      d = d1 > d ? d1 : d; e = e1 > e ? e1 : e; f = f1 > f ? f1 : f;
+    }
     m = a > m ? a : m; m = b > m ? b : m; m = c > m ? c : m;
     m = d > m ? d : m; m = e > m ? e : m; m = f > m ? f : m;
   }
@@ -242,9 +248,9 @@ size_t sy2sb_workspace_bytes(int64_t n) {
   const int64_t nwg = cdiv(n, QT) + 1;
   size_t b = 0;
   b += align_up(sizeof(float) * n * SNB, 256);          // pan
-  b += align_up(sizeof(float) * 4 * SNB * n, 256) * 2;  // stackA, stackB
+  b += align_up(sizeof(float) * 2 * SGRP * SNB * n, 256) * 2;  // stackA, stackB
   b += align_up(sizeof(float) * SNB * n, 256);          // xt
-  b += align_up(sizeof(float) * SNB * 2 * SNB, 256);    // G12
+  b += align_up(sizeof(float) * SNB * 2 * SNB * SGRP, 256);    // G12
   b += align_up(sizeof(float) * 2 * nwg * SNB, 256);    // QR partials u (double-buffered)
   b += align_up(sizeof(float) * 2 * SNB, 256);          // QR diagonal row
   b += align_up(sizeof(float) * SNB * SNB, 256) * 4;    // S T Y3 S2
@@ -266,10 +272,10 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
   const int64_t nwg = cdiv(n, QT) + 1;
   Sy2sbWs ws;
   ws.pan = (float *)take(sizeof(float) * n * SNB);
-  ws.stackA = (float *)take(sizeof(float) * 4 * SNB * n);
-  ws.stackB = (float *)take(sizeof(float) * 4 * SNB * n);
+  ws.stackA = (float *)take(sizeof(float) * 2 * SGRP * SNB * n);
+  ws.stackB = (float *)take(sizeof(float) * 2 * SGRP * SNB * n);
   ws.xt = (float *)take(sizeof(float) * SNB * n);
-  ws.G12 = (float *)take(sizeof(float) * SNB * 2 * SNB);
+  ws.G12 = (float *)take(sizeof(float) * SNB * 2 * SNB * SGRP);
   ws.qp.u = (float *)take(sizeof(float) * 2 * nwg * SNB);
   ws.qp.diag = (float *)take(sizeof(float) * 2 * SNB);
   ws.S = (float *)take(sizeof(float) * SNB * SNB);
@@ -332,62 +338,54 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     return hipMemcpy2DAsync(dst, sizeof(float) * ldn, src, sizeof(float) * ldn, sizeof(float) * cols, SNB,
                             hipMemcpyDeviceToDevice, stream) == hipSuccess ? VIVIT_OK : VIVIT_E_LAUNCH;
   };
-  auto no_fix = [](float *) -> int { return VIVIT_OK; };
 
-  // Panels are processed in PAIRS (A at j0, B at j0 + SNB) with one rank-256 update of the trailing matrix per
-  // pair instead of two rank-128 updates - the update is a read-modify-write of the whole trailing matrix and
-  // HBM-bound.  Panel A's update is applied at once only to the block column that becomes panel B; panel B's
-  // P^T = V2^T A22 is formed from the not yet updated trailing matrix and corrected,
-  //   V2^T (A22 - V1 W1^T - W1 V1^T) = V2^T A22 - (V2^T V1) W1^T - (V2^T W1) V1^T.
-  // stackA = [V1; W1; V2; W2], stackB = [W1; V1; W2; V2] (k-major): the update is stackA^T stackB.
+  // Panels are processed in GROUPS of SGRP with ONE rank-(2 SNB SGRP) update of the trailing matrix per group
+  // instead of SGRP rank-128 updates - the update is a read-modify-write of the whole trailing matrix and
+  // HBM-bound.  The pending updates of the group's earlier panels are applied at once only to the block column
+  // that becomes the next panel; that panel's P^T = V^T A22 is formed from the not yet updated trailing matrix
+  // and corrected,   V^T (A22 - sum_i V_i W_i^T + W_i V_i^T) = V^T A22 - (V^T [V_i W_i ...]) [W_i^T; V_i^T; ...].
+  // stackA = [V1; W1; V2; W2; ...], stackB = [W1; V1; W2; V2; ...] (k-major): the update is stackA^T stackB.
   float *sA = ws.stackA, *sB = ws.stackB;
   for (int64_t j0 = 0; j0 + SNB < n;) {
-    const int64_t mpA = n - j0 - SNB, giA = j0 + SNB;
-    const bool pair = mpA > SNB;  // panel B (at j0 + SNB) exists
     int st;
-    if (hipMemsetAsync(sA, 0, sizeof(float) * 4 * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
-    if (hipMemsetAsync(sB, 0, sizeof(float) * 4 * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
-    // ---- panel A: V1 -> sA rows 0.., sB rows SNB..;  W1 -> sA rows SNB.., sB rows 0..
-    st = factor_panel(j0, sA, sB + (int64_t)SNB * n);
-    if (st != VIVIT_OK) return st;
-    st = compute_w(j0, sA + giA, sA + (int64_t)SNB * n + giA, no_fix);
-    if (st != VIVIT_OK) return st;
-    st = copy_rows(sB + giA, sA + (int64_t)SNB * n + giA, mpA);
-    if (st != VIVIT_OK) return st;
-    if (!pair) {
-      // A22 -= [V W] [W V]^T   (lower tiles on MFMA, mirrored store keeps A22 fully symmetric)
-      st = gemm_launch(LAY_M, LAY_M, sA + giA, sB + giA, A + giA * lda + giA, mpA, mpA, 2 * SNB, ldn, ldn, lda, -1.f, 1.f, true,
-                       ws.gws, ws.gws_bytes, stream);
+    if (hipMemsetAsync(sA, 0, sizeof(float) * 2 * SGRP * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (hipMemsetAsync(sB, 0, sizeof(float) * 2 * SGRP * SNB * n, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    int np = 0;            // panels of this group done so far
+    int64_t gi_last = 0;   // first row/column of the trailing matrix after the group's last panel
+    for (; np < SGRP && j0 + SNB < n; ++np, j0 += SNB) {
+      const int64_t mp = n - j0 - SNB, gi = j0 + SNB;
+      const int64_t kp = (int64_t)2 * SNB * np;  // stack rows of the pending updates
+      if (np > 0) {
+        // pending updates on the block column that becomes this panel: rows gi - SNB .., columns gi - SNB .. gi - 1
+        const int64_t gc = gi - SNB;
+        st = gemm_launch(LAY_M, LAY_M, sA + gc, sB + gc, A + gc * lda + gc, n - gc, SNB, kp, ldn, ldn, lda, -1.f, 1.f, false,
+                         ws.gws, ws.gws_bytes, stream);
+        if (st != VIVIT_OK) return st;
+      }
+      // V -> sA rows kp.., sB rows kp + SNB..;  W -> sA rows kp + SNB.., sB rows kp..
+      float *Vrow = sA + kp * n, *Wrow = sA + (kp + SNB) * n;
+      st = factor_panel(j0, Vrow, sB + (kp + SNB) * n);
       if (st != VIVIT_OK) return st;
-      j0 += SNB;
-      continue;
+      auto fix = [&](float *Pt) -> int {
+        if (np == 0) return VIVIT_OK;
+        // G = V^T [V1 W1 ...] (rows >= gi), Pt -= G [W1^T; V1^T; ...]
+        int s2 = gemm_launch(LAY_K, LAY_K, Vrow + gi, sA + gi, ws.G12, SNB, kp, mp, ldn, ldn, kp, 1.f, 0.f, false, ws.gws,
+                             ws.gws_bytes, stream);
+        if (s2 != VIVIT_OK) return s2;
+        return gemm_launch(LAY_K, LAY_M, ws.G12, sB + gi, Pt, SNB, mp, kp, kp, ldn, ldn, -1.f, 1.f, false, ws.gws, ws.gws_bytes,
+                           stream);
+      };
+      st = compute_w(j0, Vrow + gi, Wrow + gi, fix);
+      if (st != VIVIT_OK) return st;
+      st = copy_rows(sB + kp * n + gi, Wrow + gi, mp);
+      if (st != VIVIT_OK) return st;
+      gi_last = gi;
     }
-    // ---- panel A's update on the block column that becomes panel B (all mpA rows x SNB columns)
-    st = gemm_launch(LAY_M, LAY_M, sA + giA, sB + giA, A + giA * lda + giA, mpA, SNB, 2 * SNB, ldn, ldn, lda, -1.f, 1.f, false,
-                     ws.gws, ws.gws_bytes, stream);
+    // ---- trailing matrix (from the last panel's gi) -= stackA^T stackB : one update, lower tiles + mirror
+    const int64_t mt = n - gi_last;
+    st = gemm_launch(LAY_M, LAY_M, sA + gi_last, sB + gi_last, A + gi_last * lda + gi_last, mt, mt, (int64_t)2 * SNB * np, ldn, ldn,
+                     lda, -1.f, 1.f, true, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    // ---- panel B: V2 -> sA rows 2 SNB.., sB rows 3 SNB..;  W2 -> sA rows 3 SNB.., sB rows 2 SNB..
-    const int64_t j0B = j0 + SNB, giB = giA + SNB, mpB = mpA - SNB;
-    st = factor_panel(j0B, sA + (int64_t)2 * SNB * n, sB + (int64_t)3 * SNB * n);
-    if (st != VIVIT_OK) return st;
-    float *V2t = sA + (int64_t)2 * SNB * n + giB, *W2t = sA + (int64_t)3 * SNB * n + giB;
-    auto fix_b = [&](float *Pt) -> int {
-      // G12 = V2^T [V1 W1] (rows >= giB), Pt -= G12 [W1^T; V1^T]
-      int s2 = gemm_launch(LAY_K, LAY_K, V2t, sA + giB, ws.G12, SNB, 2 * SNB, mpB, ldn, ldn, 2 * SNB, 1.f, 0.f, false, ws.gws,
-                           ws.gws_bytes, stream);
-      if (s2 != VIVIT_OK) return s2;
-      return gemm_launch(LAY_K, LAY_M, ws.G12, sB + giB, Pt, SNB, mpB, 2 * SNB, 2 * SNB, ldn, ldn, -1.f, 1.f, false, ws.gws,
-                         ws.gws_bytes, stream);
-    };
-    st = compute_w(j0B, V2t, W2t, fix_b);
-    if (st != VIVIT_OK) return st;
-    st = copy_rows(sB + (int64_t)2 * SNB * n + giB, W2t, mpB);
-    if (st != VIVIT_OK) return st;
-    // ---- A22 (from giB) -= [V1 W1 V2 W2] [W1 V1 W2 V2]^T : one rank-256 update, lower tiles + mirror
-    st = gemm_launch(LAY_M, LAY_M, sA + giB, sB + giB, A + giB * lda + giB, mpB, mpB, 4 * SNB, ldn, ldn, lda, -1.f, 1.f, true,
-                     ws.gws, ws.gws_bytes, stream);
-    if (st != VIVIT_OK) return st;
-    j0 += 2 * SNB;
   }
   return launch_status();
 }

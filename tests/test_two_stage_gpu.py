@@ -171,3 +171,26 @@ print(json.dumps(dict(same=same, diff=diff, orth=float(np.abs(Zc.T @ Zc - np.eye
     assert res["diff"] <= 2e-5, res   # split-K choices may depend on the row count: allow rounding-level differences
     assert res["orth"] <= 5e-5, res
     assert res["resid"] <= 3e-5, res
+
+
+def test_two_stage_default_size_degenerate_inputs():
+    """n = 8192 takes the two-stage path by default: NaN input must raise like a failing Tensor.symeig
+    (vivit/utils/eig.py:37-40) instead of hanging or faulting; the zero matrix and a multiple of the identity
+    (every reflector degenerate, total deflation) must come back exact."""
+    from vivit_amd import kernels
+
+    n = 8192
+    g = torch.Generator().manual_seed(0)
+    M = torch.randn(n, n, generator=g)
+    S = ((M + M.T) / 2).to(DEV)
+    S[100, 200] = float("nan")
+    S[200, 100] = float("nan")
+    for vec in (False, True):
+        with pytest.raises(RuntimeError):
+            kernels.symeig(S, eigenvectors=vec)
+    w, Z = kernels.symeig(torch.zeros(n, n, device=DEV), eigenvectors=True)
+    assert float(w.abs().max()) == 0.0
+    assert float((Z.T @ Z - torch.eye(n, device=DEV)).abs().max()) < 1e-6
+    w, Z = kernels.symeig(3.0 * torch.eye(n, device=DEV), eigenvectors=True)
+    assert float((w - 3.0).abs().max()) == 0.0
+    assert float((Z.T @ Z - torch.eye(n, device=DEV)).abs().max()) < 1e-6

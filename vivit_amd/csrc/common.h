@@ -18,6 +18,17 @@ static inline int launch_status() {
   return hipGetLastError() == hipSuccess ? VIVIT_OK : VIVIT_E_LAUNCH;
 }
 
+// Large dynamic-LDS kernels need hipFuncAttributeMaxDynamicSharedMemorySize once PER DEVICE (the attribute lives
+// on the device's code object): `done` is a per-call-site bitmap over device ordinals.
+static inline bool ensure_dynamic_lds(const void *fn, int bytes, unsigned long long &done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done & bit) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  return true;  // the caller sets the bit after ALL kernels of its group succeeded
+}
+
 // Operand storage of a GEMM input X that is logically [rows, k]:
 //   LAY_K: X[row * ld + k]   (k contiguous)
 //   LAY_M: X[k * ld + row]   (row contiguous)

@@ -1016,16 +1016,19 @@ static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit
 }
 
 static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    const void *fns[4] = {reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_K>),
-                          reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_M>),
-                          reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_K>),
-                          reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_M>)};
-    for (const void *f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS_BYTES) != hipSuccess)
-        return VIVIT_E_LAUNCH;
-    attr = true;
+  static unsigned long long attr_done = 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (!(attr_done & (1ull << (dev & 63)))) {
+      const void *fns[4] = {reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_K>),
+                            reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_M>),
+                            reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_K>),
+                            reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_M>)};
+      for (const void *f : fns)
+        if (!ensure_dynamic_lds(f, GEMM256_LDS_BYTES, attr_done)) return VIVIT_E_LAUNCH;
+      attr_done |= 1ull << (dev & 63);
+    }
   }
   // never more splits than the caller's workspace holds (callers size it for their largest problem; the plan
   // of a smaller one may differ)
@@ -1103,16 +1106,19 @@ static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *kspli
 }
 
 static int gemm64_launch(int alay, int blay, GemmArgs p, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    const void *fns[4] = {reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_K, LAY_K>),
-                          reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_K, LAY_M>),
-                          reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_M, LAY_K>),
-                          reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_M, LAY_M>)};
-    for (const void *f : fns)
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM64_LDS_BYTES) != hipSuccess)
-        return VIVIT_E_LAUNCH;
-    attr = true;
+  static unsigned long long attr_done = 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (!(attr_done & (1ull << (dev & 63)))) {
+      const void *fns[4] = {reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_K, LAY_K>),
+                            reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_K, LAY_M>),
+                            reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_M, LAY_K>),
+                            reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_M, LAY_M>)};
+      for (const void *f : fns)
+        if (!ensure_dynamic_lds(f, GEMM64_LDS_BYTES, attr_done)) return VIVIT_E_LAUNCH;
+      attr_done |= 1ull << (dev & 63);
+    }
   }
   const size_t need = gemm64_workspace_bytes(p.M, p.N, p.K, &p.ksplit, &p.kchunk);
   p.slab = nullptr;

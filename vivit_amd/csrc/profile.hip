@@ -27,14 +27,14 @@ void prof_begin(int kind, double work, hipStream_t stream) {
   s.kind = kind;
   s.work = work;
   if (hipEventCreate(&s.start) != hipSuccess || hipEventCreate(&s.stop) != hipSuccess) return;
-  hipEventRecord(s.start, stream);
+  (void)hipEventRecord(s.start, stream);
   g_open[kind] = s;
   g_open_valid[kind] = true;
 }
 
 void prof_end(int kind, hipStream_t stream) {
   if (!g_prof_on || !g_open_valid[kind]) return;
-  hipEventRecord(g_open[kind].stop, stream);
+  (void)hipEventRecord(g_open[kind].stop, stream);
   g_samples.push_back(g_open[kind]);
   g_open_valid[kind] = false;
 }
@@ -62,8 +62,8 @@ int vivit_profile_end(double *out) {
       acc[s.kind][1] += ms;
       acc[s.kind][2] += s.work;
     }
-    hipEventDestroy(s.start);
-    hipEventDestroy(s.stop);
+    (void)hipEventDestroy(s.start);
+    (void)hipEventDestroy(s.stop);
   }
   g_samples.clear();
   if (out)

@@ -294,14 +294,16 @@ size_t q2_workspace_bytes(int64_t n) {
 int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const float *R2, int64_t ldr, const float *tau2,
                     void *ws, hipStream_t stream) {
   if (n < 3) return VIVIT_OK;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(q2_apply_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            Q2_LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(q2_apply_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            Q2_LDS_BYTES) != hipSuccess)
-      return VIVIT_E_LAUNCH;
-    attr = true;
+  static unsigned long long attr_done = 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (!(attr_done & (1ull << (dev & 63)))) {
+      if (!ensure_dynamic_lds(reinterpret_cast<const void *>(q2_apply_kernel<true>), Q2_LDS_BYTES, attr_done) ||
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(q2_apply_kernel<false>), Q2_LDS_BYTES, attr_done))
+        return VIVIT_E_LAUNCH;
+      attr_done |= 1ull << (dev & 63);
+    }
   }
   float *Tbuf = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
   const bool vec = ((reinterpret_cast<uintptr_t>(Zt) & 15) == 0) && (ldz % 4 == 0) && (n % 4 == 0);

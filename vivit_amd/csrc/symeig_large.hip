@@ -94,12 +94,14 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
   const size_t gws_bytes = bt_gemm_ws_bytes(n);
   void *gws = take(gws_bytes);
   if (jmax < 0 || nrows <= 0) return VIVIT_OK;
-  static bool tf_attr = false;
-  if (!tf_attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(bt_tfactor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            BT_TF_LDS) != hipSuccess)
-      return VIVIT_E_LAUNCH;
-    tf_attr = true;
+  static unsigned long long tf_done = 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (!(tf_done & (1ull << (dev & 63)))) {
+      if (!ensure_dynamic_lds(reinterpret_cast<const void *>(bt_tfactor_kernel), BT_TF_LDS, tf_done)) return VIVIT_E_LAUNCH;
+      tf_done |= 1ull << (dev & 63);
+    }
   }
   int st;
   for (int64_t a = (jmax / KS) * KS; a >= 0; a -= KS) {

@@ -202,13 +202,16 @@ size_t symeig_small_lds_bytes(int n) {
 
 int symeig_small_launch(const float *A, int64_t lda, int n, float *w, float *Z, int64_t ldz, int32_t *info,
                         hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(symeig_small_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)symeig_small_lds_bytes(SMALL_N_MAX)) != hipSuccess)
-      return VIVIT_E_LAUNCH;
-    attr_set = true;
+  static unsigned long long attr_done = 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (!(attr_done & (1ull << (dev & 63)))) {
+      if (!ensure_dynamic_lds(reinterpret_cast<const void *>(symeig_small_kernel), (int)symeig_small_lds_bytes(SMALL_N_MAX),
+                              attr_done))
+        return VIVIT_E_LAUNCH;
+      attr_done |= 1ull << (dev & 63);
+    }
   }
   symeig_small_kernel<<<1, 256, symeig_small_lds_bytes(n), stream>>>(A, lda, n, w, Z, ldz, info);
   return launch_status();

@@ -41,6 +41,10 @@ __global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict_
   extern __shared__ float tf_lds[];
   float *Ss = tf_lds, *Ts = Ss + KB * BT_LD, *taus = Ts + KB * BT_LD;
   const int r = threadIdx.x;
+  // workgroup b factors diagonal block b of the super-block: reflectors a + b KB .., S and T blocks at (b KB, b KB)
+  a += blockIdx.x * KB;
+  S += (int64_t)blockIdx.x * KB * (lds_ + 1);
+  T += (int64_t)blockIdx.x * KB * (ldt + 1);
   for (int idx = r; idx < KB * KB; idx += KB) Ss[(idx / KB) * BT_LD + (idx % KB)] = S[(int64_t)(idx / KB) * lds_ + (idx % KB)];
   taus[r] = (a + r <= jmax) ? tau[a + r] : 0.f;
   __syncthreads();
@@ -110,9 +114,8 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
     st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KS, KS, n, n, n, KS, 1.f, 0.f, false, gws, gws_bytes, stream);
     if (st != VIVIT_OK) return st;
     if (nsub > 1 && hipMemsetAsync(T, 0, sizeof(float) * KS * KS, stream) != hipSuccess) return VIVIT_E_LAUNCH;
-    for (int b = 0; b < nsub; ++b)
-      bt_tfactor_kernel<<<1, KB, BT_TF_LDS, stream>>>(S + (int64_t)b * KB * (KS + 1), KS, tau, (int)jmax, (int)(a + b * KB),
-                                                      T + (int64_t)b * KB * (KS + 1), KS);
+    // block T factors of the nsub diagonal blocks: one workgroup each, one launch
+    bt_tfactor_kernel<<<nsub, KB, BT_TF_LDS, stream>>>(S, KS, tau, (int)jmax, (int)a, T, KS);
     // merge tree: T12 = -T1 S12 T2 for halves of size h = KB, 2 KB, ...
     for (int64_t h = KB; h < KS; h *= 2)
       for (int64_t o = 0; o < KS; o += 2 * h) {

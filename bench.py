@@ -30,6 +30,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+# HBM-side traffic of ONE launch of the dominant kernel (the first layer's Gram SYRK, n = 40960, P = 401408) from
+# separate `rocprofv3 --pmc` passes (profiles/r01_pmc/syrk256_n40960_p401408_*.csv, corrected as the guide
+# prescribes: 2 x FETCH_SIZE KiB + WRITE_SIZE KiB; FETCH_SIZE includes Infinity-Cache hits, so this is an upper
+# bound).  PMC collection cannot run inside this process; the constant is only attached to the exact shape it
+# was measured on.
+SYRK_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * 3695931059.375 + 276639882.25) * 1024.0}
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
 
 WORKLOADS = {
@@ -223,7 +229,8 @@ def main():
             roofline = {
                 "kernel": "gemm256_kernel<LAY_K,LAY_K> (Gram SYRK, fp32 MFMA)",
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_F32_PEAK_TF, "traffic": None,
+                "frac": achieved / MFMA_F32_PEAK_TF,
+                "traffic": SYRK_TRAFFIC_BYTES_PMC.get((args.workload, world)),
                 "launches_sampled": int(syrk_cnt), "avg_launch_ms": syrk_ms / max(syrk_cnt, 1),
                 "est_share_of_step": syrk_total_s / (elapsed / args.steps),
             }

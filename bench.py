@@ -231,6 +231,8 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F32_PEAK_TF,
                 "traffic": SYRK_TRAFFIC_BYTES_PMC.get((args.workload, world)),
+                "traffic_note": "bytes of the first-layer weight's SYRK launch (98.6 % of the Gram flops, 4.73 s), separate "
+                                "rocprofv3 --pmc passes (profiles/r01_pmc), FETCH_SIZE includes Infinity-Cache hits",
                 "launches_sampled": int(syrk_cnt), "avg_launch_ms": syrk_ms / max(syrk_cnt, 1),
                 "est_share_of_step": syrk_total_s / (elapsed / args.steps),
             }

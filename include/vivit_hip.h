@@ -51,7 +51,8 @@ const char *vivit_hip_status_string(int status);
  *   vivit/extensions/secondorder/sqrt_ggn/gram_sqrt_ggn.py:50-52,
  *   vivit/optim/directional_damped_newton.py:254, and the `gram += gram_p` accumulation of
  *   vivit/utils/gram.py:104-116 (beta = 1).
- * Only the lower-triangular 128x128 tiles are computed on MFMA (n(n+1)p flops) and mirrored.
+ * Only the lower-triangular tiles (256x256 for large outputs with a long contraction, 128x128 otherwise) are
+ * computed on MFMA (n(n+1)p flops); the mirror tiles are transposed through LDS and stored as well.
  * ------------------------------------------------------------------------------------------- */
 size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p);
 int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float *G, int64_t ldg,

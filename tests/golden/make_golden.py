@@ -209,6 +209,9 @@ CASES = [
     dict(name="subsampled", seed=3, C=4, N=2, shapes=[(6, 5), (6,)], k=3, N_total=6, N_grad=3),
     dict(name="mc1", seed=4, C=1, N=8, shapes=[(4, 9), (4,), (3, 4)], k=4),
     dict(name="wide", seed=5, C=10, N=6, shapes=[(12, 20), (12,)], k=10),
+    # n = C*N = 320 > 192: the multi-kernel eigensolver (tridiagonalisation + D&C + back-transformation) instead of
+    # the single-workgroup one that serves the reference's own test sizes
+    dict(name="multikernel", seed=6, C=10, N=32, shapes=[(16, 24), (16,)], k=10),
 ]
 
 
@@ -240,6 +243,25 @@ def run_case(vivit, case):
 
     def fresh_params():
         return [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+
+    # --- parameter-list forms: compute_gram_mat, V_mat_prod(concat), sqrt_gram_mat_prod(concat)
+    from vivit.utils.ggn import V_mat_prod
+    from vivit.utils.gram import compute_gram_mat, sqrt_gram_mat_prod
+
+    params = fresh_params()
+    for p_, v in zip(params, V):
+        p_.sqrt_factor = v
+    out["compute_gram_mat"] = compute_gram_mat(params, "sqrt_factor", 2, flatten=True).numpy()
+    out["V_mat_prod_concat"] = V_mat_prod(mat, params, "sqrt_factor", concat=True).numpy()
+    for i, r in enumerate(V_mat_prod(mat, params, "sqrt_factor")):
+        out[f"V_mat_prod{i}"] = r.numpy()
+    sub_idx = [N - 1, 0]  # sub-sampled application: V_t[:, subsampling] (vivit/utils/ggn.py:53-70)
+    out["V_mat_prod_sub0"] = V_mat_prod(mat[:, :, :2].contiguous(), params, "sqrt_factor", subsampling=sub_idx)[0].numpy()
+    cmat = torch.randn(C * N, 3, generator=gen)
+    out["cmat"] = cmat.numpy()
+    out["sqrt_gram_mat_prod_concat"] = sqrt_gram_mat_prod(cmat, params, "sqrt_factor", 2, concat=True).numpy()
+    for i, r in enumerate(sqrt_gram_mat_prod(cmat, params, "sqrt_factor", 2)):
+        out[f"sqrt_gram_mat_prod{i}"] = r.numpy()
 
     # --- EigvalshComputation / EighComputation (closures built from the reference's own utils)
     def attach_vivit(params, savefield):
@@ -319,6 +341,14 @@ def run_case(vivit, case):
         hook = cls()
         hook(FakeModule(params, N_total))
         out[key] = hook.get_result().numpy()
+    from vivit.extensions.hooks import CenteredBatchGrad
+
+    params = fresh_params()
+    attach_sqrt(params)
+    hook = CenteredBatchGrad()
+    hook(FakeModule(params, N_total))
+    for i, p_ in enumerate(params):
+        out[f"centered_grad_batch{i}"] = getattr(p_, hook.savefield).numpy()
     return out
 
 

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["mlp_small", "conv_like", "subsampled", "mc1", "wide"]
+CASES = ["mlp_small", "conv_like", "subsampled", "mc1", "wide", "multikernel"]
 
 
 def load_golden(name):

@@ -22,7 +22,13 @@ from helpers import (
 )
 from vivit_amd import kernels
 from vivit_amd.backend.extensions import _materialised_closures
-from vivit_amd.extensions.hooks import CenteredGramBatchGrad, GramBatchGrad, GramSqrtGGNExact, GramSqrtGGNMC
+from vivit_amd.extensions.hooks import (
+    CenteredBatchGrad,
+    CenteredGramBatchGrad,
+    GramBatchGrad,
+    GramSqrtGGNExact,
+    GramSqrtGGNMC,
+)
 
 FLAVOURS = [pytest.param("host", id="host"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
 
@@ -157,6 +163,98 @@ def test_gram_hooks(case, device):
         hook = cls()
         hook(FakeModule(params, int(g["N_total"])))
         close(hook.get_result(), g[key], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_contractions_and_parameter_list_forms(case, device):
+    """vivit_amd.utils.{gram,ggn} against what the reference's own functions returned (K1, K2, K8, K9):
+    partial_contract / Vmp / mVp on one factor, compute_gram_mat / V_mat_prod / sqrt_gram_mat_prod over the
+    parameter list (vivit/utils/gram.py:72-179,182-203, vivit/utils/ggn.py:11-115)."""
+    from vivit_amd.utils.ggn import V_mat_prod, V_param_mat_prod, Vmp
+    from vivit_amd.utils.gram import compute_gram_mat, mVp, pairwise_dot, partial_contract, sqrt_gram_mat_prod
+
+    g = load_golden(case)
+    V, G = golden_factors(g, device)
+    scale = np.abs(g["gram_flat"]).max()
+    mat = torch.from_numpy(g["mat"]).to(device)
+    pmat = torch.from_numpy(g["pmat"]).to(device)
+    cmat = torch.from_numpy(g["cmat"]).to(device)
+    close(partial_contract(V[0], G[0], (2, 1)), g["V_t_g0"], rtol=1e-5, atol=1e-6 * scale)
+    close(Vmp(V[0], mat, 2), g["Vmp0"], rtol=1e-5, atol=1e-5)
+    close(mVp(V[0], pmat, 2), g["mVp0"], rtol=1e-5, atol=1e-5)
+    close(sum(pairwise_dot(v, start_dim=2) for v in V), g["gram_flat"], rtol=1e-5, atol=1e-6 * scale)
+
+    params = fresh_params(V, device)
+    for p, v in zip(params, V):
+        p.sqrt_factor = v
+    gram = compute_gram_mat(params, "sqrt_factor", 2, flatten=True)
+    assert gram.shape == g["compute_gram_mat"].shape
+    close(gram, g["compute_gram_mat"], rtol=1e-5, atol=1e-6 * scale)
+    C, N = V[0].shape[:2]
+    assert compute_gram_mat(params, "sqrt_factor", 2, flatten=False).shape == (C, N, C, N)
+    for i, r in enumerate(V_mat_prod(mat, params, "sqrt_factor")):
+        assert tuple(r.shape) == g[f"V_mat_prod{i}"].shape
+        close(r, g[f"V_mat_prod{i}"], rtol=1e-5, atol=1e-5)
+    close(V_mat_prod(mat, params, "sqrt_factor", concat=True), g["V_mat_prod_concat"], rtol=1e-5, atol=1e-5)
+    sub = V_param_mat_prod(params[0], mat[:, :, :2].contiguous(), "sqrt_factor", subsampling=[N - 1, 0])
+    close(sub, g["V_mat_prod_sub0"], rtol=1e-5, atol=1e-5)
+    with pytest.raises(AssertionError):
+        V_mat_prod(mat[0], params, "sqrt_factor")
+    for i, r in enumerate(sqrt_gram_mat_prod(cmat, params, "sqrt_factor", 2)):
+        assert tuple(r.shape) == g[f"sqrt_gram_mat_prod{i}"].shape
+        close(r, g[f"sqrt_gram_mat_prod{i}"], rtol=1e-5, atol=1e-5)
+    close(sqrt_gram_mat_prod(cmat, params, "sqrt_factor", 2, concat=True), g["sqrt_gram_mat_prod_concat"],
+          rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_centered_batch_grad(case, device):
+    """CenteredBatchGrad (vivit/extensions/firstorder/batch_grad/gram_batch_grad.py:7-37)."""
+    g = load_golden(case)
+    V, G = golden_factors(g, device)
+    params = fresh_params(V, device)
+    attach_sqrt(params, V, G, "sqrt_ggn_exact")
+    hook = CenteredBatchGrad()
+    hook(FakeModule(params, int(g["N_total"])))
+    for i, p in enumerate(params):
+        close(getattr(p, hook.savefield), g[f"centered_grad_batch{i}"], rtol=1e-5, atol=1e-7)
+
+
+def test_eig_utils(device):
+    """vivit_amd.utils.eig against the reference's vivit/utils/eig.py on the matrices of
+    test/utils/test_stable_symeig.py:10-11 (T2 is NOT symmetric: ``upper=True`` must read its upper triangle)."""
+    from vivit_amd.utils.eig import remove_zero_evals, shift_diag, symeig, symeig_psd
+
+    g = load_golden("eig_utils")
+    for name in ["T1", "T2", "T3"]:
+        T = torch.from_numpy(g[name]).to(device)
+        for shift in [0.0, 0.1, 1.0, 10.0]:
+            for inplace in [False, True]:
+                inp = T.clone()
+                w, v = symeig_psd(inp, eigenvectors=True, shift=shift, shift_inplace=inplace)
+                close(w, g[f"{name}_psd_w_{shift}"], rtol=1e-5, atol=1e-5)
+                # the input is never destroyed; an in-place shift is taken back (test_stable_symeig.py:48-74)
+                close(inp, g[name], rtol=1e-6, atol=1e-6)
+                assert v.shape == T.shape
+            w_only, empty = symeig_psd(T.clone(), eigenvectors=False, shift=shift)
+            close(w_only, g[f"{name}_psd_w_{shift}"], rtol=1e-5, atol=1e-5)
+            assert empty.numel() == 0
+        w, v = symeig(T.clone(), eigenvectors=True)
+        close(w, g[f"{name}_symeig_w"], rtol=1e-5, atol=1e-6)
+        assert (v.shape[1] if v.numel() else 0) == int(g[f"{name}_symeig_nvec"])
+    # eigenvectors of the symmetric cases: T v = w v with the upper triangle as the matrix
+    T3 = torch.from_numpy(g["T3"]).to(device)
+    w, v = symeig_psd(T3.clone(), eigenvectors=True)
+    close(T3 @ v, (v * w).cpu().numpy(), rtol=1e-4, atol=1e-5)
+    w, v = remove_zero_evals(w, v, atol=1e-4)  # rank 3 of 6
+    assert w.numel() == 3 and v.shape == (6, 3)
+    inp = torch.tensor([[1.0, 1.0], [2.0, 2.0], [3.0, 4.0]], device=device)
+    close(shift_diag(inp, 0.1), g["shift_nonsquare"])  # non-square input (test_stable_symeig.py:104-121)
+    assert shift_diag(inp, 0.0) is inp
+    with pytest.raises(ValueError):
+        symeig_psd(torch.zeros(2, 2, 2, device=device))
+    with pytest.raises(ValueError):
+        symeig(torch.zeros(4, device=device))
 
 
 def test_error_conventions(device):

@@ -47,10 +47,21 @@ def make_problem(name):
         bn.bias.data.uniform_(-0.5, 0.5)
         model = nn.Sequential(nn.Linear(7, 6), bn, nn.ReLU(), nn.Linear(6, 3)).eval()
         X, y, lossf, loss = torch.rand(5, 7), torch.randint(0, 3, (5,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "linear_extra_mse":  # test/settings.py:67-96 analogue: nn.Linear with additional input dims
+        model = nn.Sequential(nn.Linear(5, 3), nn.Sigmoid(), nn.Linear(3, 2), nn.Tanh(), nn.Flatten())
+        X, y, lossf, loss = torch.rand(3, 4, 5), torch.rand(3, 8), nn.MSELoss(), "mse"
+    elif name == "bn2d_ce":  # test/settings.py:127-134 analogue
+        bn = nn.BatchNorm2d(2)
+        bn.running_mean.uniform_(-0.5, 0.5)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.uniform_(-0.5, 0.5)
+        model = nn.Sequential(bn, nn.Flatten(), nn.Linear(24, 3)).eval()
+        X, y, lossf, loss = torch.rand(3, 2, 4, 3), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
     return model, X, y, lossf, loss
 
 
-PROBLEMS = ["mlp_ce", "mlp_mse", "cnn_ce", "bn_ce"]
+PROBLEMS = ["mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce"]
 
 
 def run_backward(model, X, y, lossf, extensions, hook=None):
@@ -160,7 +171,9 @@ def test_eigvalsh_and_eigh_end_to_end(problem, subsampling, groups_kind, device)
         np.testing.assert_allclose(w[-k:].numpy(), ref_w[-k:].numpy(), rtol=1e-4, atol=5e-6)
 
     comp = vivit_amd.EighComputation(subsampling=subsampling, warn_small_eigvals=0.0)
-    crit = lambda evals: [i for i in range(evals.numel()) if evals[i].abs() >= 1e-4]  # keep_nonzero
+    # keep_nonzero (test/linalg/settings.py:35-44); directions with eigenvalues next to the 1e-4 threshold are
+    # ill-conditioned in fp32 (the back-projection divides by sqrt(lambda)), hence the relative floor as well
+    crit = lambda evals: [i for i in range(evals.numel()) if evals[i].abs() >= max(1e-4, 1e-3 * float(evals[-1]))]
     groups = [{"params": [params[i] for i in idx], "criterion": crit} for idx in index_groups]
     run_backward(model, X, y, lossf, [comp.get_extension()], comp.get_extension_hook(groups))
     for idx, grp in zip(index_groups, groups):
@@ -220,3 +233,32 @@ def test_damped_newton_end_to_end(problem, sub_grad, sub_ggn, mc, device):
     close(gam.abs(), ref_gam.abs(), rtol=1e-3, atol=1e-4 * ref_gam.abs().max().item())
     close(lam, ref_lam, rtol=1e-3, atol=1e-5 * ref_lam.abs().max().item())
     # lambdas.mean(0) == evals (docs/examples/basic_usage/example_directional_derivatives.py:192-199)
+
+
+@pytest.mark.parametrize("problem", ["mlp_ce", "cnn_ce", "bn2d_ce"])
+def test_eigvalsh_mc_with_supplied_samples(problem, device):
+    """``EigvalshComputation(mc_samples=M)`` -> ``ViViTGGNMC``: the Gram spectrum equals the spectrum of the MC-GGN
+    built from the SAME samples (test/extensions/secondorder/sqrt_ggn/test_gram_sqrt_ggn.py:42-56 re-seeds to get
+    identical samples; here they are handed to the extension)."""
+    model, X, y, lossf, loss = make_problem(problem)
+    ref_model = make_problem(problem)[0]
+    out = ref_model(X).detach()
+    N, C = out.shape
+    M = 2
+    gen = torch.Generator().manual_seed(11)
+    idx = torch.multinomial(out.softmax(1), M, replacement=True, generator=gen)
+    onehots = torch.nn.functional.one_hot(idx.t(), C).float()
+    V_ref = oracle.sqrt_ggn_factors(ref_model.double(), X.double(), oracle.loss_hessian_sqrt_mc(out.double(), onehots.double()))
+    Vflat = torch.cat([v.flatten(2) for v in V_ref], dim=2).flatten(0, 1)  # [M N, P]
+    ref_w = torch.linalg.eigvalsh(Vflat @ Vflat.T)
+
+    model, X, y = model.to(device), X.to(device), y.to(device)
+    comp = vivit_amd.EigvalshComputation(mc_samples=M)
+    ext = comp.get_extension()
+    assert ext.savefield == "vivit_ggn_mc" and ext.get_num_mc_samples() == M
+    ext._samples = onehots
+    group = {"params": list(model.parameters())}
+    run_backward(model, X, y, lossf, [ext], comp.get_extension_hook([group]))
+    w = comp.get_result(group).cpu().double()
+    assert w.numel() == M * N
+    np.testing.assert_allclose(w.numpy(), ref_w.numpy(), rtol=1e-4, atol=1e-5 * ref_w.abs().max().item())

@@ -186,10 +186,13 @@ int vivit_row_sqnorm_acc_f32(const float *X, float *acc, int64_t K, int64_t len,
   const int nchunk = (int)cdiv(len, SQN_CHUNK);
   const size_t need = (size_t)K * nchunk * sizeof(float);
   if (!workspace || workspace_bytes < need) return VIVIT_E_WORKSPACE;
-  if (K > 65535) return VIVIT_E_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float *part = static_cast<float *>(workspace);
-  row_sqnorm_part_kernel<<<dim3((unsigned)nchunk, (unsigned)K), EW_BLOCK, 0, s>>>(X, part, len, nchunk);
+  for (int64_t k0 = 0; k0 < K; k0 += 65535) {  // grid.y is limited to 65535 rows per launch
+    const int64_t kc = (K - k0 < 65535) ? K - k0 : 65535;
+    row_sqnorm_part_kernel<<<dim3((unsigned)nchunk, (unsigned)kc), EW_BLOCK, 0, s>>>(X + k0 * len, part + k0 * nchunk, len,
+                                                                                    nchunk);
+  }
   row_sqnorm_final_kernel<<<(unsigned)cdiv(K, EW_BLOCK), EW_BLOCK, 0, s>>>(part, acc, K, nchunk);
   return launch_status();
 }

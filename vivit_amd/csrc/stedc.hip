@@ -643,9 +643,11 @@ __global__ __launch_bounds__(256) void dc_gather_rows_kernel(int n, const float 
 int dc_rows_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *w, float *Zs,
                    int64_t ldz, int64_t r0, int64_t r1, const float *scal, hipStream_t stream) {
   dc_final_rank_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>((int)n, dcur, order, w, scal);
-  if (r1 > r0)
-    dc_gather_rows_kernel<<<dim3((unsigned)(cdiv(n, 1024) < 64 ? cdiv(n, 1024) : 64), (unsigned)(r1 - r0)), 256, 0, stream>>>(
-        (int)n, Qt, ldq, order, (int)r0, Zs, ldz);
+  for (int64_t r = r0; r < r1; r += 65535) {  // grid.y is limited to 65535 rows per launch
+    const int64_t rc = (r1 - r < 65535) ? r1 - r : 65535;
+    dc_gather_rows_kernel<<<dim3((unsigned)(cdiv(n, 1024) < 64 ? cdiv(n, 1024) : 64), (unsigned)rc), 256, 0, stream>>>(
+        (int)n, Qt, ldq, order, (int)r, Zs + (r - r0) * ldz, ldz);
+  }
   return launch_status();
 }
 

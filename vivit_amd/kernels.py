@@ -5,6 +5,7 @@ gfx950 kernels behind the C ABI of ``include/vivit_hip.h``.  Every function rais
 ``RuntimeError`` for tensors that are not fp32 HIP-device tensors: there is deliberately no CPU
 path (tests inject the oracle through :func:`vivit_amd.kernels.set_backend_for_testing`).
 """
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -26,6 +27,7 @@ def set_backend_for_testing(backend):
 
 
 def _require_device(*tensors):
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -35,6 +37,55 @@ def _require_device(*tensors):
             )
         if t.dtype != torch.float32:
             raise RuntimeError(f"vivit_amd kernels are fp32 only (got {t.dtype})")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"all operands must live on one device (got {dev} and {t.device})")
+
+
+def _first_device(args, kwargs):
+    for a in list(args) + list(kwargs.values()):
+        if isinstance(a, torch.Tensor):
+            return a.device if a.is_cuda else None
+        if isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor):
+            return a[0].device if a[0].is_cuda else None
+    return None
+
+
+def _launcher(fn):
+    """Run ``fn`` with the HIP device of its first tensor operand current.
+
+    The C side launches on the *current* device (``<<<>>>`` on the given stream, the dynamic-LDS attribute bitmap is
+    keyed on ``hipGetDevice``), so a process that drives several GPUs must switch before every call -- torch ops do
+    that implicitly, a raw ctypes call does not."""
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None if _TEST_BACKEND is not None else _first_device(args, kwargs)
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+
+    return wrapped
+
+
+def _check_out(out, m, n, *operands):
+    """``out`` is written by the kernel with a single leading dimension: shape, strides and aliasing must be right,
+    otherwise the launch would write out of bounds or into an operand it is still reading."""
+    if out is None:
+        return
+    if tuple(out.shape) != (m, n):
+        raise ValueError(f"out must have shape {(m, n)}, got {tuple(out.shape)}")
+    if out.numel() > 0 and (out.stride(1) != 1 or (m > 1 and out.stride(0) < n)):
+        raise ValueError(f"out must be row-major with unit column stride (strides {out.stride()})")
+    for t in operands:
+        if t is not None and t.numel() > 0 and out.numel() > 0 and t.untyped_storage().data_ptr() == out.untyped_storage().data_ptr():
+            lo, hi = out.data_ptr(), out.data_ptr() + 4 * ((m - 1) * out.stride(0) + n)
+            tlo = t.data_ptr()
+            thi = tlo + 4 * (sum((sz - 1) * st for sz, st in zip(t.shape, t.stride())) + 1)
+            if tlo < hi and lo < thi:
+                raise ValueError("out must not alias an input operand")
 
 
 def _stream(t):
@@ -67,6 +118,7 @@ def _ld(t):
     return max(t.stride(0), t.shape[1], 1) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
+@_launcher
 def gram_syrk(A: torch.Tensor, out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0):
     """``out = alpha * A @ A.T + beta * out`` for ``A: [n, p]`` (K1, MFMA SYRK)."""
     if _TEST_BACKEND is not None:
@@ -74,6 +126,7 @@ def gram_syrk(A: torch.Tensor, out: Optional[torch.Tensor] = None, alpha: float 
     _require_device(A, out)
     A = _as2d(A)
     n, p = A.shape
+    _check_out(out, n, n, A)
     if out is None:
         out = torch.empty((n, n), dtype=torch.float32, device=A.device)
         beta = 0.0
@@ -86,6 +139,7 @@ def gram_syrk(A: torch.Tensor, out: Optional[torch.Tensor] = None, alpha: float 
 
 def _gemm(name, A, B, m, n, k, out, alpha, beta):
     lib = _lib.load()
+    _check_out(out, m, n, A, B)
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=A.device)
         beta = 0.0
@@ -97,6 +151,7 @@ def _gemm(name, A, B, m, n, k, out, alpha, beta):
     return out
 
 
+@_launcher
 def gemm_nt(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out = alpha * A @ B.T + beta * out``; ``A: [m, k]``, ``B: [n, k]`` (K2/K9)."""
     if _TEST_BACKEND is not None:
@@ -108,6 +163,7 @@ def gemm_nt(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     return _gemm("vivit_gemm_nt_f32", A, B, A.shape[0], B.shape[0], A.shape[1], out, alpha, beta)
 
 
+@_launcher
 def gemm_nn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out = alpha * A @ B + beta * out``; ``A: [m, k]``, ``B: [k, n]`` (K6/K7/K8)."""
     if _TEST_BACKEND is not None:
@@ -119,6 +175,7 @@ def gemm_nn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     return _gemm("vivit_gemm_nn_f32", A, B, A.shape[0], B.shape[1], A.shape[1], out, alpha, beta)
 
 
+@_launcher
 def gemm_tn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out = alpha * A.T @ B + beta * out``; ``A: [k, m]``, ``B: [k, n]`` (K5)."""
     if _TEST_BACKEND is not None:
@@ -130,6 +187,7 @@ def gemm_tn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     return _gemm("vivit_gemm_tn_f32", A, B, A.shape[1], B.shape[1], A.shape[0], out, alpha, beta)
 
 
+@_launcher
 def gram_hadamard(Gz, Gs, C: int, N: int, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out[c,n,d,m] = alpha * Gz[n,m] * Gs[c,n,d,m] + beta * out`` (K1')."""
     if _TEST_BACKEND is not None:
@@ -139,18 +197,25 @@ def gram_hadamard(Gz, Gs, C: int, N: int, out=None, alpha: float = 1.0, beta: fl
     if out is None:
         out = torch.empty((C * N, C * N), dtype=torch.float32, device=Gz.device)
         beta = 0.0
-    if not out.is_contiguous():
-        raise ValueError("out must be contiguous")
+    if not out.is_contiguous() or tuple(out.shape) != (C * N, C * N):
+        raise ValueError(f"out must be a contiguous [{C * N}, {C * N}] matrix")
+    if tuple(Gz.shape) != (N, N) or Gs.numel() != (C * N) ** 2:
+        raise ValueError("Gz must be [N, N] and Gs [C*N, C*N]")
     st = _lib.load().vivit_gram_hadamard_f32(Gz.data_ptr(), Gs.data_ptr(), out.data_ptr(), C, N, alpha, beta, _stream(Gz))
     _lib.check(st, "vivit_gram_hadamard_f32")
     return out
 
 
-def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+@_launcher
+def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False, info_out: Optional[list] = None
+           ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Eigenvalues (ascending) and, optionally, column eigenvectors of symmetric ``G`` (K3/K4).
 
     Raises ``RuntimeError`` if the solver reports unconverged eigenvalues (the reference's
-    behaviour for a failing ``Tensor.symeig``, vivit/utils/eig.py:37-40).
+    behaviour for a failing ``Tensor.symeig``, vivit/utils/eig.py:37-40).  That check reads the device-side
+    ``info`` word, i.e. synchronises with the stream; a caller that wants to stay asynchronous passes a list as
+    ``info_out``: the ``info`` tensor is appended to it instead and nothing is read back (check it with
+    :func:`check_info` when convenient).
     """
     if _TEST_BACKEND is not None:
         return _TEST_BACKEND.symeig(G, eigenvectors)
@@ -170,15 +235,24 @@ def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False)
         A.data_ptr(), n, _ld(A), w.data_ptr(), Z.data_ptr() if eigenvectors else None, n, ws, wsb, info.data_ptr(), _stream(G)
     )
     _lib.check(st, "vivit_symeig_f32")
-    nfail = int(info.item())  # device->host sync; the reference syncs here too (criterion callback)
+    if info_out is not None:
+        info_out.append(info)
+    else:
+        check_info(info)  # device->host sync; the reference syncs here too (criterion callback)
+    return w, Z
+
+
+def check_info(info: torch.Tensor):
+    """Map the eigensolver's device-side status word to the reference's RuntimeError (synchronises)."""
+    nfail = int(info.item())
     if nfail != 0:
         raise RuntimeError(f"symeig: {nfail} eigenvalues did not converge")
-    return w, Z
 
 
 SYMEIG_ROWS_MIN_N = 193  # below: single-workgroup solver, no row-range entry point
 
 
+@_launcher
 def symeig_rows(G: torch.Tensor, row_begin: int, row_end: int, overwrite: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """All eigenvalues (ascending) of symmetric ``G`` and the eigenvectors ``row_begin .. row_end-1`` as ROWS
     ``[row_end - row_begin, n]`` (``vivit_symeig_rows_f32``): the unit of work of one rank in the multi-GPU
@@ -213,6 +287,7 @@ def symeig_rows(G: torch.Tensor, row_begin: int, row_end: int, overwrite: bool =
     return w, Zt[: row_end - row_begin]
 
 
+@_launcher
 def stedc(d: torch.Tensor, e: torch.Tensor, eigenvectors: bool = False):
     """Eigen-decomposition of the symmetric tridiagonal (d, e) -- stage 2 of ``symeig`` (testing)."""
     _require_device(d, e)
@@ -232,6 +307,7 @@ def stedc(d: torch.Tensor, e: torch.Tensor, eigenvectors: bool = False):
     return w, Z
 
 
+@_launcher
 def sytrd(G: torch.Tensor):
     """Householder tridiagonalisation -- stage 1 of ``symeig`` (testing).
     Returns ``(d, e, tau, A)`` with the reflectors in the upper triangle of ``A``."""
@@ -248,6 +324,7 @@ def sytrd(G: torch.Tensor):
     return d, e, tau, A
 
 
+@_launcher
 def sy2sb(G: torch.Tensor):
     """Full symmetric -> band (testing). Returns ``(AB, tau1, A)``: band in row-band layout, reflector
     scalars, and the overwritten matrix (band + reflector rows)."""
@@ -264,6 +341,7 @@ def sy2sb(G: torch.Tensor):
     return AB, tau1, A
 
 
+@_launcher
 def sb2st(AB: torch.Tensor):
     """Band -> tridiagonal by bulge chasing (testing). ``AB``: [n, 2*NB+1] row-band layout.
     Returns ``(d, e, R2, tau2)``."""
@@ -286,6 +364,7 @@ def sb2st(AB: torch.Tensor):
     return d, e[: n - 1], R2, tau2
 
 
+@_launcher
 def dir_curvature(GE, evals, C: int, N: int, scale: float):
     """``lambdas[n,k] = scale * sum_c GE[(c,n),k]^2 / evals[k]`` (K6 epilogue)."""
     if _TEST_BACKEND is not None:
@@ -299,6 +378,7 @@ def dir_curvature(GE, evals, C: int, N: int, scale: float):
     return out
 
 
+@_launcher
 def scale_cols_rsqrt_(X, evals, pre: float = 1.0):
     """In place ``X[:, k] *= pre / sqrt(evals[k])`` (K5 epilogue)."""
     if _TEST_BACKEND is not None:
@@ -312,6 +392,7 @@ def scale_cols_rsqrt_(X, evals, pre: float = 1.0):
     return X
 
 
+@_launcher
 def normalize_rows_(tensors):
     """Normalise ``K`` stacked vectors given in parameter-list format, in place (K10).
 

@@ -34,7 +34,7 @@ class EighComputation:
         mc_samples: int = 0,
         verbose: bool = False,
         warn_small_eigvals: float = 1e-4,
-        side: str = "auto",
+        side: str = "gram",
     ):
         """``side`` (not in the reference): ``"auto"`` solves a group on its parameter side (``P x P``, eigenvectors
         directly in parameter space) when it has fewer parameters than Gram rows; ``"gram"`` = reference path."""
@@ -114,7 +114,7 @@ class EighComputation:
                 # P x P block of the GGN: its eigenvectors are the parameter-space eigenvectors themselves
                 import torch
 
-                all_evals, Q, n_zero = parameter_side_symeig(group["params"], savefield, eigenvectors=True)
+                all_evals, Q, cols = parameter_side_symeig(group["params"], savefield, eigenvectors=True)
                 if subsampling is not None:
                     all_evals *= batch_size / len(subsampling)
                 keep = group["criterion"](all_evals)
@@ -122,11 +122,13 @@ class EighComputation:
                 kept_evals = all_evals[keep_t]
                 if (kept_evals.abs() < warn_small_eigvals).any():
                     warn(small_warning)
-                # indices below n_zero address the Gram matrix' exact zeros: no GGN eigenvector belongs to them
+                # padded zeros (cols == -1) address the Gram matrix' exact null space: no GGN eigenvector belongs
+                # to them, their rows stay zero (the reference returns a normalised noise vector there)
                 vecs = torch.zeros((len(keep), Q.shape[0]), dtype=Q.dtype, device=Q.device)
-                valid = keep_t >= n_zero
+                kept_cols = cols[keep_t]
+                valid = kept_cols >= 0
                 if bool(valid.any()):
-                    vecs[valid] = Q[:, keep_t[valid] - n_zero].T
+                    vecs[valid] = Q[:, kept_cols[valid]].T
                 group_evecs, off = [], 0
                 for param in group["params"]:
                     numel = param.numel()

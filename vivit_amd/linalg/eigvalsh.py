@@ -27,7 +27,7 @@ class EigvalshComputation:
     in place into the group's ``[n, n]`` Gram (beta = 1), then one values-only ``symeig``.
     """
 
-    def __init__(self, subsampling: List[int] = None, mc_samples: int = 0, verbose: bool = False, side: str = "auto"):
+    def __init__(self, subsampling: List[int] = None, mc_samples: int = 0, verbose: bool = False, side: str = "gram"):
         """``side`` (not in the reference): ``"auto"`` solves a group on its parameter side (``P x P``) when it has
         fewer parameters than Gram rows, ``"gram"`` always decomposes the Gram matrix like the reference."""
         check_subsampling_unique(subsampling)

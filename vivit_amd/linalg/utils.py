@@ -65,10 +65,12 @@ def use_parameter_side(params, n: int, side: str) -> bool:
 def parameter_side_symeig(params, savefield: str, eigenvectors: bool):
     """Eigen-decomposition of the group's ``P x P`` GGN block ``H = V^T V``, padded to the Gram spectrum.
 
-    Returns ``(evals [n] ascending, Q [P, P] or None, n - P_eff)``: the first ``n - P`` entries of ``evals``
-    are the exact zeros the (rank-deficient) Gram matrix has in their place; ``Q[:, i]`` is the unit
-    parameter-space eigenvector of ``evals[n - P + i]`` (concatenated over ``params`` in order).
-    If ``P >= n`` the top ``n`` eigenvalues are returned (the remaining ``P - n`` are zero up to rounding).
+    Returns ``(evals [n] ascending, Q [P, P] or None, cols [n])``: ``n - P`` entries of ``evals`` are the exact
+    zeros the (rank-deficient) Gram matrix has in their place -- inserted where they belong in the ascending order,
+    i.e. after any negative rounding noise of ``H``'s own spectrum; ``cols[i]`` is the column of ``Q`` holding the
+    unit parameter-space eigenvector of ``evals[i]`` (concatenated over ``params`` in order) or ``-1`` for a padded
+    zero, which has no GGN eigenvector.  If ``P >= n`` the top ``n`` eigenvalues are returned (the remaining
+    ``P - n`` are zero up to rounding).
     """
     import torch
 
@@ -83,9 +85,17 @@ def parameter_side_symeig(params, savefield: str, eigenvectors: bool):
     H = kernels.gemm_tn(Vcat, Vcat)                                 # [P, P] = V^T V, contraction over the n rows
     w, Q = kernels.symeig(H, eigenvectors=eigenvectors, overwrite=True)
     if P >= n:
-        return w[P - n:], (Q[:, P - n:] if eigenvectors else None), 0
-    evals = torch.cat([torch.zeros(n - P, dtype=w.dtype, device=w.device), w])
-    return evals, Q, n - P
+        cols = torch.arange(P - n, P, device=w.device)
+        return w[P - n:], (Q if eigenvectors else None), cols
+    neg = int((w < 0).sum().item())  # rounding noise below zero sorts in front of the exact zeros
+    zeros = torch.zeros(n - P, dtype=w.dtype, device=w.device)
+    evals = torch.cat([w[:neg], zeros, w[neg:]])
+    cols = torch.cat([
+        torch.arange(neg, device=w.device),
+        torch.full((n - P,), -1, dtype=torch.long, device=w.device),
+        torch.arange(neg, P, device=w.device),
+    ])
+    return evals, Q, cols
 
 
 def get_hook_store_batch_size(

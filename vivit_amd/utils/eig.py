@@ -11,8 +11,10 @@ from vivit_amd import kernels
 def _device_symeig(mat, eigenvectors, upper):
     # The kernel reads the lower triangle; ``upper=True`` (the old default) reads the upper one,
     # i.e. the lower triangle of the transpose.
+    # The solver destroys its input, the reference never mutates the caller's matrix: always work on a private
+    # row-major copy (``.contiguous()`` alone would alias a column-major input such as ``G.T``).
     src = mat.detach()
-    work = src.t().contiguous() if upper else src.clone()
+    work = (src.t() if upper else src).clone(memory_format=torch.contiguous_format)
     evals, evecs = kernels.symeig(work, eigenvectors=eigenvectors, overwrite=True)
     if evecs is None:
         evecs = mat.new_empty(0)

@@ -93,6 +93,26 @@ int vivit_gemm_tn_f32(const float *A, const float *B, float *C, int64_t m, int64
 int vivit_gram_hadamard_f32(const float *Gz, const float *Gs, float *G, int64_t C, int64_t N,
                             float alpha, float beta, void *stream);
 
+/* Rectangular block of the same product: rows (c, n) with c < Cr, n < Nr; columns (d, m) with d < Cc, m < Nc:
+ *   G[(c,n), (d,m)] = alpha * Gz[n, m] * Gs[(c,n), (d,m)] + beta * G[(c,n), (d,m)]
+ *   Gz: [Nr, Nc], Gs: [Cr*Nr, Cc*Nc] contiguous; G: [Cr*Nr, Cc*Nc] with leading dimension ldg.
+ * Used for (i) the block row G[N_g, :] of a batch shard in the data-parallel Gram build (Nr = local samples,
+ * Nc = all samples; the reference has no multi-device code: SURVEY.md 8e) and (ii) V^T g of a factorised Linear
+ * weight, einsum("cno,ni,mo,mi->cnm"): the factorised form of partial_contract(V, g, (2, 1))
+ * vivit/optim/directional_damped_newton.py:255 with V as in linear.py:41-42 (Cc = 1). */
+int vivit_gram_hadamard_block_f32(const float *Gz, const float *Gs, float *G, int64_t Cr, int64_t Nr, int64_t Cc,
+                                  int64_t Nc, int64_t ldg, float alpha, float beta, void *stream);
+
+/* Length-C contractions of the factorised Linear products (the MFMA GEMM with z does the rest):
+ *   vivit_class_contract_f32:  T[f, o, n] = sum_c mat[f, c, n] * s[c, n, o]      mat: [F,C,N], s: [C,N,O], T: [F,O,N]
+ *     first half of einsum("cno,vcn,ni->voi")  vivit/extensions/secondorder/vivit/linear.py:53
+ *   vivit_class_expand_f32:    R[f, c, n] = sum_o s[c, n, o] * U[f, o, n]        U: [F,O,N], R: [F,C,N]
+ *     second half of einsum("cno,voi,ni->vcn")  vivit/extensions/secondorder/vivit/linear.py:64 */
+int vivit_class_contract_f32(const float *mat, const float *s, float *T, int64_t F, int64_t C, int64_t N, int64_t O,
+                             void *stream);
+int vivit_class_expand_f32(const float *s, const float *U, float *R, int64_t F, int64_t C, int64_t N, int64_t O,
+                           void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K3/K4  Symmetric eigendecomposition (Householder tridiagonalisation + implicit-shift QL,
  * divide-and-conquer merges above the single-workgroup size).
@@ -185,6 +205,13 @@ int vivit_scale_rows_rsqrt_f32(float *X, const float *acc, int64_t K, int64_t le
  * symv algorithmic bytes 4*m(m+1)/2}.  Not thread-safe; leave off in production. */
 int vivit_profile_begin(int symv_stride);
 int vivit_profile_end(double *out);
+/* Per-stage time of the vivit_symeig*_f32 calls issued since vivit_profile_begin (HIP events at the stage
+ * boundaries, on the launch stream), summed over calls, in ms.  out_ms[k], k < num (host pointer):
+ *   1 prescale + mirror, 2 full -> band (sy2sb), 3 band -> tridiagonal (sb2st), 4 tridiagonal eigenproblem
+ *   (divide & conquer | Sturm multisection | inverse iteration), 5 back-transformation Q2, 6 back-transformation
+ *   Q1 / Q, 7 sort + transpose into the output, 8 one-stage tridiagonalisation (sytrd).  Synchronises on the
+ *   recorded events and clears them; call before vivit_profile_end or after, once. */
+int vivit_profile_stages(double *out_ms, int num);
 
 /* Mirror the lower triangle of G into the upper triangle (G[i][j] = G[j][i], i < j). */
 int vivit_symmetrize_lower_f32(float *G, int64_t n, int64_t ldg, void *stream);

@@ -88,6 +88,16 @@ class OracleBackend:
         res = (Gz.view(1, N, 1, N) * Gs.view(C, N, C, N)).reshape(C * N, C * N)
         return self._acc(res, out, alpha, beta)
 
+    def gram_hadamard_block(self, Gz, Gs, Cr, Nr, Cc, Nc, out=None, alpha=1.0, beta=0.0):
+        res = (Gz.view(1, Nr, 1, Nc) * Gs.reshape(Cr, Nr, Cc, Nc)).reshape(Cr * Nr, Cc * Nc)
+        return self._acc(res, out, alpha, beta)
+
+    def class_contract(self, mat, s):
+        return torch.einsum("vcn,cno->von", mat, s).contiguous()
+
+    def class_expand(self, s, U):
+        return torch.einsum("cno,von->vcn", s, U).contiguous()
+
     def symeig(self, G, eigenvectors=False, overwrite=False):
         from oracle import vivit_oracle as oracle
 

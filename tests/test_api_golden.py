@@ -240,7 +240,8 @@ def test_eig_utils(device):
             close(w_only, g[f"{name}_psd_w_{shift}"], rtol=1e-5, atol=1e-5)
             assert empty.numel() == 0
         w, v = symeig(T.clone(), eigenvectors=True)
-        close(w, g[f"{name}_symeig_w"], rtol=1e-5, atol=1e-6)
+        # fp32 rounding noise of the null space is ~1e-7 * lambda_max: absolute floor scaled like test_eigvalsh.py:55-60
+        close(w, g[f"{name}_symeig_w"], rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(g[f"{name}_symeig_w"]).max())))
         assert (v.shape[1] if v.numel() else 0) == int(g[f"{name}_symeig_nvec"])
     # eigenvectors of the symmetric cases: T v = w v with the upper triangle as the matrix
     T3 = torch.from_numpy(g["T3"]).to(device)

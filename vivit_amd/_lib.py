@@ -28,6 +28,9 @@ SIGNATURES = {
     "vivit_gemm_nn_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _ptr, _sz, _ptr]),
     "vivit_gemm_tn_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _ptr, _sz, _ptr]),
     "vivit_gram_hadamard_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _f32, _f32, _ptr]),
+    "vivit_gram_hadamard_block_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _ptr]),
+    "vivit_class_contract_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
+    "vivit_class_expand_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
     "vivit_symeig_f32_workspace_bytes": (_sz, [_i64, _int]),
     "vivit_symeig_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
     "vivit_symeig_rows_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr, _sz, _ptr, _ptr]),
@@ -47,6 +50,7 @@ SIGNATURES = {
     "vivit_scale_rows_rsqrt_f32": (_int, [_ptr, _ptr, _i64, _i64, _ptr]),
     "vivit_profile_begin": (_int, [_int]),
     "vivit_profile_end": (_int, [ctypes.POINTER(ctypes.c_double)]),
+    "vivit_profile_stages": (_int, [ctypes.POINTER(ctypes.c_double), _int]),
     "vivit_symmetrize_lower_f32": (_int, [_ptr, _i64, _i64, _ptr]),
 }
 

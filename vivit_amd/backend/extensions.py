@@ -239,13 +239,13 @@ def _linear_weight_closures(s: Tensor, z: Tensor):
 
     def V_mat_prod(mat):  # [F, C, N] -> [F, O, I]     "cno,vcn,ni->voi"
         Fdim = mat.shape[0]
-        T = torch.einsum("vcn,cno->von", mat, s).reshape(Fdim * O, N)
+        T = kernels.class_contract(mat, s).view(Fdim * O, N)
         return kernels.gemm_nn(T, z).view(Fdim, O, z.shape[1])
 
     def V_t_mat_prod(mat):  # [F, O, I] -> [F, C, N]   "cno,voi,ni->vcn"
         Fdim = mat.shape[0]
         U = kernels.gemm_nt(mat.reshape(Fdim * O, -1), z).view(Fdim, O, N)
-        return torch.einsum("cno,von->vcn", s, U)
+        return kernels.class_expand(s, U)
 
     def factor():  # the explicit V_t[c,n,o,i] = s[c,n,o] z[n,i]; only asked for when O*I is small
         return torch.einsum("cno,ni->cnoi", s, z)

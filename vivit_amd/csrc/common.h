@@ -86,5 +86,9 @@ bool prof_enabled();
 int prof_stride();
 void prof_begin(int kind, double work, hipStream_t stream);
 void prof_end(int kind, hipStream_t stream);
+// stage marks of the eigensolver (vivit_profile_stages): indices of out_ms
+enum { PROF_STAGE_BEGIN = 0, PROF_STAGE_PREP = 1, PROF_STAGE_SY2SB = 2, PROF_STAGE_SB2ST = 3, PROF_STAGE_TRIDIAG = 4,
+       PROF_STAGE_Q2 = 5, PROF_STAGE_Q1 = 6, PROF_STAGE_OUTPUT = 7, PROF_STAGE_SYTRD = 8, PROF_NUM_STAGES = 9 };
+void prof_mark(int stage, hipStream_t stream);
 
 } // namespace vivit

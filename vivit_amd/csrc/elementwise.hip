@@ -41,6 +41,65 @@ __global__ __launch_bounds__(EW_BLOCK) void hadamard_kernel(const float *__restr
   }
 }
 
+// Rectangular block of a factorised product: rows (c, nn) with c < Cr, nn < Nr, columns (d, mm) with d < Cc, mm < Nc:
+//   G[(c,nn), (d,mm)] = alpha * Gz[nn, mm] * Gs[(c,nn), (d,mm)] + beta * G[...]      (G: ldg, Gs / Gz contiguous)
+// Serves the block row of a batch shard (Nr = local samples, Nc = all samples) and V^T g of a factorised
+// Linear weight (Cc = 1: the per-sample gradient has no class axis).
+template <bool VEC>
+__global__ __launch_bounds__(EW_BLOCK) void hadamard_block_kernel(const float *__restrict__ Gz, const float *__restrict__ Gs,
+                                                                  float *__restrict__ G, int64_t Cr, int64_t Nr, int64_t Cc,
+                                                                  int64_t Nc, int64_t ldg, float alpha, float beta) {
+  const int64_t rows = Cr * Nr, cols = Cc * Nc;
+  const int64_t total = VEC ? (rows * cols) >> 2 : rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t flat = VEC ? idx << 2 : idx;
+    const int64_t row = flat / cols, col = flat - row * cols;
+    const int64_t nn = row % Nr, mm = col % Nc;
+    float *g = G + row * ldg + col;
+    if (VEC) {
+      const float4 z = *reinterpret_cast<const float4 *>(Gz + nn * Nc + mm);
+      const float4 sv = *reinterpret_cast<const float4 *>(Gs + flat);
+      float4 o = make_float4(alpha * z.x * sv.x, alpha * z.y * sv.y, alpha * z.z * sv.z, alpha * z.w * sv.w);
+      if (beta != 0.f) {
+        const float4 old = *reinterpret_cast<const float4 *>(g);
+        o.x += beta * old.x; o.y += beta * old.y; o.z += beta * old.z; o.w += beta * old.w;
+      }
+      *reinterpret_cast<float4 *>(g) = o;
+    } else {
+      float o = alpha * Gz[nn * Nc + mm] * Gs[flat];
+      if (beta != 0.f) o += beta * *g;
+      *g = o;
+    }
+  }
+}
+
+// Length-C contractions of the factorised Linear products (vivit/extensions/secondorder/vivit/linear.py:53,64):
+//   T[f, o, nn] = sum_c mat[f, c, nn] * s[c, nn, o]         ("vcn,cno->von"; then V mat = T z on MFMA)
+__global__ __launch_bounds__(EW_BLOCK) void class_contract_kernel(const float *__restrict__ mat, const float *__restrict__ s,
+                                                                  float *__restrict__ T, int64_t F, int64_t C, int64_t N,
+                                                                  int64_t O) {
+  const int64_t total = F * O * N;
+  for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t nn = idx % N, o = (idx / N) % O, f = idx / (N * O);
+    float acc = 0.f;
+    for (int64_t c = 0; c < C; ++c) acc += mat[(f * C + c) * N + nn] * s[(c * N + nn) * O + o];
+    T[idx] = acc;
+  }
+}
+//   R[f, c, nn] = sum_o s[c, nn, o] * U[f, o, nn]           ("cno,von->vcn"; U = mat z^T from MFMA)
+__global__ __launch_bounds__(EW_BLOCK) void class_expand_kernel(const float *__restrict__ s, const float *__restrict__ U,
+                                                                float *__restrict__ R, int64_t F, int64_t C, int64_t N,
+                                                                int64_t O) {
+  const int64_t total = F * C * N;
+  for (int64_t idx = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * EW_BLOCK) {
+    const int64_t nn = idx % N, c = (idx / N) % C, f = idx / (N * C);
+    const float *srow = s + (c * N + nn) * O;
+    float acc = 0.f;
+    for (int64_t o = 0; o < O; ++o) acc += srow[o] * U[(f * O + o) * N + nn];
+    R[idx] = acc;
+  }
+}
+
 // lambdas[nn, k] = scale * sum_c GE[(c*N + nn), k]^2 / evals[k]
 __global__ __launch_bounds__(EW_BLOCK) void dir_curvature_kernel(const float *__restrict__ GE,
                                                                  const float *__restrict__ evals,
@@ -154,6 +213,40 @@ int vivit_gram_hadamard_f32(const float *Gz, const float *Gs, float *G, int64_t 
     hadamard_kernel<true><<<ew_grid((n * n) >> 2), EW_BLOCK, 0, s>>>(Gz, Gs, G, C, N, alpha, beta);
   else
     hadamard_kernel<false><<<ew_grid(n * n), EW_BLOCK, 0, s>>>(Gz, Gs, G, C, N, alpha, beta);
+  return launch_status();
+}
+
+int vivit_gram_hadamard_block_f32(const float *Gz, const float *Gs, float *G, int64_t Cr, int64_t Nr, int64_t Cc,
+                                  int64_t Nc, int64_t ldg, float alpha, float beta, void *stream) {
+  if (Cr < 0 || Nr < 0 || Cc < 0 || Nc < 0 || ldg < Cc * Nc) return VIVIT_E_BADARG;
+  if (Cr == 0 || Nr == 0 || Cc == 0 || Nc == 0) return VIVIT_OK;
+  if (!Gz || !Gs || !G) return VIVIT_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t total = Cr * Nr * Cc * Nc;
+  const bool vec = (Nc % 4 == 0) && (ldg % 4 == 0) && ((reinterpret_cast<uintptr_t>(Gz) | reinterpret_cast<uintptr_t>(Gs) |
+                                                       reinterpret_cast<uintptr_t>(G)) & 15) == 0;
+  if (vec)
+    hadamard_block_kernel<true><<<ew_grid(total >> 2), EW_BLOCK, 0, s>>>(Gz, Gs, G, Cr, Nr, Cc, Nc, ldg, alpha, beta);
+  else
+    hadamard_block_kernel<false><<<ew_grid(total), EW_BLOCK, 0, s>>>(Gz, Gs, G, Cr, Nr, Cc, Nc, ldg, alpha, beta);
+  return launch_status();
+}
+
+int vivit_class_contract_f32(const float *mat, const float *s, float *T, int64_t F, int64_t C, int64_t N, int64_t O,
+                             void *stream) {
+  if (F < 0 || C < 0 || N < 0 || O < 0) return VIVIT_E_BADARG;
+  if (F == 0 || N == 0 || O == 0) return VIVIT_OK;
+  if (!T || (C > 0 && (!mat || !s))) return VIVIT_E_BADARG;
+  class_contract_kernel<<<ew_grid(F * O * N), EW_BLOCK, 0, static_cast<hipStream_t>(stream)>>>(mat, s, T, F, C, N, O);
+  return launch_status();
+}
+
+int vivit_class_expand_f32(const float *s, const float *U, float *R, int64_t F, int64_t C, int64_t N, int64_t O,
+                           void *stream) {
+  if (F < 0 || C < 0 || N < 0 || O < 0) return VIVIT_E_BADARG;
+  if (F == 0 || C == 0 || N == 0) return VIVIT_OK;
+  if (!R || (O > 0 && (!s || !U))) return VIVIT_E_BADARG;
+  class_expand_kernel<<<ew_grid(F * C * N), EW_BLOCK, 0, static_cast<hipStream_t>(stream)>>>(s, U, R, F, C, N, O);
   return launch_status();
 }
 

@@ -196,20 +196,26 @@ static int symeig_two_stage_values(float *A, int64_t n, int64_t lda, float *w, v
   float *tau2 = (float *)take(sizeof(float) * n * sb2st_num_levels(n));
   float *d = (float *)take(sizeof(float) * n);
   float *e = (float *)take(sizeof(float) * n);
+  prof_mark(PROF_STAGE_BEGIN, stream);
   int st = prescale_launch(A, n, lda, scal, part, stream);
   if (st != VIVIT_OK) return st;
   st = symmetrize_launch(A, n, lda, stream);
   if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_PREP, stream);
   float *tau1;
   st = sy2sb_launch(A, n, lda, sbws, &tau1, stream);
   if (st != VIVIT_OK) return st;
   st = sy2sb_extract_band_launch(A, lda, n, AB, stream);
   if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_SY2SB, stream);
   st = sb2st_launch(AB, n, d, e, R2, n, rrows, tau2, stream);
   if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_SB2ST, stream);
   st = stebz_launch(d, e, n, w, scal, stream);
   if (st != VIVIT_OK) return st;
-  return info_finalize_launch(info, n, scal, stream);
+  st = info_finalize_launch(info, n, scal, stream);
+  prof_mark(PROF_STAGE_TRIDIAG, stream);
+  return st;
 }
 
 // rows mode (r1 >= 0): Z receives the eigenvectors r0 .. r1-1 (ascending eigenvalue order) as ROWS, [r1-r0][ldz];
@@ -243,18 +249,22 @@ static int symeig_large_impl(float *A, int64_t n, int64_t lda, float *w, float *
     float *tau2 = (float *)take(tau2_bytes);
     float *d = (float *)take(sizeof(float) * n);
     float *e = (float *)take(sizeof(float) * n);
+    prof_mark(PROF_STAGE_BEGIN, stream);
     int st = prescale_launch(A, n, lda, scal, part, stream);
     if (st != VIVIT_OK) return st;
     st = symmetrize_launch(A, n, lda, stream);
     if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_PREP, stream);
     float *tau1;
     st = sy2sb_launch(A, n, lda, sbws, &tau1, stream);
     if (st != VIVIT_OK) return st;
     st = sy2sb_extract_band_launch(A, lda, n, AB, stream);
     if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_SY2SB, stream);
     if (hipMemsetAsync(tau2, 0, tau2_bytes, stream) != hipSuccess) return VIVIT_E_LAUNCH;
     st = sb2st_launch(AB, n, d, e, R2, n, n, tau2, stream);
     if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_SB2ST, stream);
     void *dc_base = take(stedc_workspace_bytes(n, true));
     float *Qt, *dd;
     int *order;
@@ -264,30 +274,42 @@ static int symeig_large_impl(float *A, int64_t n, int64_t lda, float *w, float *
     if (rows_mode) {
       st = dc_rows_launch(n, dd, Qt, n, order, w, Z, ldz, r0, r1, scal, stream);
       if (st != VIVIT_OK) return st;
+      prof_mark(PROF_STAGE_TRIDIAG, stream);
       st = q2_apply_launch(Z, ldz, r1 - r0, n, R2, n, tau2, q2ws, stream);
       if (st != VIVIT_OK) return st;
+      prof_mark(PROF_STAGE_Q2, stream);
       st = backtransform_launch(A, n, lda, tau1, TS_NB, n - TS_NB - 1, Z, ldz, r1 - r0, take, stream);
       if (st != VIVIT_OK) return st;
+      prof_mark(PROF_STAGE_Q1, stream);
       return info_scal_launch(info, n, scal, stream);
     }
+    prof_mark(PROF_STAGE_TRIDIAG, stream);
     st = q2_apply_launch(Qt, n, n, n, R2, n, tau2, q2ws, stream);
     if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_Q2, stream);
     st = backtransform_launch(A, n, lda, tau1, TS_NB, n - TS_NB - 1, Qt, n, n, take, stream);
     if (st != VIVIT_OK) return st;
-    return dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, scal, info, stream);
+    prof_mark(PROF_STAGE_Q1, stream);
+    st = dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, scal, info, stream);
+    prof_mark(PROF_STAGE_OUTPUT, stream);
+    return st;
   }
 
   // ---- stage 1: A = Q_H T Q_H^T
   SytrdWs tw;
   float *trd_base = (float *)take(sizeof(float) * sytrd_workspace_floats(n));
+  prof_mark(PROF_STAGE_BEGIN, stream);
   int st = sytrd_launch(A, n, lda, trd_base, &tw, stream);
   if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_SYTRD, stream);
 
   if (!vectors) {
     // ---- stage 2 (values only): bisection, undo the scaling
     st = stebz_launch(tw.d, tw.e, n, w, tw.scal, stream);
     if (st != VIVIT_OK) return st;
-    return info_finalize_launch(info, n, tw.scal, stream);
+    st = info_finalize_launch(info, n, tw.scal, stream);
+    prof_mark(PROF_STAGE_TRIDIAG, stream);
+    return st;
   }
 
   // ---- stage 2: T = Q_T diag(w) Q_T^T by divide and conquer (Qt = Q_T^T, rows unsorted)
@@ -300,17 +322,23 @@ static int symeig_large_impl(float *A, int64_t n, int64_t lda, float *w, float *
   if (rows_mode) {
     st = dc_rows_launch(n, dd, Qt, n, order, w, Z, ldz, r0, r1, tw.scal, stream);
     if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_TRIDIAG, stream);
     st = backtransform_launch(A, n, lda, tw.tau, 1, n - 3, Z, ldz, r1 - r0, take, stream);
     if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_Q1, stream);
     return info_scal_launch(info, n, tw.scal, stream);
   }
+  prof_mark(PROF_STAGE_TRIDIAG, stream);
 
   // ---- stage 3: Zt = Qt * Q_H^T
   st = backtransform_launch(A, n, lda, tw.tau, 1, n - 3, Qt, n, n, take, stream);
   if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_Q1, stream);
 
   // ---- sort ascending, undo the scaling, deliver column eigenvectors
-  return dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, tw.scal, info, stream);
+  st = dc_output_launch(n, dd, Qt, n, order, w, Z, ldz, tw.scal, info, stream);
+  prof_mark(PROF_STAGE_OUTPUT, stream);
+  return st;
 }
 
 int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *ws, size_t ws_bytes,

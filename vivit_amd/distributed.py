@@ -1,21 +1,125 @@
-"""Multi-GPU Gram build: one process per GPU, RCCL (backend "nccl" on ROCm) over xGMI.
+"""Multi-GPU Gram path: one process per GPU, RCCL (backend "nccl" on ROCm) over xGMI.
 
-The Gram matrix ``G[(c,n),(d,m)] = sum_p V[c,n,p] V[d,m,p]`` couples every pair of samples, so a
-batch shard does NOT yield a partial sum.  What is a sum is the contraction
-over parameters -- the reference's own ``gram += gram_p`` (vivit/utils/gram.py:104-116).  Ranks
-therefore own *column slices* of ``V`` (whole parameters or slices of a parameter's trailing
-dims), each builds the ``[n, n]`` partial Gram of its slice on MFMA, and one all-reduce adds them.
-The eigensolver's reduction and tridiagonal solve then run replicated (deterministic, no atomics:
-every rank holds bit-identical intermediate results, nothing is broadcast); its back-transformations
-act on every eigenvector independently, so rank r back-transforms only the r-th slice of the
-eigenvectors (``vivit_symeig_rows_f32``) and one all-gather delivers them to everybody (`symeig`).
+The reference is single-process (no collectives).  The layout here is data parallel: rank ``g`` ran
+forward/backward on its batch shard ``N_g`` and holds the sqrt-GGN factors of *its* samples only.  The Gram matrix
+``G[(c,n),(d,m)] = sum_p V[c,n,p] V[d,m,p]`` couples every pair of samples, so shards are not partial sums
+(SURVEY.md 8e); two exchange schemes make them so:
+
+* **materialised factors** ``V_g [C, N_g, *param]`` (generic layers, BackPACK ``SqrtGGN*``): one
+  ``all_to_all`` per parameter turns the batch shards into *parameter* shards -- rank ``r`` receives columns
+  ``[lo_r, hi_r)`` of every rank's rows, i.e. ``V[:, :, lo_r:hi_r]`` for ALL samples (class-major rows restored on
+  receipt).  The contraction over parameters IS a sum (the reference's own ``gram += gram_p``,
+  vivit/utils/gram.py:104-116), so each rank runs the full-size MFMA SYRK on ``1/R`` of the contraction length and the
+  partial Gram matrices are summed with one all-reduce.  On the point-to-point xGMI fabric the all-to-all uses all
+  seven links of every GPU at once and moves ``(R-1)/R`` of ``V`` exactly once (a ring pass of row blocks would move
+  ``V`` ``R/2`` times).
+* **factorised Linear weights** ``(s_g [C, N_g, out], z_g [N_g, in])`` (vivit/extensions/secondorder/vivit/linear.py:41-42;
+  the only form that exists for BASELINE config 5): all-gather the small factors, every rank computes its **block row**
+  ``G[N_g, :] = (z_g z^T) o (s_g s^T)`` (``1/R`` of the flops), block rows are all-gathered and stored class-major.
+
+The eigensolver's reduction and tridiagonal solve then run replicated (deterministic, no atomics: bit-identical on all
+ranks, nothing is broadcast); its back-transformations act on every eigenvector independently, so rank ``r``
+back-transforms the ``r``-th slice (``vivit_symeig_rows_f32``) and one all-gather delivers the eigenvectors
+(:func:`symeig`).  Back-projections ``V v`` are true sums over samples: each rank applies its own rows of ``V`` and one
+all-reduce of ``P`` floats finishes the Newton step (vivit/optim/directional_damped_newton.py:370-373;
+:func:`all_reduce_sum_`).
+
+For functional tests several ranks may share one GPU with the ``gloo`` backend; collectives on device tensors are then
+staged through host memory (``_staged``) -- test plumbing, never the measured path.
 """
-from typing import Iterable, Optional
+from typing import Iterable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 from vivit_amd import kernels
+
+SMALL_PARAM_COLUMNS = 64  # parameters with fewer columns per rank than this are owned whole by one rank
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# collectives (thin wrappers: RCCL directly; gloo + device tensors are staged through the host for 1-GPU functional tests)
+def _active(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank_of(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def _staged(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over the ranks of ``group`` (the Gram partials, the ``P``-float Newton step, ...)."""
+    if not _active(group):
+        return t
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        if not t.is_contiguous():
+            raise ValueError("all_reduce_sum_ needs a contiguous tensor")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def all_gather_cat(t: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[R * t.shape[0], *t.shape[1:]]``: the ranks' equally shaped ``t`` stacked along dim 0 in rank order."""
+    R = world_size(group)
+    t = t.contiguous()
+    if out is None:
+        out = torch.empty((R * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if R == 1:
+        out.copy_(t)
+        return out
+    if _staged(t, group):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, t.cpu(), group=group)
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
+def all_to_all_flat(send: torch.Tensor, in_splits: Sequence[int], out_splits: Sequence[int], group=None) -> torch.Tensor:
+    """1-D all-to-all with per-peer element counts; returns the received flat buffer (peer order)."""
+    recv = torch.empty(int(sum(out_splits)), dtype=send.dtype, device=send.device)
+    if _staged(send, group):
+        h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(h, send.cpu(), list(out_splits), list(in_splits), group=group)
+        recv.copy_(h)
+    else:
+        dist.all_to_all_single(recv, send, list(out_splits), list(in_splits), group=group)
+    return recv
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def column_slices(num_columns: int, world: int):
+    """Balanced contiguous column ranges ``[(lo, hi)] * world`` of a ``[n, num_columns]`` factor."""
+    return [((num_columns * r) // world, (num_columns * (r + 1)) // world) for r in range(world)]
+
+
+def row_slices(n: int, world: int):
+    """Equal-length eigenvector ranges (the last ones may be shorter / empty): ``[(lo, hi)] * world``."""
+    per = -(-n // world)
+    return [(min(r * per, n), min((r + 1) * per, n)) for r in range(world)]
+
+
+def parameter_slices(num_columns: int, world: int, index: int = 0):
+    """Column ranges of one parameter's factor owned by each rank after the all-to-all.  Large parameters are cut
+    into balanced contiguous ranges; a parameter too small to give every rank ``SMALL_PARAM_COLUMNS`` columns goes
+    whole to rank ``index % world`` (a rank-``k`` SYRK with tiny ``k`` costs an ``n^2`` read-modify-write per rank)."""
+    if num_columns < SMALL_PARAM_COLUMNS * world:
+        owner = index % world
+        return [(0, num_columns) if r == owner else (0, 0) for r in range(world)]
+    return column_slices(num_columns, world)
 
 
 def partial_gram(local_factors: Iterable[torch.Tensor], start_dim: int = 2, out: Optional[torch.Tensor] = None):
@@ -38,22 +142,191 @@ def partial_gram(local_factors: Iterable[torch.Tensor], start_dim: int = 2, out:
 
 def sharded_gram(local_factors: Iterable[torch.Tensor], start_dim: int = 2, group=None,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Full Gram matrix on every rank from parameter-sharded factors (partial Gram + all-reduce)."""
+    """Full Gram matrix on every rank from PARAMETER-sharded factors (partial Gram + all-reduce): the layout of a
+    tensor-parallel layer, and the second half of the batch-sharded scheme below."""
     G = partial_gram(local_factors, start_dim=start_dim, out=out)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
-    return G
+    return all_reduce_sum_(G, group)
 
 
-def column_slices(num_columns: int, world_size: int):
-    """Balanced contiguous column ranges ``[(lo, hi)] * world_size`` of a ``[n, num_columns]`` factor."""
-    return [((num_columns * r) // world_size, (num_columns * (r + 1)) // world_size) for r in range(world_size)]
+def to_parameter_shard(local: torch.Tensor, lead_dims: int, group=None, index: int = 0) -> torch.Tensor:
+    """Batch shard -> parameter shard of one factor by all-to-all.
+
+    ``local``: this rank's ``[C, N_g, *param]`` (``lead_dims = 2``; sqrt-GGN factor) or ``[N_g, *param]``
+    (``lead_dims = 1``; per-sample gradients).  Returns ``[C * N, w]`` (resp. ``[N, w]``): ALL samples (rank-major
+    order ``n = g N_g + n_local`` inside each class, i.e. the reference's class-major rows ``c N + n``), columns
+    ``[lo, hi)`` of the flattened parameter owned by this rank (:func:`parameter_slices`), ``w = hi - lo`` (may be 0).
+    """
+    R, me = world_size(group), rank_of(group)
+    if lead_dims == 1:
+        local = local.unsqueeze(0)
+    C, Ng = int(local.shape[0]), int(local.shape[1])
+    F = local.detach().reshape(C, Ng, -1)
+    P = F.shape[2]
+    if R == 1:
+        return F.reshape(C * Ng, P)
+    slices = parameter_slices(P, R, index)
+    send = torch.cat([F[:, :, lo:hi].reshape(-1) for lo, hi in slices])
+    w = slices[me][1] - slices[me][0]
+    recv = all_to_all_flat(send, [C * Ng * (hi - lo) for lo, hi in slices], [C * Ng * w] * R, group)
+    del send
+    # [R, C, N_g, w] -> class-major [C, R, N_g, w]  (for C == 1 the received order already is the row order)
+    recv = recv.view(R, C, Ng, w)
+    if C > 1:
+        recv = recv.permute(1, 0, 2, 3).contiguous()
+    return recv.reshape(C * R * Ng, w)
 
 
-def row_slices(n: int, world_size: int):
-    """Equal-length eigenvector ranges (the last ones may be shorter / empty): ``[(lo, hi)] * world_size``."""
-    per = -(-n // world_size)
-    return [(min(r * per, n), min((r + 1) * per, n)) for r in range(world_size)]
+def check_equal_shards(n_local: int, group=None) -> int:
+    """Global batch size; raises if the ranks' shards differ in size (the block layout needs equal shards)."""
+    R = world_size(group)
+    if R == 1:
+        return n_local
+    sizes = [None] * R
+    dist.all_gather_object(sizes, int(n_local), group=group)
+    if any(s != sizes[0] for s in sizes):
+        raise ValueError(f"batch shards must have equal size on every rank, got {sizes}")
+    return n_local * R
+
+
+class BatchShardedGram:
+    """Accumulate ``V^T V`` (and optionally ``V^T g``) of one parameter group from BATCH-sharded factors.
+
+    ``C``: classes / MC samples, ``N_local``: this rank's samples.  After the ``add_*`` calls of all parameters,
+    :meth:`finalize` returns the full ``[C, N, C, N]`` Gram matrix (``N = R N_local``, class-major like the reference:
+    vivit/utils/gram.py:58-69) on every rank; :meth:`finalize_vtg` the ``[C, N, N_grad]`` dot products.
+    """
+
+    def __init__(self, C: int, N_local: int, group=None, N_grad_local: Optional[int] = None):
+        self.group = group
+        self.R, self.me = world_size(group), rank_of(group)
+        self.C, self.Ng = int(C), int(N_local)
+        self.N = self.Ng * self.R
+        self.n = self.C * self.N
+        self.Mg = None if N_grad_local is None else int(N_grad_local)
+        self.M = None if self.Mg is None else self.Mg * self.R
+        self.partial = None    # [n, n]   parameter-sharded partial sum (all-to-all path)
+        self.rows = None       # [C N_g, n] block row of this rank (factorised / all-gather path)
+        self.partial_g = None  # [n, M]
+        self.rows_g = None     # [C N_g, M]
+        self._count = 0
+
+    # -- materialised factors: all-to-all to parameter shards, full-size SYRK on 1/R of the contraction ------------
+    def add_factor(self, V_local: torch.Tensor, g_local: Optional[torch.Tensor] = None):
+        """``V_local: [C, N_g, *param]``; ``g_local: [M_g, *param]`` adds ``V^T g`` (K2) of the same parameter."""
+        idx = self._count
+        self._count += 1
+        A = to_parameter_shard(V_local, 2, self.group, idx)
+        if self.partial is None:
+            self.partial = torch.zeros((self.n, self.n), dtype=torch.float32, device=V_local.device)
+        if A.shape[1] > 0:
+            kernels.gram_syrk(A, out=self.partial, alpha=1.0, beta=1.0)
+        if g_local is not None:
+            B = to_parameter_shard(g_local, 1, self.group, idx)
+            if self.partial_g is None:
+                self.partial_g = torch.zeros((self.n, self.M), dtype=torch.float32, device=V_local.device)
+            if A.shape[1] > 0:
+                kernels.gemm_nt(A, B, out=self.partial_g, alpha=1.0, beta=1.0)
+
+    # -- small materialised factors (biases, ...): all-gather the factor, block row by one NT GEMM -----------------
+    def add_factor_rows(self, V_local: torch.Tensor, g_local: Optional[torch.Tensor] = None):
+        self._count += 1
+        C, Ng = self.C, self.Ng
+        A = V_local.detach().reshape(C * Ng, -1)
+        full = self._gather_class_major(V_local.detach().reshape(C, Ng, -1))        # [C, N, P]
+        self.rows = kernels.gemm_nt(A, full.reshape(self.n, -1), out=self.rows, alpha=1.0,
+                                    beta=0.0 if self.rows is None else 1.0)
+        if g_local is not None:
+            gfull = all_gather_cat(g_local.detach().reshape(self.Mg, -1), self.group)  # [M, P]
+            self.rows_g = kernels.gemm_nt(A, gfull, out=self.rows_g, alpha=1.0, beta=0.0 if self.rows_g is None else 1.0)
+
+    # -- factorised Linear weight: all-gather (s, z), block row (z_g z^T) o (s_g s^T) -------------------------------
+    def add_linear(self, s_local: torch.Tensor, z_local: torch.Tensor, delta_local: Optional[torch.Tensor] = None,
+                   zg_local: Optional[torch.Tensor] = None):
+        """``s_local: [C, N_g, out]``, ``z_local: [N_g, in]`` (``V_t[c,n,o,i] = s[c,n,o] z[n,i]``);
+        ``delta_local: [M_g, out]`` with ``zg_local: [M_g, in]`` (default ``z_local``): the per-sample gradient
+        ``g[m,o,i] = delta[m,o] zg[m,i]``, adds ``V^T g``."""
+        self._count += 1
+        C, Ng, N = self.C, self.Ng, self.N
+        s_local, z_local = s_local.detach().contiguous(), z_local.detach().contiguous()
+        z = all_gather_cat(z_local, self.group)                                     # [N, in]
+        s = self._gather_class_major(s_local)                                       # [C, N, out]
+        Gz = kernels.gemm_nt(z_local, z)                                            # [N_g, N]
+        Gs = kernels.gemm_nt(s_local.reshape(C * Ng, -1), s.reshape(C * N, -1))     # [C N_g, C N]
+        self.rows = kernels.gram_hadamard_block(Gz, Gs, C, Ng, C, N, out=self.rows, alpha=1.0,
+                                                beta=0.0 if self.rows is None else 1.0)
+        if delta_local is not None:
+            zg_local = z_local if zg_local is None else zg_local.detach().contiguous()
+            zg = all_gather_cat(zg_local, self.group)                               # [M, in]
+            delta = all_gather_cat(delta_local.detach().contiguous(), self.group)   # [M, out]
+            Gzg = kernels.gemm_nt(z_local, zg)                                      # [N_g, M]
+            Gsd = kernels.gemm_nt(s_local.reshape(C * Ng, -1), delta)               # [C N_g, M]
+            self.rows_g = kernels.gram_hadamard_block(Gzg, Gsd, C, Ng, 1, self.M, out=self.rows_g, alpha=1.0,
+                                                      beta=0.0 if self.rows_g is None else 1.0)
+
+    def _gather_class_major(self, t_local: torch.Tensor) -> torch.Tensor:
+        """``[C, N_g, X]`` per rank -> ``[C, N, X]`` (samples in rank order inside each class)."""
+        C, Ng = self.C, self.Ng
+        g = all_gather_cat(t_local.reshape(1, C, Ng, -1), self.group)               # [R, C, N_g, X]
+        if C == 1 or self.R == 1:
+            return g.reshape(C, self.N, -1)
+        return g.permute(1, 0, 2, 3).reshape(C, self.N, -1)
+
+    def _assemble(self, rows, partial, width):
+        """Block rows ``[C N_g, width]`` of all ranks -> class-major ``[n, width]``; plus the all-reduced partial."""
+        C, Ng, R, n = self.C, self.Ng, self.R, self.n
+        out = None
+        if partial is not None:
+            if rows is not None:  # disjoint supports: fold the block row into the partial sum before the all-reduce
+                partial.view(C, R, Ng, width)[:, self.me].add_(rows.view(C, Ng, width))
+                rows = None
+            out = all_reduce_sum_(partial, self.group)
+        if rows is not None:
+            g = all_gather_cat(rows.view(1, C * Ng, width), self.group)            # [R, C N_g, width]
+            if C > 1 and R > 1:  # class-major store: row (c, g N_g + n_local)
+                g = g.view(R, C, Ng, width).permute(1, 0, 2, 3).contiguous()
+            out = g.reshape(n, width)
+        return out
+
+    def finalize(self) -> torch.Tensor:
+        """The group's Gram matrix ``[C, N, C, N]``, identical on every rank."""
+        if self.rows is None and self.partial is None:
+            raise ValueError("no factor was added")
+        G = self._assemble(self.rows, self.partial, self.n)
+        self.rows = self.partial = None
+        return G.view(self.C, self.N, self.C, self.N)
+
+    def finalize_vtg(self) -> torch.Tensor:
+        """``V^T g`` as ``[C, N, N_grad]`` (vivit/optim/directional_damped_newton.py:255), identical on every rank."""
+        if self.rows_g is None and self.partial_g is None:
+            raise ValueError("no gradient factor was added")
+        A = self._assemble(self.rows_g, self.partial_g, self.M)
+        self.rows_g = self.partial_g = None
+        return A.view(self.C, self.N, self.M)
+
+    def local_samples(self, t: torch.Tensor, dim: int) -> torch.Tensor:
+        """Slice of a global-sample axis (length ``N``) that belongs to this rank."""
+        return t.narrow(dim, self.me * self.Ng, self.Ng)
+
+
+def batch_sharded_gram(local_factors: Sequence[torch.Tensor], group=None) -> torch.Tensor:
+    """``[n, n]`` Gram matrix on every rank from batch-sharded materialised factors ``[C, N_g, *param]``."""
+    C, Ng = int(local_factors[0].shape[0]), int(local_factors[0].shape[1])
+    acc = BatchShardedGram(C, Ng, group)
+    for V in local_factors:
+        acc.add_factor(V)
+    return acc.finalize().view(acc.n, acc.n)
+
+
+def backproject_sum(coef: torch.Tensor, V_local: torch.Tensor, acc: BatchShardedGram) -> torch.Tensor:
+    """``sum_{c,n} coef[k, c, n] V[c, n, ...]`` over ALL samples: every rank applies its own rows of ``V``, one
+    all-reduce of ``K P`` floats sums the shards (the Newton step, directional_damped_newton.py:370-373, K = 1;
+    the eigenvector back-projection, vivit/utils/ggn.py:94-115).  ``coef: [K, C, N]`` (global), ``V_local:
+    [C, N_g, *param]``."""
+    K = coef.shape[0]
+    mine = acc.local_samples(coef.reshape(K, acc.C, acc.N), 2).reshape(K, acc.C * acc.Ng).contiguous()
+    out = kernels.gemm_nn(mine, V_local.detach().reshape(acc.C * acc.Ng, -1))
+    all_reduce_sum_(out, acc.group)
+    return out.view(K, *V_local.shape[2:])
 
 
 def symeig(G: torch.Tensor, group=None, overwrite: bool = False):
@@ -64,11 +337,11 @@ def symeig(G: torch.Tensor, group=None, overwrite: bool = False):
     ``(evals [n], evecs [n, n])`` like ``kernels.symeig(G, eigenvectors=True)``; ``evecs`` is the
     transposed view of the gathered row-major eigenvector matrix (``evecs[:, i]`` contiguous).
     """
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    world = world_size(group)
     if world == 1:
         return kernels.symeig(G, eigenvectors=True, overwrite=overwrite)
     n = G.shape[0]
-    rank = dist.get_rank(group)
+    rank = rank_of(group)
     per = -(-n // world)
     lo, hi = row_slices(n, world)[rank]
     w, Zt_local = kernels.symeig_rows(G, lo, hi, overwrite=overwrite)
@@ -77,6 +350,5 @@ def symeig(G: torch.Tensor, group=None, overwrite: bool = False):
     else:  # pad the short last slices: all_gather_into_tensor needs equal shapes
         send = torch.zeros((per, n), dtype=Zt_local.dtype, device=Zt_local.device)
         send[: hi - lo] = Zt_local
-    Zt = torch.empty((world * per, n), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(Zt, send.contiguous(), group=group)
+    Zt = all_gather_cat(send, group)
     return w, Zt[:n].T

@@ -207,6 +207,61 @@ def gram_hadamard(Gz, Gs, C: int, N: int, out=None, alpha: float = 1.0, beta: fl
 
 
 @_launcher
+def gram_hadamard_block(Gz, Gs, Cr: int, Nr: int, Cc: int, Nc: int, out=None, alpha: float = 1.0, beta: float = 0.0):
+    """``out[(c,n),(d,m)] = alpha * Gz[n,m] * Gs[(c,n),(d,m)] + beta * out`` for a rectangular block (rows
+    ``Cr x Nr``, columns ``Cc x Nc``): the block row of a batch shard, and ``V^T g`` of a factorised Linear weight."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.gram_hadamard_block(Gz, Gs, Cr, Nr, Cc, Nc, out, alpha, beta)
+    _require_device(Gz, Gs, out)
+    Gz, Gs = Gz.contiguous(), Gs.contiguous()
+    rows, cols = Cr * Nr, Cc * Nc
+    if tuple(Gz.shape) != (Nr, Nc) or Gs.numel() != rows * cols:
+        raise ValueError(f"Gz must be [{Nr}, {Nc}] and Gs [{rows}, {cols}]")
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=Gz.device)
+        beta = 0.0
+    _check_out(out, rows, cols, Gz, Gs)
+    st = _lib.load().vivit_gram_hadamard_block_f32(Gz.data_ptr(), Gs.data_ptr(), out.data_ptr(), Cr, Nr, Cc, Nc, _ld(out),
+                                                   alpha, beta, _stream(Gz))
+    _lib.check(st, "vivit_gram_hadamard_block_f32")
+    return out
+
+
+@_launcher
+def class_contract(mat, s):
+    """``T[f,o,n] = sum_c mat[f,c,n] s[c,n,o]``; ``mat: [F,C,N]``, ``s: [C,N,O]`` (first half of linear.py:53)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.class_contract(mat, s)
+    _require_device(mat, s)
+    mat, s = mat.contiguous(), s.contiguous()
+    F, C, N = mat.shape
+    if tuple(s.shape[:2]) != (C, N):
+        raise ValueError(f"s must be [{C}, {N}, O], got {tuple(s.shape)}")
+    O = s.shape[2]
+    T = torch.empty((F, O, N), dtype=torch.float32, device=mat.device)
+    st = _lib.load().vivit_class_contract_f32(mat.data_ptr(), s.data_ptr(), T.data_ptr(), F, C, N, O, _stream(mat))
+    _lib.check(st, "vivit_class_contract_f32")
+    return T
+
+
+@_launcher
+def class_expand(s, U):
+    """``R[f,c,n] = sum_o s[c,n,o] U[f,o,n]``; ``s: [C,N,O]``, ``U: [F,O,N]`` (second half of linear.py:64)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.class_expand(s, U)
+    _require_device(s, U)
+    s, U = s.contiguous(), U.contiguous()
+    C, N, O = s.shape
+    F = U.shape[0]
+    if tuple(U.shape[1:]) != (O, N):
+        raise ValueError(f"U must be [F, {O}, {N}], got {tuple(U.shape)}")
+    R = torch.empty((F, C, N), dtype=torch.float32, device=s.device)
+    st = _lib.load().vivit_class_expand_f32(s.data_ptr(), U.data_ptr(), R.data_ptr(), F, C, N, O, _stream(s))
+    _lib.check(st, "vivit_class_expand_f32")
+    return R
+
+
+@_launcher
 def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False, info_out: Optional[list] = None
            ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Eigenvalues (ascending) and, optionally, column eigenvectors of symmetric ``G`` (K3/K4).

@@ -141,6 +141,30 @@ int vivit_symeig_f32(float *A, int64_t n, int64_t lda, float *w, float *Z, int64
 int vivit_symeig_rows_f32(float *A, int64_t n, int64_t lda, float *w, float *Zt, int64_t ldz, int64_t row_begin,
                           int64_t row_end, void *workspace, size_t workspace_bytes, int32_t *info, void *stream);
 
+/* Two-phase variant for callers that keep only a few eigenvectors (SURVEY.md 8b `symeig_select_f32`).  The reference
+ * computes all n eigenvectors and slices them with the index list its `criterion` callback returns from the
+ * eigenvalues: evals, evecs = symeig(...); keep = criterion(evals); evecs[:, keep]
+ *   vivit/linalg/eigh.py:248-253, vivit/optim/directional_damped_newton.py:315-321,
+ *   vivit/optim/directional_derivatives.py:291-297.
+ * Here the callback runs between two calls:
+ *   vivit_symeig_reduce_f32: A (destroyed, as in vivit_symeig_f32) -> tridiagonal form; w: all n eigenvalues,
+ *     ascending (Sturm multisection).  `state` (vivit_symeig_reduce_f32_workspace_bytes(n) bytes) receives the
+ *     tridiagonal, the fp64 eigenvalues, the reflector scalars and the second-stage reflectors; A keeps the
+ *     first-stage reflectors.  Neither may be touched before phase 2.
+ *   vivit_symeig_select_f32: idx: DEVICE int32 [K], strictly ascending positions into w; Zt: [K, n] (ldz >= n),
+ *     row k = unit eigenvector of w[idx[k]].  K <= 256: inverse iteration on the tridiagonal (fp64), else divide &
+ *     conquer; then only those K rows are back-transformed (4 K n^2 flop instead of 4 n^3).  May be called more than
+ *     once per reduction.  Same (A, n, lda, state) as phase 1; `workspace` is scratch of
+ *     vivit_symeig_select_f32_workspace_bytes(n, K) bytes.
+ * n <= 192: VIVIT_E_UNSUPPORTED (use vivit_symeig_f32 and slice). */
+size_t vivit_symeig_reduce_f32_workspace_bytes(int64_t n);
+size_t vivit_symeig_select_f32_workspace_bytes(int64_t n, int64_t K);
+int vivit_symeig_reduce_f32(float *A, int64_t n, int64_t lda, float *w, void *state, size_t state_bytes,
+                            int32_t *info, void *stream);
+int vivit_symeig_select_f32(const float *A, int64_t n, int64_t lda, const int32_t *idx, int64_t K, float *Zt, int64_t ldz,
+                            void *state, size_t state_bytes, void *workspace, size_t workspace_bytes, int32_t *info,
+                            void *stream);
+
 /* Stage 1 of vivit_symeig_f32, exported for testing: Householder tridiagonalisation
  * A = Q T Q^T (lower triangle read).  d: [n], e: [n-1], tau: [n]; on return row j of A's upper
  * triangle, A[j][j+1:], holds reflector v_j (v_j[j+1] = 1), Q = H_0 ... H_{n-3},

@@ -35,3 +35,14 @@ def test_bench_factors_match_backend():
     G_full = sum(f @ f.T for f in facs)
     G_sharded = sum(f @ f.T for f in f0) + sum(f @ f.T for f in f1)
     torch.testing.assert_close(G_full, G_sharded, rtol=1e-5, atol=1e-6)
+
+
+def test_bench_factors_batch_shard_rows():
+    """``samples=(lo, hi)`` (a data-parallel rank's shard) = the corresponding class-major rows of the full factors."""
+    dims, batch, C = (7, 6, 5), 6, 5
+    full = bench.mlp_sqrt_ggn_factors(dims, batch, torch.device("cpu"), seed=3)
+    lo, hi = 2, 4
+    part = bench.mlp_sqrt_ggn_factors(dims, batch, torch.device("cpu"), seed=3, samples=(lo, hi))
+    for f, p in zip(full, part):
+        expect = f.view(C, batch, -1)[:, lo:hi].reshape(C * (hi - lo), -1)
+        torch.testing.assert_close(p, expect, rtol=1e-5, atol=1e-8)  # (S @ W2 is blocked differently on a slice)

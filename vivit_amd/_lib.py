@@ -34,6 +34,10 @@ SIGNATURES = {
     "vivit_symeig_f32_workspace_bytes": (_sz, [_i64, _int]),
     "vivit_symeig_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
     "vivit_symeig_rows_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr, _sz, _ptr, _ptr]),
+    "vivit_symeig_reduce_f32_workspace_bytes": (_sz, [_i64]),
+    "vivit_symeig_select_f32_workspace_bytes": (_sz, [_i64, _i64]),
+    "vivit_symeig_reduce_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _sz, _ptr, _ptr]),
+    "vivit_symeig_select_f32": (_int, [_ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr, _sz, _ptr, _sz, _ptr, _ptr]),
     "vivit_sytrd_f32_workspace_bytes": (_sz, [_i64]),
     "vivit_sytrd_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     "vivit_sy2sb_f32_workspace_bytes": (_sz, [_i64]),

@@ -32,6 +32,35 @@ def subsample(tensor: Tensor, dim: int = 0, subsampling: Optional[List[int]] = N
     return tensor.index_select(dim, idx)
 
 
+class LinearFactor:
+    """Factorised quantity of a Linear weight, ``T[..., n, o, i] = s[..., n, o] * z[n, i]``, never materialised.
+
+    ``s: [C, N, out]`` for a sqrt-GGN factor (``V_t`` of vivit/extensions/secondorder/vivit/linear.py:41-42) or
+    ``[N, out]`` for per-sample gradients (``grad_batch[n] = delta_n z_n^T``); ``z: [N, in]``.  Stored under the
+    savefield in place of the tensor when an extension is created with ``factorised=True``: the only representation
+    that exists at BASELINE config 5 (the tensor would be 2.7 TB).  ``vivit_amd.optim`` contracts it with two small
+    GEMMs and the fused Hadamard kernel."""
+
+    def __init__(self, s: Tensor, z: Tensor):
+        self.s, self.z = s.contiguous(), z.contiguous()
+
+    @property
+    def shape(self):
+        return tuple(self.s.shape) + (self.z.shape[1],)
+
+    def dim(self):
+        return self.s.dim() + 1
+
+    def detach(self):
+        return self
+
+    def materialise(self) -> Tensor:
+        """The explicit tensor (small problems / mixed representations only)."""
+        if self.s.dim() == 2:
+            return torch.einsum("no,ni->noi", self.s, self.z)
+        return torch.einsum("cno,ni->cnoi", self.s, self.z)
+
+
 class _Extension:
     savefield = None
 
@@ -106,6 +135,10 @@ class BatchGrad(_Extension):
 
     savefield = "grad_batch"
 
+    def __init__(self, subsampling: Optional[List[int]] = None, factorised: bool = False):
+        super().__init__(subsampling)
+        self._factorised = factorised
+
     def apply(self, ctx, module, g_out):
         params = _own_params(module)
         if not params or isinstance(module, _LOSSES):
@@ -114,7 +147,10 @@ class BatchGrad(_Extension):
         g = subsample(g_out.detach(), 0, sub).unsqueeze(0)  # [1, N, *out]
         x = subsample(module.input0.detach(), 0, sub)
         for name, p in params:
-            setattr(p, self.savefield, _param_factor(module, name, g, x)[0])
+            if self._factorised and isinstance(module, nn.Linear) and name == "weight" and g.dim() == 3:
+                setattr(p, self.savefield, LinearFactor(g[0], x))
+            else:
+                setattr(p, self.savefield, _param_factor(module, name, g, x)[0])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -155,16 +191,20 @@ def _loss_hessian_sqrt(module, strategy: str, mc_samples: int, samples: Optional
 class _SqrtGGN(_Extension):
     strategy = "exact"
 
-    def __init__(self, subsampling=None, mc_samples: int = 1, samples: Optional[Tensor] = None):
+    def __init__(self, subsampling=None, mc_samples: int = 1, samples: Optional[Tensor] = None, factorised: bool = False):
         super().__init__(subsampling)
         self._mc_samples = mc_samples
         self._samples = samples  # externally supplied MC one-hots [M, N, C] (parity needs them)
+        self._factorised = factorised
 
     def get_num_mc_samples(self) -> int:
         return self._mc_samples
 
     def _store(self, module, name, param, M, x):
-        setattr(param, self.savefield, _param_factor(module, name, M, x))
+        if self._factorised and isinstance(module, nn.Linear) and name == "weight" and M.dim() == 3:
+            setattr(param, self.savefield, LinearFactor(M, x))
+        else:
+            setattr(param, self.savefield, _param_factor(module, name, M, x))
 
     def apply(self, ctx, module, g_out):
         sub = self.get_subsampling()
@@ -188,8 +228,8 @@ class SqrtGGNExact(_SqrtGGN):
     savefield = "sqrt_ggn_exact"
     strategy = "exact"
 
-    def __init__(self, subsampling=None):
-        super().__init__(subsampling)
+    def __init__(self, subsampling=None, factorised: bool = False):
+        super().__init__(subsampling, factorised=factorised)
 
 
 class SqrtGGNMC(_SqrtGGN):
@@ -198,8 +238,8 @@ class SqrtGGNMC(_SqrtGGN):
     savefield = "sqrt_ggn_mc"
     strategy = "sampling"
 
-    def __init__(self, mc_samples: int = 1, subsampling=None, samples: Optional[Tensor] = None):
-        super().__init__(subsampling, mc_samples, samples)
+    def __init__(self, mc_samples: int = 1, subsampling=None, samples: Optional[Tensor] = None, factorised: bool = False):
+        super().__init__(subsampling, mc_samples, samples, factorised=factorised)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -10,6 +10,12 @@ int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, in
                         int32_t *info, hipStream_t stream);
 int symeig_large_rows_launch(float *A, int64_t n, int64_t lda, float *w, float *Zt, int64_t ldz, int64_t r0, int64_t r1,
                              void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream);
+size_t symeig_reduce_workspace_bytes(int64_t n);
+size_t symeig_select_workspace_bytes(int64_t n, int64_t K);
+int symeig_reduce_launch(float *A, int64_t n, int64_t lda, float *w, void *ws, size_t ws_bytes, int32_t *info,
+                         hipStream_t stream);
+int symeig_select_launch(const float *A, int64_t n, int64_t lda, const int *sel, int64_t K, float *Zt, int64_t ldz,
+                         void *state, size_t state_bytes, void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream);
 } // namespace vivit
 
 using namespace vivit;
@@ -56,6 +62,35 @@ int vivit_symeig_rows_f32(float *A, int64_t n, int64_t lda, float *w, float *Zt,
   if (n <= SMALL_N_MAX) return VIVIT_E_UNSUPPORTED;  // single-workgroup sizes: use vivit_symeig_f32 and slice
   return symeig_large_rows_launch(A, n, lda, w, Zt, ldz, row_begin, row_end, workspace, workspace_bytes, info,
                                   static_cast<hipStream_t>(stream));
+}
+
+size_t vivit_symeig_reduce_f32_workspace_bytes(int64_t n) {
+  if (n <= SMALL_N_MAX) return 0;
+  return symeig_reduce_workspace_bytes(n);
+}
+
+size_t vivit_symeig_select_f32_workspace_bytes(int64_t n, int64_t K) {
+  if (n <= SMALL_N_MAX) return 0;
+  return symeig_select_workspace_bytes(n, K);
+}
+
+// Phase 1 of the selected-eigenvector solver: reduction to tridiagonal form + ALL eigenvalues (ascending).
+int vivit_symeig_reduce_f32(float *A, int64_t n, int64_t lda, float *w, void *state, size_t state_bytes,
+                            int32_t *info, void *stream) {
+  if (n < 0 || !info) return VIVIT_E_BADARG;
+  if (!A || !w || lda < n) return VIVIT_E_BADARG;
+  if (n <= SMALL_N_MAX) return VIVIT_E_UNSUPPORTED;  // single-workgroup sizes: use vivit_symeig_f32 and slice
+  return symeig_reduce_launch(A, n, lda, w, state, state_bytes, info, static_cast<hipStream_t>(stream));
+}
+
+// Phase 2: the eigenvectors of the K eigenvalues at ascending positions idx[0] < idx[1] < ... as ROWS of Zt.
+int vivit_symeig_select_f32(const float *A, int64_t n, int64_t lda, const int32_t *idx, int64_t K, float *Zt, int64_t ldz,
+                            void *state, size_t state_bytes, void *workspace, size_t workspace_bytes, int32_t *info,
+                            void *stream) {
+  if (n < 0 || !info || !A || lda < n) return VIVIT_E_BADARG;
+  if (n <= SMALL_N_MAX) return VIVIT_E_UNSUPPORTED;
+  return symeig_select_launch(A, n, lda, idx, K, Zt, ldz, state, state_bytes, workspace, workspace_bytes, info,
+                              static_cast<hipStream_t>(stream));
 }
 
 } // extern "C"

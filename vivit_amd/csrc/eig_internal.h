@@ -27,13 +27,31 @@ size_t stedc_workspace_bytes(int64_t n, bool vectors);
 int stedc_dc_launch(const float *d, const float *e, int64_t n, void *wsbase, float **Qt_out, float **d_out,
                     int **order_scratch, int32_t *info, hipStream_t stream);
 // w[m] = m-th smallest eigenvalue of (d, e) by bisection, divided by scal[1] when scal != nullptr
-int stebz_launch(const float *d, const float *e, int64_t n, float *w, const float *scal, hipStream_t stream);
+// (w64, optional: the same eigenvalues in fp64, NOT divided by the scale)
+int stebz_launch(const float *d, const float *e, int64_t n, float *w, const float *scal, hipStream_t stream,
+                 double *w64 = nullptr);
+// stein.hip: selected eigenvectors of the tridiagonal (d, e) by inverse iteration, rows of Zt
+size_t stein_workspace_bytes(int64_t n, int64_t K);
+int stein_launch(const float *d, const float *e, int64_t n, const double *lam64, const int *sel, int64_t K, float *Zt,
+                 int64_t ldz, void *wsbase, hipStream_t stream);
+// sytrd.hip: pointers into a workspace laid out by sytrd_launch (same base, same n) without launching anything
+void sytrd_layout(float *wsbase, int64_t n, SytrdWs *out);
+// two-phase eigensolver for criterion-selected eigenvectors (symeig_large.hip)
+size_t symeig_reduce_workspace_bytes(int64_t n);
+size_t symeig_select_workspace_bytes(int64_t n, int64_t K);
+int symeig_reduce_launch(float *A, int64_t n, int64_t lda, float *w, void *ws, size_t ws_bytes, int32_t *info,
+                         hipStream_t stream);
+int symeig_select_launch(const float *A, int64_t n, int64_t lda, const int *sel, int64_t K, float *Zt, int64_t ldz,
+                         void *state, size_t state_bytes, void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream);
 // w = sorted(dcur) / sigma;  Z[i][p] = Qt[order[p]][i];  info = n if the input was non-finite
 int symeig_large_rows_launch(float *A, int64_t n, int64_t lda, float *w, float *Zt, int64_t ldz, int64_t r0, int64_t r1,
                              void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream);
 int dc_rows_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *w, float *Zs,
                    int64_t ldz, int64_t r0, int64_t r1, const float *scal, hipStream_t stream);
 int info_scal_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream);
+// rows Zs[s] = eigenvector at ascending position sel[s] (device int32 [K]) of a finished divide & conquer
+int dc_select_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *wscratch,
+                     const int *sel, int64_t K, float *Zs, int64_t ldz, hipStream_t stream);
 int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *w, float *Z,
                      int64_t ldz, const float *scal, int32_t *info, hipStream_t stream);
 

@@ -56,7 +56,7 @@ struct DcWs {
 constexpr int SB_LANES = 8;    // shifts per eigenvalue and round
 constexpr int SB_ROUNDS = 12;
 __global__ __launch_bounds__(256) void stebz_kernel(const float *__restrict__ d, const float *__restrict__ e, int n,
-                                                    float *__restrict__ w) {
+                                                    float *__restrict__ w, double *__restrict__ w64) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
   // Gershgorin interval (every block recomputes it: O(n) reads, fixed order)
@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void stebz_kernel(const float *__restrict__ d,
     b = nle < SB_LANES ? nb : b;
     if (!(b > a)) break;
   }
-  if (active && sub == 0) w[m] = (float)(0.5 * (a + b));
+  if (active && sub == 0) {
+    w[m] = (float)(0.5 * (a + b));
+    if (w64) w64[m] = 0.5 * (a + b);  // unrounded, unscaled: the shifts of the inverse iteration (stein.hip)
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -608,8 +611,9 @@ int stedc_dc_launch(const float *d, const float *e, int64_t n, void *wsbase, flo
   return launch_status();
 }
 
-int stebz_launch(const float *d, const float *e, int64_t n, float *w, const float *scal, hipStream_t stream) {
-  stebz_kernel<<<(unsigned)cdiv(n, 256 / SB_LANES), 256, 0, stream>>>(d, e, (int)n, w);
+int stebz_launch(const float *d, const float *e, int64_t n, float *w, const float *scal, hipStream_t stream,
+                 double *w64) {
+  stebz_kernel<<<(unsigned)cdiv(n, 256 / SB_LANES), 256, 0, stream>>>(d, e, (int)n, w, w64);
   if (scal) scale_w_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(w, (int)n, scal);
   return launch_status();
 }
@@ -647,6 +651,27 @@ int dc_rows_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, i
     const int64_t rc = (r1 - r < 65535) ? r1 - r : 65535;
     dc_gather_rows_kernel<<<dim3((unsigned)(cdiv(n, 1024) < 64 ? cdiv(n, 1024) : 64), (unsigned)rc), 256, 0, stream>>>(
         (int)n, Qt, ldq, order, (int)r, Zs + (r - r0) * ldz, ldz);
+  }
+  return launch_status();
+}
+
+// Zs[s][:] = Qt[order[sel[s]]][:]   (arbitrary selection of eigenvectors, ascending eigenvalue positions sel[s])
+__global__ __launch_bounds__(256) void dc_gather_sel_kernel(int n, const float *__restrict__ Qt, int64_t ldq,
+                                                            const int *__restrict__ order, const int *__restrict__ sel,
+                                                            int s0, float *__restrict__ Zs, int64_t ldz) {
+  const int s = s0 + blockIdx.y;
+  const float *src = Qt + (int64_t)order[sel[s]] * ldq;
+  float *dst = Zs + (int64_t)s * ldz;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+int dc_select_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq, int *order, float *wscratch,
+                     const int *sel, int64_t K, float *Zs, int64_t ldz, hipStream_t stream) {
+  dc_final_rank_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>((int)n, dcur, order, wscratch, nullptr);
+  for (int64_t s = 0; s < K; s += 65535) {
+    const int64_t sc = (K - s < 65535) ? K - s : 65535;
+    dc_gather_sel_kernel<<<dim3((unsigned)(cdiv(n, 1024) < 64 ? cdiv(n, 1024) : 64), (unsigned)sc), 256, 0, stream>>>(
+        (int)n, Qt, ldq, order, sel, (int)s, Zs, ldz);
   }
   return launch_status();
 }

@@ -341,6 +341,179 @@ static int symeig_large_impl(float *A, int64_t n, int64_t lda, float *w, float *
   return st;
 }
 
+// ---- two-phase solver: reduction + all eigenvalues, host-side criterion, then only the selected eigenvectors --------
+// Phase 1 (symeig_reduce_launch) leaves in the workspace everything phase 2 needs: the tridiagonal (d, e), the
+// eigenvalues in fp64, the reflector scalars (the reflectors themselves are in A and, two-stage, in R2).
+// Phase 2 (symeig_select_launch): K <= SELECT_STEIN_MAX eigenvectors by inverse iteration on T (stein.hip),
+// otherwise divide & conquer + gather; then the back-transformations on those K rows only (4 K n^2 flop).
+constexpr int64_t SELECT_STEIN_MAX = 256;
+
+struct SelectLayout {
+  bool two_stage;
+  // two-stage
+  float *scal, *part;
+  void *sbws;
+  float *AB, *R2, *tau2, *tau1, *d, *e;
+  // one-stage
+  float *trd_base;
+  SytrdWs tw;
+  double *lam64;
+  int *order_id;  // [n] identity permutation (rows mode of the D&C output wants an order array)
+  char *rest;     // phase-2 scratch (stein | stedc, q2, back-transformation)
+};
+
+static bool select_two_stage(int64_t n) { return use_two_stage(n, false); }
+
+static SelectLayout select_layout(void *ws, int64_t n) {
+  char *p = reinterpret_cast<char *>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+  auto take = [&](size_t bytes) {
+    char *r = p;
+    p += align_up(bytes, 256);
+    return r;
+  };
+  SelectLayout L;
+  L.two_stage = select_two_stage(n);
+  if (L.two_stage) {
+    L.scal = (float *)take(sizeof(float) * 16);
+    L.part = (float *)take(sizeof(float) * 2 * n);
+    L.sbws = take(sy2sb_workspace_bytes(n));
+    L.AB = (float *)take(sizeof(float) * n * (2 * TS_NB + 1));
+    L.R2 = (float *)take(sizeof(float) * n * n);
+    L.tau2 = (float *)take(sizeof(float) * n * sb2st_num_levels(n));
+    L.tau1 = (float *)take(sizeof(float) * n);
+    L.d = (float *)take(sizeof(float) * n);
+    L.e = (float *)take(sizeof(float) * n);
+    L.trd_base = nullptr;
+  } else {
+    L.trd_base = (float *)take(sizeof(float) * sytrd_workspace_floats(n));
+    sytrd_layout(L.trd_base, n, &L.tw);
+    L.scal = L.tw.scal;
+    L.d = L.tw.d;
+    L.e = L.tw.e;
+    L.tau1 = L.tw.tau;
+  }
+  L.lam64 = (double *)take(sizeof(double) * n);
+  L.rest = p;
+  return L;
+}
+
+// state workspace (phase 1 writes it, phase 2 reads it)
+size_t symeig_reduce_workspace_bytes(int64_t n) {
+  size_t b = 0;
+  if (select_two_stage(n)) {
+    b += align_up(sizeof(float) * 16, 256) + align_up(sizeof(float) * 2 * n, 256);
+    b += align_up(sy2sb_workspace_bytes(n), 256);
+    b += align_up(sizeof(float) * n * (2 * TS_NB + 1), 256);
+    b += align_up(sizeof(float) * n * n, 256);
+    b += align_up(sizeof(float) * n * sb2st_num_levels(n), 256);
+    b += align_up(sizeof(float) * n, 256) * 3;
+  } else {
+    b += align_up(sizeof(float) * sytrd_workspace_floats(n), 256);
+  }
+  b += align_up(sizeof(double) * n, 256);
+  return b + 1024;
+}
+
+// scratch workspace of phase 2 for K selected eigenvectors
+size_t symeig_select_workspace_bytes(int64_t n, int64_t K) {
+  if (K < 1) K = 1;
+  if (K > n) K = n;
+  size_t b = select_two_stage(n) ? q2_workspace_bytes(n) + 512 : 0;
+  const size_t after = bt_workspace_bytes(n);
+  if (K > SELECT_STEIN_MAX) {  // D&C buffers, reused by the back-transformations afterwards
+    const size_t dc = align_up(stedc_workspace_bytes(n, true), 256);
+    b += align_up(sizeof(float) * n, 256) + (dc > after ? dc : after);
+  } else {
+    b += align_up(stein_workspace_bytes(n, K), 256) + after;
+  }
+  return b + 1024;
+}
+
+int symeig_reduce_launch(float *A, int64_t n, int64_t lda, float *w, void *ws, size_t ws_bytes, int32_t *info,
+                         hipStream_t stream) {
+  if (n > 0x7fffffffLL / 8) return VIVIT_E_UNSUPPORTED;
+  if (!ws || ws_bytes < symeig_reduce_workspace_bytes(n)) return VIVIT_E_WORKSPACE;
+  if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return VIVIT_E_LAUNCH;
+  SelectLayout L = select_layout(ws, n);
+  prof_mark(PROF_STAGE_BEGIN, stream);
+  int st;
+  if (L.two_stage) {
+    st = prescale_launch(A, n, lda, L.scal, L.part, stream);
+    if (st != VIVIT_OK) return st;
+    st = symmetrize_launch(A, n, lda, stream);
+    if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_PREP, stream);
+    float *tau1;
+    st = sy2sb_launch(A, n, lda, L.sbws, &tau1, stream);
+    if (st != VIVIT_OK) return st;
+    if (hipMemcpyAsync(L.tau1, tau1, sizeof(float) * n, hipMemcpyDeviceToDevice, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    st = sy2sb_extract_band_launch(A, lda, n, L.AB, stream);
+    if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_SY2SB, stream);
+    if (hipMemsetAsync(L.tau2, 0, sizeof(float) * n * sb2st_num_levels(n), stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    st = sb2st_launch(L.AB, n, L.d, L.e, L.R2, n, n, L.tau2, stream);
+    if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_SB2ST, stream);
+  } else {
+    SytrdWs tw;
+    st = sytrd_launch(A, n, lda, L.trd_base, &tw, stream);
+    if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_SYTRD, stream);
+  }
+  st = stebz_launch(L.d, L.e, n, w, L.scal, stream, L.lam64);
+  if (st != VIVIT_OK) return st;
+  st = info_finalize_launch(info, n, L.scal, stream);
+  prof_mark(PROF_STAGE_TRIDIAG, stream);
+  return st;
+}
+
+// order[i] = sel[i] for i < K (device copy with the identity elsewhere is not needed: dc_rows_launch sorts itself)
+int symeig_select_launch(const float *A, int64_t n, int64_t lda, const int *sel, int64_t K, float *Zt, int64_t ldz,
+                         void *state, size_t state_bytes, void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream) {
+  if (K < 0 || K > n || (K > 0 && (!sel || !Zt || ldz < n))) return VIVIT_E_BADARG;
+  if (!state || state_bytes < symeig_reduce_workspace_bytes(n)) return VIVIT_E_WORKSPACE;
+  if (K == 0) return VIVIT_OK;
+  if (!ws || ws_bytes < symeig_select_workspace_bytes(n, K)) return VIVIT_E_WORKSPACE;
+  SelectLayout L = select_layout(state, n);
+  char *p = reinterpret_cast<char *>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+  auto take = [&](size_t bytes) {
+    char *r = p;
+    p += align_up(bytes, 256);
+    return r;
+  };
+  prof_mark(PROF_STAGE_BEGIN, stream);
+  int st;
+  if (K <= SELECT_STEIN_MAX) {
+    void *stws = take(stein_workspace_bytes(n, K));
+    st = stein_launch(L.d, L.e, n, L.lam64, sel, K, Zt, ldz, stws, stream);
+    if (st != VIVIT_OK) return st;
+  } else {  // many eigenvectors: divide & conquer for all of them, keep the selected rows
+    float *wscratch = (float *)take(sizeof(float) * n);
+    void *dc_base = take(stedc_workspace_bytes(n, true));
+    float *Qt, *dd;
+    int *order;
+    st = stedc_dc_launch(L.d, L.e, n, dc_base, &Qt, &dd, &order, info, stream);
+    if (st != VIVIT_OK) return st;
+    st = dc_select_launch(n, dd, Qt, n, order, wscratch, sel, K, Zt, ldz, stream);
+    if (st != VIVIT_OK) return st;
+    p = reinterpret_cast<char *>(dc_base);  // the D&C buffers are free again for the back-transformations
+  }
+  prof_mark(PROF_STAGE_TRIDIAG, stream);
+  if (L.two_stage) {
+    void *q2ws = take(q2_workspace_bytes(n));
+    st = q2_apply_launch(Zt, ldz, K, n, L.R2, n, L.tau2, q2ws, stream);
+    if (st != VIVIT_OK) return st;
+    prof_mark(PROF_STAGE_Q2, stream);
+    st = backtransform_launch(A, n, lda, L.tau1, TS_NB, n - TS_NB - 1, Zt, ldz, K, take, stream);
+  } else {
+    st = backtransform_launch(A, n, lda, L.tau1, 1, n - 3, Zt, ldz, K, take, stream);
+  }
+  if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_Q1, stream);
+  (void)info;
+  return VIVIT_OK;
+}
+
 int symeig_large_launch(float *A, int64_t n, int64_t lda, float *w, float *Z, int64_t ldz, void *ws, size_t ws_bytes,
                         int32_t *info, hipStream_t stream) {
   return symeig_large_impl(A, n, lda, w, Z, ldz, 0, -1, ws, ws_bytes, info, stream);

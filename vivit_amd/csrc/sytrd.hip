@@ -510,6 +510,11 @@ static SytrdWs sytrd_carve(float *base, int64_t n, float **scanpart) {
   return ws;
 }
 
+void sytrd_layout(float *wsbase, int64_t n, SytrdWs *out) {
+  float *scanpart;
+  *out = sytrd_carve(wsbase, n, &scanpart);
+}
+
 int prescale_launch(float *A, int64_t n, int64_t lda, float *scal, float *part, hipStream_t stream) {
   const int ni = (int)n;
   trd_scan_kernel<<<ni, 256, 0, stream>>>(A, lda, ni, part);

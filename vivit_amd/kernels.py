@@ -70,6 +70,20 @@ def _launcher(fn):
     return wrapped
 
 
+def _launcher_method(fn):
+    """``_launcher`` for methods whose device is that of ``self.evals``."""
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        dev = self.evals.device
+        if _TEST_BACKEND is not None or not dev.type == "cuda" or dev.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+
+    return wrapped
+
+
 def _check_out(out, m, n, *operands):
     """``out`` is written by the kernel with a single leading dimension: shape, strides and aliasing must be right,
     otherwise the launch would write out of bounds or into an operand it is still reading."""
@@ -295,6 +309,76 @@ def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False,
     else:
         check_info(info)  # device->host sync; the reference syncs here too (criterion callback)
     return w, Z
+
+
+class SymeigPlan:
+    """A symmetric matrix reduced to tridiagonal form with ALL eigenvalues known (``evals``, ascending), waiting for
+    the caller to say which eigenvectors it wants: the two launches around the reference's ``criterion`` callback
+    (vivit/linalg/eigh.py:248-253).  :meth:`select` returns ``evecs[:, keep]`` of the reference."""
+
+    def __init__(self, evals, n, A=None, state=None, full=None):
+        self.evals, self.n = evals, n
+        self._A, self._state, self._full = A, state, full
+
+    @_launcher_method
+    def select(self, keep) -> torch.Tensor:
+        """``[n, K]`` column eigenvectors of ``evals[keep]`` (``keep``: any order, list of ints or an integer tensor)."""
+        n = self.n
+        dev = self.evals.device
+        keep = [int(k) for k in (keep.tolist() if isinstance(keep, torch.Tensor) else keep)]
+        keep = [k + n if k < 0 else k for k in keep]
+        if any(k < 0 or k >= n for k in keep):
+            raise IndexError(f"eigenvector index out of range for n = {n}")
+        K = len(keep)
+        if self._full is not None:  # small problem / test backend: all vectors already there
+            return self._full[:, keep]
+        if K == 0:
+            return torch.empty((n, 0), dtype=torch.float32, device=dev)
+        uniq = sorted(set(keep))
+        idx = torch.tensor(uniq, dtype=torch.int32, device=dev)
+        Zt = torch.empty((len(uniq), n), dtype=torch.float32, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        ws, wsb = _workspace(lib.vivit_symeig_select_f32_workspace_bytes(n, len(uniq)), self.evals)
+        st = lib.vivit_symeig_select_f32(
+            self._A.data_ptr(), n, _ld(self._A), idx.data_ptr(), len(uniq), Zt.data_ptr(), n, self._state.data_ptr(),
+            self._state.numel(), ws, wsb, info.data_ptr(), _stream(self.evals))
+        _lib.check(st, "vivit_symeig_select_f32")
+        check_info(info)
+        if uniq != keep:  # caller's order / repeated indices
+            pos = {k: i for i, k in enumerate(uniq)}
+            Zt = Zt[torch.tensor([pos[k] for k in keep], dtype=torch.long, device=dev)]
+        return Zt.T
+
+
+@_launcher
+def symeig_reduce(G: torch.Tensor, overwrite: bool = False) -> SymeigPlan:
+    """Phase 1 of the selected-eigenvector solver: all eigenvalues of symmetric ``G`` (ascending, in ``plan.evals``)
+    and a reduced state from which ``plan.select(keep)`` produces only the wanted eigenvectors
+    (``vivit_symeig_reduce_f32`` / ``vivit_symeig_select_f32``).  Synchronises (the caller's criterion needs the
+    eigenvalues anyway) and raises ``RuntimeError`` on non-convergence like :func:`symeig`."""
+    if _TEST_BACKEND is not None:
+        w, Z = _TEST_BACKEND.symeig(G, True)
+        return SymeigPlan(w, G.shape[0], full=Z)
+    _require_device(G)
+    if G.dim() != 2 or G.shape[0] != G.shape[1]:
+        raise ValueError(f"Input must be a square matrix. Got shape {tuple(G.shape)}.")
+    n = G.shape[0]
+    if n < SYMEIG_ROWS_MIN_N:  # single-workgroup solver: all vectors cost nothing extra
+        w, Z = symeig(G, eigenvectors=True, overwrite=overwrite)
+        return SymeigPlan(w, n, full=Z)
+    A = _as2d(G)
+    if A.data_ptr() == G.data_ptr() and not overwrite:
+        A = A.clone()
+    w = torch.empty(n, dtype=torch.float32, device=G.device)
+    info = torch.zeros(1, dtype=torch.int32, device=G.device)
+    lib = _lib.load()
+    state = torch.empty(lib.vivit_symeig_reduce_f32_workspace_bytes(n) + 256, dtype=torch.uint8, device=G.device)
+    st = lib.vivit_symeig_reduce_f32(A.data_ptr(), n, _ld(A), w.data_ptr(), state.data_ptr(), state.numel(),
+                                     info.data_ptr(), _stream(G))
+    _lib.check(st, "vivit_symeig_reduce_f32")
+    check_info(info)
+    return SymeigPlan(w, n, A=A, state=state)
 
 
 def check_info(info: torch.Tensor):

@@ -146,12 +146,16 @@ class EighComputation:
                 gram_mat = gram_fn() if gram_mat is None else gram_fn(out=gram_mat, beta=1.0)
             C, N = gram_mat.shape[:2]
 
-            gram_evals, gram_evecs = kernels.symeig(reshape_as_square(gram_mat), eigenvectors=True, overwrite=True)
+            # two launches around the criterion callback: reduction + all eigenvalues, then only the kept eigenvectors
+            # (inverse iteration + back-transformation of K rows; the reference computes all n and slices, eigh.py:248-253)
+            plan = kernels.symeig_reduce(reshape_as_square(gram_mat), overwrite=True)
+            gram_evals = plan.evals
             if subsampling is not None:  # eigh.py:245-246; eigenvectors are scale invariant
                 gram_evals *= batch_size / len(subsampling)
 
             keep = group["criterion"](gram_evals)
-            gram_evals, gram_evecs = gram_evals[keep], gram_evecs[:, keep]
+            gram_evals, gram_evecs = gram_evals[keep], plan.select(keep)
+            del plan
 
             if (gram_evals.abs() < warn_small_eigvals).any():
                 warn(small_warning)

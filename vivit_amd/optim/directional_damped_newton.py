@@ -9,6 +9,7 @@ from vivit_amd import kernels
 from vivit_amd.linalg.utils import get_hook_store_batch_size
 from vivit_amd.optim.directional_derivatives import (
     accumulate_dot_products,
+    apply_factor,
     dot_products,
     gram_space_directions,
 )
@@ -43,7 +44,21 @@ class DirectionalDampedNewtonComputation:
         mc_samples_ggn: Optional[int] = 0,
         verbose: Optional[bool] = False,
         warn_small_eigvals: float = 1e-4,
+        factorised: bool = False,
+        data_parallel: bool = False,
+        process_group=None,
     ):
+        """Reference signature (vivit/optim/directional_damped_newton.py:39-83) plus three opt-in extensions:
+
+        ``factorised``: Linear weights keep ``V_t = s (x) z`` and ``grad_batch = delta (x) z`` factorised
+          (vivit/extensions/secondorder/vivit/linear.py:41-42) -- same step, no ``[C, N, out, in]`` tensors (the only
+          way BASELINE config 5 fits: its materialised factor is 2.7 TB).
+        ``data_parallel`` / ``process_group``: every rank of the (default) ``torch.distributed`` group ran the backward
+          pass on ITS batch shard; the Gram matrix and ``V^T g`` are assembled across ranks
+          (:class:`vivit_amd.distributed.BatchShardedGram`), eigensolve / gammas / lambdas run replicated, each rank
+          back-projects its own samples and one all-reduce of ``P`` floats sums the step
+          (directional_damped_newton.py:370-373).  The batch size used for the scalings is the global one.
+        """
         check_subsampling_unique(subsampling_grad)
         check_subsampling_unique(subsampling_ggn)
         self._mc_samples_ggn = mc_samples_ggn
@@ -51,6 +66,8 @@ class DirectionalDampedNewtonComputation:
             assert mc_samples_ggn == 1
         self._subsampling_grad = subsampling_grad
         self._subsampling_ggn = subsampling_ggn
+        self._factorised = factorised
+        self._dp = {"group": process_group} if data_parallel else None
         self._savefield_grad = get_batch_grad_extension(None).savefield
         self._savefield_ggn = get_sqrt_ggn_extension(None, mc_samples_ggn).savefield
         self._verbose = verbose
@@ -66,8 +83,9 @@ class DirectionalDampedNewtonComputation:
 
     def get_extensions(self) -> List:
         return [
-            get_batch_grad_extension(self._subsampling_grad),
-            get_sqrt_ggn_extension(subsampling=self._subsampling_ggn, mc_samples=self._mc_samples_ggn),
+            get_batch_grad_extension(self._subsampling_grad, factorised=self._factorised),
+            get_sqrt_ggn_extension(subsampling=self._subsampling_ggn, mc_samples=self._mc_samples_ggn,
+                                   factorised=self._factorised),
         ]
 
     def get_extension_hook(self, param_groups: List[Dict]) -> Callable[[Module], None]:
@@ -76,7 +94,7 @@ class DirectionalDampedNewtonComputation:
         hook = ParameterGroupsHook.from_functions(
             param_groups,
             lambda hook, param: self._param_computation(
-                hook, param, self._savefield_ggn, self._savefield_grad, self._verbose
+                hook, param, self._savefield_ggn, self._savefield_grad, self._verbose, self._dp
             ),
             lambda hook, accumulation, group: self._group_hook(
                 hook, accumulation, group, self._batch_size, self._savefield_ggn, self._newton_steps,
@@ -98,8 +116,8 @@ class DirectionalDampedNewtonComputation:
         return extension_hook
 
     @staticmethod
-    def _param_computation(hook, param, savefield_ggn, savefield_grad, verbose):
-        result = dot_products(hook, param, savefield_ggn, savefield_grad, verbose)
+    def _param_computation(hook, param, savefield_ggn, savefield_grad, verbose, data_parallel=None):
+        result = dot_products(hook, param, savefield_ggn, savefield_grad, verbose, data_parallel)
         # V is kept for the back-projection of the step (directional_damped_newton.py:258)
         delete_savefield(param, savefield_grad, verbose=verbose)
         return result
@@ -108,7 +126,7 @@ class DirectionalDampedNewtonComputation:
     def _group_hook(hook, accumulation, group, batch_size, savefield_ggn, newton_steps, verbose,
                     warn_small_eigvals):
         N = batch_size.pop(id(group))
-        evals, evecs, gammas, lambdas, V_correction, C, N_ggn = gram_space_directions(
+        evals, evecs, gammas, lambdas, V_correction, C, N_ggn, dp_acc = gram_space_directions(
             accumulation, group, N, verbose, warn_small_eigvals, _SMALL_EVALS_NEWTON
         )
         # coefficients along the directions (directional_damped_newton.py:353-359): O(K) glue
@@ -118,12 +136,19 @@ class DirectionalDampedNewtonComputation:
         )
         # weight in Gram space (:362-366), then apply V (K7, :370-373): step_p = v^T V_p
         v = kernels.gemm_nn(evecs, coefficients.reshape(-1, 1).contiguous(), alpha=V_correction)  # [n, 1]
-        v_row = v.reshape(1, C * N_ggn)
+        coef = v.reshape(1, C, N_ggn)
         params = group["params"]
         steps = []
+        if dp_acc is not None:
+            # data parallel: this rank applies the rows of V it owns, one all-reduce of P floats sums the shards
+            from vivit_amd.distributed import all_reduce_sum_
+
+            coef = dp_acc.local_samples(coef, 2).contiguous()
         for param in params:
-            V = getattr(param, savefield_ggn).detach()
-            steps.append(kernels.gemm_nn(v_row, V.reshape(C * N_ggn, -1)).view(param.shape))
+            step = apply_factor(getattr(param, savefield_ggn), coef)[0]
+            if dp_acc is not None:
+                all_reduce_sum_(step, dp_acc.group)
+            steps.append(step.view(param.shape))
         for param in params:
             delete_savefield(param, savefield_ggn, verbose=verbose)
         newton_steps[id(group)] = steps

@@ -184,13 +184,15 @@ def test_eigvalsh_and_eigh_end_to_end(problem, subsampling, groups_kind, device)
         np.testing.assert_allclose((E @ B).numpy(), (evals.cpu().double()[:, None] * E).numpy(), rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("factorised", [False, True], ids=["materialised", "factorised"])
 @pytest.mark.parametrize("mc", [0, 1])
 @pytest.mark.parametrize("sub_ggn", [None, [0, 1]], ids=["ggn_full", "ggn_sub"])
 @pytest.mark.parametrize("sub_grad", [None, [0, 1]], ids=["grad_full", "grad_sub"])
 @pytest.mark.parametrize("problem", ["mlp_ce", "cnn_ce"])
-def test_damped_newton_end_to_end(problem, sub_grad, sub_ggn, mc, device):
+def test_damped_newton_end_to_end(problem, sub_grad, sub_ggn, mc, factorised, device):
     """Newton step == oracle restatement on autograd factors
-    (test/optim/test_directional_damped_newton.py:33-74; rtol/atol 1e-5 there, fp32 here)."""
+    (test/optim/test_directional_damped_newton.py:33-74; rtol/atol 1e-5 there, fp32 here).  ``factorised``: Linear
+    weights stay ``s (x) z`` (vivit/extensions/secondorder/vivit/linear.py:41-42) -- same step."""
     model, X, y, lossf, loss = make_problem(problem)
     ref_model, _, _, ref_lossf, _ = make_problem(problem)
     out = ref_model(X).detach()
@@ -211,7 +213,8 @@ def test_damped_newton_end_to_end(problem, sub_grad, sub_ggn, mc, device):
 
     model, X, y = model.to(device), X.to(device), y.to(device)
     comp = vivit_amd.DirectionalDampedNewtonComputation(
-        subsampling_grad=sub_grad, subsampling_ggn=sub_ggn, mc_samples_ggn=mc, warn_small_eigvals=0.0
+        subsampling_grad=sub_grad, subsampling_ggn=sub_ggn, mc_samples_ggn=mc, warn_small_eigvals=0.0,
+        factorised=factorised,
     )
     exts = comp.get_extensions()
     if mc:
@@ -222,7 +225,8 @@ def test_damped_newton_end_to_end(problem, sub_grad, sub_ggn, mc, device):
         close(s, r, rtol=1e-3, atol=2e-5 * max(r.abs().max().item(), 1e-2))
 
     comp = vivit_amd.DirectionalDerivativesComputation(
-        subsampling_grad=sub_grad, subsampling_ggn=sub_ggn, mc_samples_ggn=mc, warn_small_eigvals=0.0
+        subsampling_grad=sub_grad, subsampling_ggn=sub_ggn, mc_samples_ggn=mc, warn_small_eigvals=0.0,
+        factorised=factorised,
     )
     exts = comp.get_extensions()
     if mc:

@@ -130,6 +130,104 @@ def _worker_batch_sharded(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _worker_dp_newton(rank, world, port, ret):
+    """DirectionalDampedNewtonComputation(data_parallel=True): every rank back-propagates ITS batch shard; the step
+    (and gammas / lambdas) must equal the single-process result on the whole batch (oracle on autograd factors)."""
+    _setup(rank, world, port)
+    import vivit_amd
+    from helpers import constant_damping, top_k_criterion
+    from oracle import vivit_oracle as oracle
+    from torch import nn
+    from vivit_amd.backend import backpack, extend
+
+    ok = {}
+    for factorised in (False, True):
+        torch.manual_seed(0)
+        model = nn.Sequential(nn.Linear(7, 6), nn.ReLU(), nn.Linear(6, 5))
+        Ng = 3
+        N = Ng * world
+        X, y = torch.rand(N, 7), torch.randint(0, 5, (N,))
+        ref = nn.Sequential(nn.Linear(7, 6), nn.ReLU(), nn.Linear(6, 5))
+        ref.load_state_dict(model.state_dict())
+        S = oracle.loss_hessian_sqrt_exact(ref(X).detach(), "ce")
+        V_ref = oracle.sqrt_ggn_factors(ref, X, S, None)
+        g_ref = oracle.batch_grads(ref, X, y, nn.CrossEntropyLoss(), None)
+        crit = top_k_criterion(3, must_exceed=1e-4)
+        ref_steps = oracle.damped_newton_group(V_ref, g_ref, crit, constant_damping(1.0), N)
+        ref_gam, ref_lam = oracle.directional_derivatives_group(V_ref, g_ref, crit, N)
+
+        lo, hi = rank * Ng, (rank + 1) * Ng
+        for cls, check in ((vivit_amd.DirectionalDampedNewtonComputation, "step"),
+                           (vivit_amd.DirectionalDerivativesComputation, "dirs")):
+            m, lossf = extend(model), extend(nn.CrossEntropyLoss())
+            comp = cls(warn_small_eigvals=0.0, factorised=factorised, data_parallel=True)
+            group = {"params": list(m.parameters()), "criterion": crit, "damping": constant_damping(1.0)}
+            m.zero_grad()
+            loss = lossf(m(X[lo:hi]), y[lo:hi])         # the rank's own shard only
+            with backpack(*comp.get_extensions(), extension_hook=comp.get_extension_hook([group])):
+                loss.backward()
+            res = comp.get_result(group)
+            if check == "step":
+                good = all(torch.allclose(s_, r_, rtol=1e-3, atol=2e-5 * max(r_.abs().max().item(), 1e-2))
+                           for s_, r_ in zip(res, ref_steps))
+                flat = torch.cat([s_.reshape(-1) for s_ in res])
+                gathered = [torch.empty_like(flat) for _ in range(world)]
+                dist.all_gather(gathered, flat)
+                good = good and all(torch.equal(gathered[0], t) for t in gathered)   # replicated step
+            else:
+                gam, lam = res
+                good = (gam.shape == ref_gam.shape
+                        and torch.allclose(gam.abs(), ref_gam.abs(), rtol=1e-3, atol=1e-4 * ref_gam.abs().max().item())
+                        and torch.allclose(lam, ref_lam, rtol=1e-3, atol=1e-5 * ref_lam.abs().max().item()))
+            ok[f"{check}_{'fact' if factorised else 'mat'}"] = bool(good)
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def _worker_dp_linalg(rank, world, port, ret):
+    """EigvalshComputation / EighComputation(data_parallel=True) on batch shards == dense GGN of the whole batch."""
+    _setup(rank, world, port)
+    import vivit_amd
+    from oracle import vivit_oracle as oracle
+    from torch import nn
+    from vivit_amd.backend import backpack, extend
+
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Conv2d(2, 2, 2), nn.Flatten(), nn.Tanh(), nn.Linear(18, 4))
+    Ng = 3
+    N = Ng * world
+    X, y = torch.rand(N, 2, 4, 4), torch.randint(0, 4, (N,))
+    ref = nn.Sequential(nn.Conv2d(2, 2, 2), nn.Flatten(), nn.Tanh(), nn.Linear(18, 4))
+    ref.load_state_dict(model.state_dict())
+    ggn = oracle.dense_ggn(ref.double(), X.double(), "ce")
+    w_ref, Q_ref = torch.linalg.eigh(ggn)
+    lo, hi = rank * Ng, (rank + 1) * Ng
+    ok = {}
+
+    def run(comp, group):
+        m, lossf = extend(model), extend(nn.CrossEntropyLoss())
+        m.zero_grad()
+        loss = lossf(m(X[lo:hi]), y[lo:hi])
+        with backpack(comp.get_extension(), extension_hook=comp.get_extension_hook([group])):
+            loss.backward()
+        return comp.get_result(group)
+
+    params = list(model.parameters())
+    P = sum(p.numel() for p in params)
+    ev = run(vivit_amd.EigvalshComputation(data_parallel=True), {"params": params})
+    k = min(4 * N, P)
+    ok["eigvalsh"] = ev.shape == (4 * N,) and torch.allclose(ev[-k:].double(), w_ref[-k:], rtol=1e-4, atol=5e-6)
+    keep = lambda evals: [i for i, e in enumerate(evals) if e > 1e-4]  # noqa: E731
+    evals, evecs = run(vivit_amd.EighComputation(data_parallel=True, warn_small_eigvals=0.0), {"params": params, "criterion": keep})
+    K = evals.numel()
+    E = torch.cat([e.reshape(K, -1) for e in evecs], 1).double()
+    ok["eigh_vals"] = torch.allclose(evals.double(), w_ref[-K:], rtol=5e-4, atol=1e-5)
+    ok["eigh_resid"] = torch.allclose(E @ ggn, evals.double()[:, None] * E, rtol=1e-3, atol=2e-4)
+    ok["eigh_orth"] = torch.allclose(E @ E.T, torch.eye(K, dtype=torch.float64), atol=2e-3)
+    ret[rank] = {k_: bool(v) for k_, v in ok.items()}
+    dist.destroy_process_group()
+
+
 def _run(worker, world):
     port = 29000 + (os.getpid() % 2000) + world
     mgr = mp.Manager()
@@ -147,4 +245,16 @@ def test_sharded_gram_world2():
 def test_batch_sharded_gram(world):
     ret = _run(_worker_batch_sharded, world)
     for r in range(world):
+        assert r in ret and all(ret[r].values()), ret
+
+
+def test_data_parallel_newton_step_world2():
+    ret = _run(_worker_dp_newton, 2)
+    for r in range(2):
+        assert r in ret and all(ret[r].values()), ret
+
+
+def test_data_parallel_linalg_world2():
+    ret = _run(_worker_dp_linalg, 2)
+    for r in range(2):
         assert r in ret and all(ret[r].values()), ret

@@ -20,6 +20,8 @@ from vivit_amd import kernels
 from vivit_amd.utils.ggn import Vmp
 from vivit_amd.utils.gram import mVp, pairwise_dot
 
+DP_ROWS_MAX_COLUMNS = 4096  # data parallel: narrower materialised factors are all-gathered (block rows), wider ones
+                            # go through the all-to-all to parameter shards (vivit_amd.distributed.BatchShardedGram)
 _LOSSES = (nn.CrossEntropyLoss, nn.MSELoss)
 _BATCHNORM = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
 
@@ -249,10 +251,17 @@ def _materialised_closures(V_t: Tensor):
     def gram_mat(out=None, beta=0.0):
         return pairwise_dot(V_t, start_dim=2, flatten=False, out=out, beta=beta)
 
+    def dp_add(acc):  # data parallel: this rank's rows of V_t into a vivit_amd.distributed.BatchShardedGram
+        if V_t[0, 0].numel() < DP_ROWS_MAX_COLUMNS:
+            acc.add_factor_rows(V_t)
+        else:
+            acc.add_factor(V_t)
+
     return {
         "V_mat_prod": lambda mat: Vmp(V_t, mat, 2),
         "V_t_mat_prod": lambda mat: mVp(V_t, mat, 2),
         "gram_mat": gram_mat,
+        "dp_add": dp_add,
         # explicit factor [C, N, *param] and its leading shape: used when the parameter side of a group is the
         # smaller one (vivit_amd.linalg.utils.parameter_side_symeig)
         "factor": lambda: V_t,
@@ -291,7 +300,7 @@ def _linear_weight_closures(s: Tensor, z: Tensor):
         return torch.einsum("cno,ni->cnoi", s, z)
 
     return {"V_mat_prod": V_mat_prod, "V_t_mat_prod": V_t_mat_prod, "gram_mat": gram_mat, "factor": factor,
-            "shape_cn": (C, N)}
+            "shape_cn": (C, N), "dp_add": lambda acc: acc.add_linear(s, z)}
 
 
 class _ViViTGGN(_SqrtGGN):

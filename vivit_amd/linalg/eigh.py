@@ -35,11 +35,19 @@ class EighComputation:
         verbose: bool = False,
         warn_small_eigvals: float = 1e-4,
         side: str = "gram",
+        data_parallel: bool = False,
+        process_group=None,
     ):
         """``side`` (not in the reference): ``"auto"`` solves a group on its parameter side (``P x P``, eigenvectors
-        directly in parameter space) when it has fewer parameters than Gram rows; ``"gram"`` = reference path."""
+        directly in parameter space) when it has fewer parameters than Gram rows; ``"gram"`` = reference path.
+        ``data_parallel`` / ``process_group`` (not in the reference): batch-sharded ranks, see
+        :class:`vivit_amd.linalg.EigvalshComputation`; the back-projection ``V e`` is summed over the ranks'
+        samples with one all-reduce of ``K P`` floats."""
         check_subsampling_unique(subsampling)
         use_parameter_side([], 1, side)  # validates ``side``
+        if data_parallel and side != "gram":
+            raise ValueError("data_parallel needs side='gram'")
+        self._dp = {"group": process_group} if data_parallel else None
         self._side = side
         self._subsampling = subsampling
         self._mc_samples = mc_samples
@@ -95,7 +103,7 @@ class EighComputation:
     def get_group_hook(self) -> Callable[[ParameterGroupsHook, None, Dict[str, Any]], None]:
         batch_sizes, subsampling, savefield = self._batch_size, self._subsampling, self._savefield
         evals, evecs, verbose = self._evals, self._evecs, self._verbose
-        warn_small_eigvals, side = self._warn_small_eigvals, self._side
+        warn_small_eigvals, side, dp = self._warn_small_eigvals, self._side, self._dp
         small_warning = (
             "Some eigenvectors have small eigenvalues."
             + " Their parameter space transformation is numerically unstable."
@@ -140,17 +148,27 @@ class EighComputation:
                 return
 
             # Gram matrix, accumulated over the group's parameters inside the kernel (eigh.py:239-242)
-            gram_mat = None
-            for param in group["params"]:
-                gram_fn = get_closures(param, savefield)["gram_mat"]
-                gram_mat = gram_fn() if gram_mat is None else gram_fn(out=gram_mat, beta=1.0)
+            gram_mat, acc = None, None
+            if dp is not None:  # batch-sharded ranks: assemble the global Gram matrix (collectives inside)
+                from vivit_amd.distributed import BatchShardedGram, all_reduce_sum_
+
+                acc = BatchShardedGram(C, N, dp["group"])
+                for param in group["params"]:
+                    get_closures(param, savefield)["dp_add"](acc)
+                gram_mat = acc.finalize()
+            else:
+                for param in group["params"]:
+                    gram_fn = get_closures(param, savefield)["gram_mat"]
+                    gram_mat = gram_fn() if gram_mat is None else gram_fn(out=gram_mat, beta=1.0)
             C, N = gram_mat.shape[:2]
 
             # two launches around the criterion callback: reduction + all eigenvalues, then only the kept eigenvectors
             # (inverse iteration + back-transformation of K rows; the reference computes all n and slices, eigh.py:248-253)
             plan = kernels.symeig_reduce(reshape_as_square(gram_mat), overwrite=True)
             gram_evals = plan.evals
-            if subsampling is not None:  # eigh.py:245-246; eigenvectors are scale invariant
+            if acc is not None:  # mean over the global batch (covers sub-sampling), see EigvalshComputation
+                gram_evals *= batch_size / acc.N
+            elif subsampling is not None:  # eigh.py:245-246; eigenvectors are scale invariant
                 gram_evals *= batch_size / len(subsampling)
 
             keep = group["criterion"](gram_evals)
@@ -164,8 +182,13 @@ class EighComputation:
             gram_evecs = gram_evecs.transpose(0, 1).reshape(-1, C, N)
 
             group_evecs = []
+            if acc is not None:  # every rank applies the rows of V it owns; one all-reduce per parameter sums them
+                gram_evecs = acc.local_samples(gram_evecs, 2).contiguous()
             for param in group["params"]:
-                group_evecs.append(get_closures(param, savefield)["V_mat_prod"](gram_evecs))
+                vecs = get_closures(param, savefield)["V_mat_prod"](gram_evecs)
+                if acc is not None:
+                    vecs = all_reduce_sum_(vecs.contiguous(), acc.group)
+                group_evecs.append(vecs)
                 delete_savefield(param, savefield, verbose=verbose)
             normalize(group_evecs)
 

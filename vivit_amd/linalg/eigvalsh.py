@@ -27,11 +27,18 @@ class EigvalshComputation:
     in place into the group's ``[n, n]`` Gram (beta = 1), then one values-only ``symeig``.
     """
 
-    def __init__(self, subsampling: List[int] = None, mc_samples: int = 0, verbose: bool = False, side: str = "gram"):
+    def __init__(self, subsampling: List[int] = None, mc_samples: int = 0, verbose: bool = False, side: str = "gram",
+                 data_parallel: bool = False, process_group=None):
         """``side`` (not in the reference): ``"auto"`` solves a group on its parameter side (``P x P``) when it has
-        fewer parameters than Gram rows, ``"gram"`` always decomposes the Gram matrix like the reference."""
+        fewer parameters than Gram rows, ``"gram"`` always decomposes the Gram matrix like the reference.
+        ``data_parallel`` / ``process_group`` (not in the reference): every rank back-propagated ITS batch shard; the
+        Gram matrix of the global batch is assembled across ranks (vivit_amd.distributed.BatchShardedGram), the
+        eigenvalues are those of the GGN of the mean loss over the global batch, identical on every rank."""
         check_subsampling_unique(subsampling)
         use_parameter_side([], 1, side)  # validates ``side``
+        if data_parallel and side != "gram":
+            raise ValueError("data_parallel needs side='gram'")
+        self._dp = {"group": process_group} if data_parallel else None
         self._side = side
         self._subsampling = subsampling
         self._mc_samples = mc_samples
@@ -73,7 +80,7 @@ class EigvalshComputation:
         return extension_hook
 
     def get_param_computation(self) -> Callable[[ParameterGroupsHook, Parameter], Tensor]:
-        verbose, savefield, side = self._verbose, self._savefield, self._side
+        verbose, savefield, side, dp = self._verbose, self._savefield, self._side, self._dp
 
         def param_computation(self: ParameterGroupsHook, param: Parameter):
             """Gram of this parameter, added in-kernel to the group accumulator if there is one.
@@ -87,6 +94,13 @@ class EigvalshComputation:
                 return [param]
             gram_fn = closures["gram_mat"]
             existing = self.current_accumulation(param)
+            if dp is not None:  # batch-sharded factors: block rows / parameter shards, assembled in the group hook
+                from vivit_amd.distributed import BatchShardedGram
+
+                acc = existing if existing is not None else BatchShardedGram(C, N, dp["group"])
+                closures["dp_add"](acc)
+                delete_savefield(param, savefield, verbose=verbose)
+                return acc
             if existing is None:
                 gram = gram_fn()
             else:
@@ -102,7 +116,9 @@ class EigvalshComputation:
             if isinstance(existing, list):  # parameter-side group: collect the parameters
                 return existing + update
             # ``update`` already is ``existing`` (+= done by the kernel's beta = 1) on the fused path
-            return update if update is existing else existing.add_(update)
+            if update is existing:
+                return update
+            return existing.add_(update)
 
         return accumulate
 
@@ -115,17 +131,22 @@ class EigvalshComputation:
             if verbose:
                 print(f"Group {group_id}: Delete 'batch_size'")
             batch_size = batch_sizes.pop(group_id)
+            scale = None if subsampling is None else batch_size / len(subsampling)  # eigvalsh.py:217-219
             if isinstance(accumulation, list):  # parameter side: P x P block of the GGN, zero-padded spectrum
                 gram_evals, _, _ = parameter_side_symeig(group["params"], savefield, eigenvectors=False)
                 for param in accumulation:
                     delete_savefield(param, savefield, verbose=verbose)
             else:
+                if not isinstance(accumulation, Tensor):  # data-parallel accumulator: assemble (collectives inside)
+                    # each rank's factors carry 1/sqrt(N_local); N_local / N_ggn(global) turns the sum into the GGN of
+                    # the mean loss over the global batch (covers sub-sampling: len(subsampling) x ranks = N_ggn)
+                    scale = batch_size / accumulation.N
+                    accumulation = accumulation.finalize()
                 gram_mat = reshape_as_square(accumulation)
                 gram_evals, _ = kernels.symeig(gram_mat, eigenvectors=False, overwrite=True)
-            # scale fix for curvature sub-sampling (eigvalsh.py:217-219); eigenvalues are
-            # homogeneous of degree one, so the O(n) vector is scaled instead of the n x n Gram
-            if subsampling is not None:
-                gram_evals *= batch_size / len(subsampling)
+            # eigenvalues are homogeneous of degree one: the O(n) vector is scaled instead of the n x n Gram
+            if scale is not None:
+                gram_evals *= scale
             if verbose:
                 print(f"Group {group_id}: Store 'gram_evals'")
             evals[group_id] = gram_evals

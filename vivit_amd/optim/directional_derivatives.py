@@ -140,10 +140,13 @@ def gram_space_directions(accumulation: Dict[str, Tensor], group: Dict, N: int, 
     """
     group_id = id(group)
     dp_acc = accumulation.pop("dp_acc", None)
-    if dp_acc is not None:  # data parallel: assemble the batch-sharded sums (collectives), N is the global batch size
+    if dp_acc is not None:
+        # data parallel: assemble the batch-sharded sums (collectives).  ``N`` stays the LOCAL batch size -- it only
+        # compensates the 1/sqrt(N) and 1/N that this rank's backward pass put into V and g -- while N_ggn below
+        # becomes the global number of curvature samples, so V_correction = sqrt(N_local / N_ggn_global) turns the
+        # sums into those of the mean loss over the global batch.
         V_t_V = dp_acc.finalize()
         accumulation["V_t_g_n"] = dp_acc.finalize_vtg()
-        N = N * dp_acc.R
     else:
         V_t_V = accumulation.pop("V_t_V")
     C, N_ggn = V_t_V.shape[0], V_t_V.shape[1]

@@ -58,10 +58,52 @@ def make_problem(name):
         bn.bias.data.uniform_(-0.5, 0.5)
         model = nn.Sequential(bn, nn.Flatten(), nn.Linear(24, 3)).eval()
         X, y, lossf, loss = torch.rand(3, 2, 4, 3), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "branching_ce":  # test/settings.py:161-181: Pad / Parallel(Identity, Linear + Slicing) skip connection
+        from vivit_amd.backend import Pad, Parallel, Slicing
+
+        model = nn.Sequential(
+            nn.Linear(7, 4), nn.ReLU(), Pad((1, 1), mode="constant", value=0.5),
+            Parallel(nn.Identity(), nn.Sequential(nn.Linear(6, 8), Slicing((slice(None), slice(0, 6))))),
+            nn.Sigmoid(), nn.Linear(6, 4))
+        X, y, lossf, loss = torch.rand(3, 7), torch.randint(0, 4, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "resblock_ce":  # a CIFAR-ResNet basic block with the option-A shortcut (subsample + zero-pad channels)
+        from vivit_amd.backend import ActiveIdentity, Pad, Parallel, Slicing
+
+        def bn(c):
+            m = nn.BatchNorm2d(c)
+            m.running_mean.uniform_(-0.5, 0.5)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.5, 0.5)
+            return m
+
+        model = nn.Sequential(
+            nn.Conv2d(3, 2, 3, padding=1, bias=False), bn(2), nn.ReLU(),
+            Parallel(ActiveIdentity(), nn.Sequential(nn.Conv2d(2, 2, 3, padding=1, bias=False), bn(2), nn.ReLU(),
+                                                     nn.Conv2d(2, 2, 3, padding=1, bias=False), bn(2))),
+            nn.ReLU(),
+            Parallel(nn.Sequential(Slicing((slice(None), slice(None), slice(None, None, 2), slice(None, None, 2))),
+                                   Pad((0, 0, 0, 0, 1, 1))),
+                     nn.Sequential(nn.Conv2d(2, 4, 3, stride=2, padding=1, bias=False), bn(4), nn.ReLU(),
+                                   nn.Conv2d(4, 4, 3, padding=1, bias=False), bn(4))),
+            nn.ReLU(), nn.AvgPool2d(3), nn.Flatten(), nn.Linear(4, 3)).eval()
+        X, y, lossf, loss = torch.rand(3, 3, 6, 6), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "conv1d_mse":  # vivit/extensions/secondorder/vivit/convnd.py:9-14
+        model = nn.Sequential(nn.Conv1d(2, 3, 2, stride=2), nn.Tanh(), nn.ConvTranspose1d(3, 2, 2), nn.Flatten(),
+                              nn.Linear(8, 2))
+        X, y, lossf, loss = torch.rand(3, 2, 6), torch.rand(3, 2), nn.MSELoss(), "mse"
+    elif name == "conv3d_ce":  # convnd.py:25-30, with groups
+        model = nn.Sequential(nn.Conv3d(2, 4, 2, groups=2), nn.Sigmoid(), nn.Flatten(), nn.Linear(32, 3))
+        X, y, lossf, loss = torch.rand(3, 2, 3, 3, 3), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "convtranspose_ce":  # vivit/extensions/secondorder/vivit/convtransposend.py:9-30
+        model = nn.Sequential(nn.ConvTranspose2d(2, 3, 2, stride=2, output_padding=1), nn.Tanh(), nn.Flatten(),
+                              nn.Linear(75, 3))
+        X, y, lossf, loss = torch.rand(3, 2, 2, 2), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
     return model, X, y, lossf, loss
 
 
-PROBLEMS = ["mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce"]
+PROBLEMS = ["mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce", "branching_ce", "resblock_ce",
+            "conv1d_mse", "conv3d_ce", "convtranspose_ce"]
 
 
 def run_backward(model, X, y, lossf, extensions, hook=None):

@@ -189,3 +189,51 @@ def test_config5_wide_mlp_factorised_newton_step():
     gs = (g.double() @ s.double()).item()
     target = -(gam.double().mean(0) ** 2 / (lam.double().mean(0) + 1.0)).sum().item()
     assert gs < 0 and abs(gs - target) <= 5e-3 * abs(target)
+
+
+@pytest.mark.parametrize("N", [8, 1024])
+def test_config4_resnet32_mc(N):
+    """Config 4: ResNet-32, CIFAR-100-shaped (C = 100), BatchNorm in eval mode, residual adds, SqrtGGN-MC with one
+    sample => n = N, P = 470 004.  N = 8: the Gram matrix against brute-force autograd (per-sample Jacobian rows of the
+    MC factor); N = 1024 (BASELINE): eigenpairs against autograd MC-GGN-vector products, all eigenvalues two ways."""
+    from helpers import resnet32
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = resnet32(100).to(dev)
+    params = list(model.parameters())
+    assert sum(p.numel() for p in params) == 470004
+    X, y = torch.rand(N, 3, 32, 32, device=dev), torch.randint(0, 100, (N,), device=dev)
+    with torch.no_grad():
+        probs = model(X).softmax(1)
+        idx = torch.multinomial(probs, 1, replacement=True, generator=torch.Generator(device=dev).manual_seed(2))
+        samples = torch.nn.functional.one_hot(idx.t(), 100).float()           # [1, N, C]
+
+    def run(comp, group):
+        model.zero_grad()
+        m, lossf = extend(model), extend(nn.CrossEntropyLoss())
+        ext = comp.get_extension()
+        ext._samples = samples
+        loss = lossf(m(X), y)
+        with backpack(ext, extension_hook=comp.get_extension_hook([group])):
+            loss.backward()
+        return comp.get_result(group)
+
+    K = min(10, N)
+    evals, evecs = run(vivit_amd.EighComputation(mc_samples=1), {"params": params, "criterion": top_k(K)})
+    assert evals.shape == (K,) and evals[0].item() > 0
+    check_eigenpairs(model, "ce", X, params, evals, evecs, samples=samples, rtol=5e-3)
+    all_evals = run(vivit_amd.EigvalshComputation(mc_samples=1), {"params": params})
+    assert all_evals.shape == (N,)
+    assert (all_evals[-K:] - evals).abs().max().item() <= 1e-4 * evals[-1].item()
+    if N <= 8:
+        # brute force: V_t[0, n, :] = S[0, n, :] J_n, row by row with autograd; Gram spectrum must match
+        out = model(X)
+        S = ((out.softmax(1).detach().unsqueeze(0) - samples) / math.sqrt(N))[0]   # [N, C]
+        rows = []
+        for n_ in range(N):
+            grads = torch.autograd.grad((out[n_] * S[n_]).sum(), params, retain_graph=True)
+            rows.append(torch.cat([g.reshape(-1) for g in grads]))
+        A = torch.stack(rows).double()
+        ref = torch.linalg.eigvalsh(A @ A.T)
+        assert (all_evals.double() - ref).abs().max().item() <= 1e-4 * ref[-1].item()

@@ -71,13 +71,20 @@ def _make_output_hook(module: Module):
 
 def _forward_hook(module: Module, inputs, output):
     if not torch.is_grad_enabled() or not isinstance(output, torch.Tensor) or not output.requires_grad:
-        return
+        return None
+    replaced = None
+    if any(output is t for t in inputs):
+        # a module that hands its input through (nn.Identity, Dropout in eval mode): give the output its own identity,
+        # otherwise the producer of that tensor would see its hook fire before this module contributed
+        output = replaced = output.view_as(output)
     # what BackPACK stores for its extensions (vivit/linalg/utils.py:54 reads ``input0``)
     module.input0 = inputs[0]
     if len(inputs) > 1:
         module.input1 = inputs[1]
+    module.inputs = tuple(inputs)
     module.output = output
     output.register_hook(_make_output_hook(module))
+    return replaced
 
 
 def extend(module: Module) -> Module:

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from vivit_amd import kernels
+from vivit_amd.backend.custom_module import SumModule
 from vivit_amd.utils.ggn import Vmp
 from vivit_amd.utils.gram import mVp, pairwise_dot
 
@@ -24,6 +25,7 @@ DP_ROWS_MAX_COLUMNS = 4096  # data parallel: narrower materialised factors are a
                             # go through the all-to-all to parameter shards (vivit_amd.distributed.BatchShardedGram)
 _LOSSES = (nn.CrossEntropyLoss, nn.MSELoss)
 _BATCHNORM = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
+_CONVS = (nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.ConvTranspose1d, nn.ConvTranspose2d, nn.ConvTranspose3d)
 
 
 def subsample(tensor: Tensor, dim: int = 0, subsampling: Optional[List[int]] = None) -> Tensor:
@@ -93,14 +95,14 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
         if M.dim() == 3:
             return torch.einsum("vno,ni->vnoi", M, x)
         return torch.einsum("vnao,nai->vnoi", M.flatten(2, -2), x.flatten(1, -2))
-    if isinstance(module, nn.Conv2d):
+    if isinstance(module, _CONVS):
         if name == "bias":
             return M.flatten(3).sum(3)
-        if module.groups != 1:
-            raise NotImplementedError("grouped convolutions are not supported by the stand-in backend")
-        xu = F.unfold(x, module.kernel_size, dilation=module.dilation, padding=module.padding, stride=module.stride)
-        out = torch.einsum("vnol,nkl->vnok", M.flatten(3), xu)
-        return out.reshape(*M.shape[:2], *module.weight.shape)
+        if isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple):
+            xu = F.unfold(x, module.kernel_size, dilation=module.dilation, padding=module.padding, stride=module.stride)
+            out = torch.einsum("vnol,nkl->vnok", M.flatten(3), xu)
+            return out.reshape(*M.shape[:2], *module.weight.shape)
+        return _conv_weight_factor(module, M, x)
     if isinstance(module, _BATCHNORM):
         if module.training:
             raise NotImplementedError("BatchNorm must be in eval mode (as in the reference tests)")
@@ -110,6 +112,31 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
         xhat = (x - module.running_mean.view(shape)) / torch.sqrt(module.running_var.view(shape) + module.eps)
         return _spatial_sum(M * xhat.unsqueeze(0), 3)
     raise NotImplementedError(f"no parameter rule for {type(module).__name__}")
+
+
+_CONV_FN = {nn.Conv1d: F.conv1d, nn.Conv2d: F.conv2d, nn.Conv3d: F.conv3d, nn.ConvTranspose1d: F.conv_transpose1d,
+            nn.ConvTranspose2d: F.conv_transpose2d, nn.ConvTranspose3d: F.conv_transpose3d}
+
+
+def _conv_weight_factor(module, M: Tensor, x: Tensor) -> Tensor:
+    """Weight rule of the convolution family (Conv1d/3d, grouped Conv2d, ConvTranspose1d/2d/3d; the derivative classes
+    of vivit/extensions/secondorder/vivit/convnd.py:9-30 and convtransposend.py:9-30): per sample ``n`` and slice ``v``
+    the vector-Jacobian product of the functional convolution w.r.t. its weight, batched with ``torch.func.vmap``."""
+    from torch.func import vjp, vmap
+
+    fn = _CONV_FN[type(module)]
+    kw = dict(stride=module.stride, padding=module.padding, dilation=module.dilation, groups=module.groups)
+    if isinstance(module, (nn.ConvTranspose1d, nn.ConvTranspose2d, nn.ConvTranspose3d)):
+        kw["output_padding"] = module.output_padding
+    if getattr(module, "padding_mode", "zeros") != "zeros":
+        raise NotImplementedError("only zero padding is supported by the stand-in backend")
+    weight = module.weight.detach()
+
+    def single(xn, mvn):  # xn: [*in], mvn: [*out]
+        _, pull = vjp(lambda w: fn(xn.unsqueeze(0), w, None, **kw).squeeze(0), weight)
+        return pull(mvn)[0]
+
+    return vmap(vmap(single, in_dims=(0, 0)), in_dims=(None, 0))(x, M)
 
 
 def _jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Tensor:
@@ -216,6 +243,11 @@ class _SqrtGGN(_Extension):
             return
         M = ctx.pop(self, module.output)
         if M is None:
+            return
+        if isinstance(module, SumModule):  # identity Jacobian w.r.t. every summand (SqrtGGNSumModule)
+            for inp in module.inputs:
+                if inp.requires_grad:
+                    ctx.put(self, inp, M)
             return
         x = subsample(module.input0.detach(), 0, sub)
         for name, p in _own_params(module):

@@ -249,7 +249,7 @@ def _tune_threads():
     return best, table
 
 
-def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), repeats=3):
+def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), eig_batches=(256, 512), repeats=3):
     """The oracle (CPU restatement of the reference algorithm) timed on this host on a bounded sample, both flavours
     the reference has for this MLP, never mixed:
       materialised -- einsum Gram over every parameter with the full 2 n^2 P work (vivit/utils/gram.py:230-232,
@@ -257,25 +257,18 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), repeats=3):
         Tensor.symeig (vivit/linalg/eigh.py:248-250);
       factorised   -- the Linear fast path of ViViTGGNExact (vivit/extensions/secondorder/vivit/linear.py:72-75) for
         the weights + materialised biases, then the same eigh.
-    Median of ``repeats`` after one warm-up at two batch sizes; the exponent of each phase is FITTED from the two sizes
-    and used to extrapolate to the full n (stated in ``sample``).  Thread count tuned first (``_tune_threads``)."""
+    Median of ``repeats`` after one warm-up; the einsum Gram is timed at ``batches`` (it is the expensive phase of the
+    sample: 2 n^2 P flop), eigh/eigvalsh at the larger ``eig_batches`` (on the same MLP's Gram matrix, built with the
+    factorised form) because LAPACK only approaches its n^3 regime there.  The exponent of each phase is FITTED between
+    its two sizes (never steeper than the flop count) and used to extrapolate to the full n (stated in ``sample``).
+    Thread count tuned first (``_tune_threads``)."""
     from oracle import vivit_oracle as oracle
 
     threads, table = _tune_threads()
     _progress(f"cpu baseline: {threads} threads (probe {table})")
     cpu = torch.device("cpu")
-    rows = []
-    for bi, b in enumerate(batches):
-        facs = mlp_sqrt_ggn_factors(dims, b, cpu)
-        n = facs[0].shape[0]
-        V = [f.view(C, b, -1) for f in facs]
-        # (the warm-up run is only needed once per process: thread pool, allocator)
-        t_gram = _median_time(lambda: oracle.compute_gram_mat(V, start_dim=2, flatten=True), repeats, warm=bi == 0)
-        _progress(f"cpu baseline: batch {b} (n={n}) einsum Gram {t_gram:.2f} s")
-        gram = oracle.compute_gram_mat(V, start_dim=2, flatten=True)
-        del V, facs
-        fz = mlp_factorised_factors(dims, b, cpu)
 
+    def fact_gram_fn(fz):
         def fact_gram():
             G = None
             for s_, z_ in fz:
@@ -284,28 +277,39 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), repeats=3):
                 G = Gw + Gb if G is None else G + Gw + Gb
             return oracle.reshape_as_square(G)
 
-        t_fact = _median_time(fact_gram, repeats)
+        return fact_gram
+
+    gram_rows, eig_rows = [], []
+    for bi, b in enumerate(batches):
+        facs = mlp_sqrt_ggn_factors(dims, b, cpu)
+        n = facs[0].shape[0]
+        V = [f.view(C, b, -1) for f in facs]
+        # (the warm-up run is only needed once per process: thread pool, allocator)
+        t_gram = _median_time(lambda: oracle.compute_gram_mat(V, start_dim=2, flatten=True), repeats, warm=bi == 0)
+        del V, facs
+        t_fact = _median_time(fact_gram_fn(mlp_factorised_factors(dims, b, cpu)), repeats)
+        _progress(f"cpu baseline: batch {b} (n={n}) einsum Gram {t_gram:.2f} s, factorised Gram {t_fact:.3f} s")
+        gram_rows.append({"batch": b, "n": n, "gram_materialised_s": t_gram, "gram_factorised_s": t_fact})
+    for b in eig_batches:
+        gram = fact_gram_fn(mlp_factorised_factors(dims, b, cpu))()
+        n = gram.shape[0]
         t_eig = _median_time(lambda: oracle.tensor_symeig(gram, eigenvectors=True), repeats)
         t_eigv = _median_time(lambda: oracle.tensor_symeig(gram, eigenvectors=False), repeats)
-        _progress(f"cpu baseline: batch {b} factorised Gram {t_fact:.3f} s, eigh {t_eig:.2f} s, eigvalsh {t_eigv:.2f} s")
-        rows.append({"batch": b, "n": n, "gram_materialised_s": t_gram, "gram_factorised_s": t_fact, "eigh_s": t_eig,
-                     "eigvalsh_s": t_eigv})
-        del gram, fz
-    a, b_ = rows[0], rows[-1]
-    ratio = math.log(b_["n"] / a["n"])
+        _progress(f"cpu baseline: batch {b} (n={n}) eigh {t_eig:.2f} s, eigvalsh {t_eigv:.2f} s")
+        eig_rows.append({"batch": b, "n": n, "eigh_s": t_eig, "eigvalsh_s": t_eigv})
+        del gram
 
-    def fit(key):
-        return math.log(b_[key] / a[key]) / ratio if len(rows) > 1 and a[key] > 0 else None
-
-    def extrap(key, textbook):
-        e = fit(key)
-        e = textbook if e is None else min(e, textbook)  # never extrapolate steeper than the flop count
+    def extrap(rows, key, textbook):
+        a, b_ = rows[0], rows[-1]
+        e = textbook
+        if len(rows) > 1 and a[key] > 0:
+            e = min(math.log(b_[key] / a[key]) / math.log(b_["n"] / a["n"]), textbook)  # never steeper than the flop count
         return b_[key] * (full_n / b_["n"]) ** e, e
 
-    tg, eg = extrap("gram_materialised_s", 2.0)
-    tf, ef = extrap("gram_factorised_s", 2.0)
-    te, ee = extrap("eigh_s", 3.0)
-    tv, ev_ = extrap("eigvalsh_s", 3.0)
+    tg, eg = extrap(gram_rows, "gram_materialised_s", 2.0)
+    tf, ef = extrap(gram_rows, "gram_factorised_s", 2.0)
+    te, ee = extrap(eig_rows, "eigh_s", 3.0)
+    tv, ev_ = extrap(eig_rows, "eigvalsh_s", 3.0)
     value = full_n / (tg + te)
     return {
         "value": value,
@@ -314,17 +318,15 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), repeats=3):
         "kind": "port",
         "cpu_model": _cpu_model(),
         "thread_probe_s": table,
-        "samples": rows,
+        "samples": {"gram": gram_rows, "eigh": eig_rows},
         "fitted_exponents": {"gram_materialised": eg, "gram_factorised": ef, "eigh": ee, "eigvalsh": ev_},
         "extrapolated_s": {"gram_materialised": tg, "gram_factorised": tf, "eigh": te, "eigvalsh": tv},
         "materialised_eigenpairs_per_s": value,
         "factorised_eigenpairs_per_s": full_n / (tf + te),
-        "measured_at_largest_sample": b_["n"] / (b_["gram_materialised_s"] + b_["eigh_s"]),
         "sample": (
-            f"same MLP at batch {[r['batch'] for r in rows]} (n={[r['n'] for r in rows]}, P={full_P}), median of {repeats} "
-            f"after a warm-up, {threads} threads ({_cpu_model()}): einsum Gram + torch.linalg.eigh; value = materialised "
-            f"line extrapolated to n={full_n} with the exponents fitted between the two sizes "
-            f"(Gram n^{eg:.2f}, eigh n^{ee:.2f})"
+            f"same MLP (P={full_P}), median of {repeats} after a warm-up, {threads} threads ({_cpu_model()}): einsum Gram at "
+            f"n={[r['n'] for r in gram_rows]}, torch.linalg.eigh at n={[r['n'] for r in eig_rows]}; value = materialised line "
+            f"extrapolated to n={full_n} with the exponents fitted between the two sizes (Gram n^{eg:.2f}, eigh n^{ee:.2f})"
         ),
     }
 
@@ -396,7 +398,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity check after the timed loop")
     ap.add_argument("--no-secondary", action="store_true", help="skip the values-only / top-10 secondary lines")
-    ap.add_argument("--cpu-batches", default="128,256", help="batch sizes of the CPU baseline sample")
+    ap.add_argument("--cpu-batches", default="128,256", help="batch sizes of the CPU baseline's einsum-Gram sample")
+    ap.add_argument("--cpu-eig-batches", default="256,512", help="batch sizes of the CPU baseline's eigh sample")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -645,7 +648,8 @@ def main():
         if secondary_lines is not None:
             out["secondary"] = secondary_lines
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dims, C, n, P_total, batches=tuple(min(int(b), batch) for b in args.cpu_batches.split(",")))
+            out["cpu_baseline"] = cpu_baseline(dims, C, n, P_total, batches=tuple(min(int(b), batch) for b in args.cpu_batches.split(",")),
+                                               eig_batches=tuple(min(int(b), batch) for b in args.cpu_eig_batches.split(",")))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

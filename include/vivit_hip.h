@@ -114,6 +114,22 @@ int vivit_class_expand_f32(const float *s, const float *U, float *R, int64_t F, 
                            void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Factor materialisation (f1): per-sample parameter Jacobian-transpose products, the `param_mjp(..., sum_batch=False)`
+ * call of vivit/extensions/secondorder/vivit/base.py:84-92 (BackPACK LinearDerivatives / Conv2DDerivatives).
+ *   vivit_linear_weight_mjp_f32: V[(c,n), o, i] = s[(c,n), o] * z[n, i]       s: [C*N, O], z: [N, I], V: [C*N, O*I]
+ *     (einsum "vno,ni->vnoi"; what linear.py:41-42 keeps factorised, materialised for SqrtGGN{Exact,MC} / BatchGrad)
+ *   vivit_conv2d_weight_mjp_f32: V[r, o, c, kh, kw] = sum_{oh,ow} M[r, o, oh, ow] * x[r % N, c, oh*sh-ph+kh*dh, ow*sw-pw+kw*dw]
+ *     M: [rows, Cout, OH, OW], x: [N, Cin, H, W], V: [rows, Cout*Cin*KH*KW]; rows = C*N (class-major), groups = 1,
+ *     zero padding (unfold + einsum "vnol,nkl->vnok" without the im2col buffer).
+ * Both are bound by the 4*rows*P bytes they write.
+ * ------------------------------------------------------------------------------------------- */
+int vivit_linear_weight_mjp_f32(const float *s, const float *z, float *V, int64_t C, int64_t N, int64_t O, int64_t I,
+                                void *stream);
+int vivit_conv2d_weight_mjp_f32(const float *M, const float *x, float *V, int64_t rows, int64_t N, int64_t Cin, int64_t H,
+                                int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int64_t sh,
+                                int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K3/K4  Symmetric eigendecomposition (Householder tridiagonalisation + implicit-shift QL,
  * divide-and-conquer merges above the single-workgroup size).
  *   A: [n, n] symmetric, lda >= n.  DESTROYED (holds the Householder reflectors on return).

@@ -98,6 +98,14 @@ class OracleBackend:
     def class_expand(self, s, U):
         return torch.einsum("cno,von->vcn", s, U).contiguous()
 
+    def linear_weight_mjp(self, s, z):
+        return torch.einsum("vno,ni->vnoi", s, z)
+
+    def conv2d_weight_mjp(self, M, x, kernel_size, stride, padding, dilation):
+        xu = torch.nn.functional.unfold(x, kernel_size, dilation=dilation, padding=padding, stride=stride)
+        out = torch.einsum("vnol,nkl->vnok", M.flatten(3), xu)
+        return out.reshape(*M.shape[:3], x.shape[1], *kernel_size)
+
     def symeig(self, G, eigenvectors=False, overwrite=False):
         from oracle import vivit_oracle as oracle
 

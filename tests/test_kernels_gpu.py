@@ -1,4 +1,5 @@
 """GPU parity of the raw kernels (through the C ABI) against fp64 references computed on the host."""
+import numpy as np
 import pytest
 import torch
 
@@ -193,3 +194,38 @@ def test_backproject_skinny(K, n, P):
     assert _rel(Cd, -0.5 * ref + 2.0 * C0.double()) < tol
     out2 = kernels.gemm_nn(E.to(_dev()), V.to(_dev()))
     assert torch.equal(out, out2), "fixed-order slab reduction must be bit-reproducible"
+
+
+@pytest.mark.parametrize("C,N,O,I", [(3, 5, 7, 9), (10, 64, 16, 32), (1, 33, 5, 12)])
+def test_linear_weight_mjp(C, N, O, I):
+    from vivit_amd import kernels
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C * N)
+    s, z = torch.randn(C, N, O, generator=g), torch.randn(N, I, generator=g)
+    V = kernels.linear_weight_mjp(s.to(dev), z.to(dev))
+    assert torch.equal(V.cpu(), torch.einsum("vno,ni->vnoi", s, z))       # one multiply per entry: bit-exact
+
+
+@pytest.mark.parametrize("geom", [
+    # (V, N, Cin, H, W, Cout, k, stride, padding, dilation)
+    (2, 3, 3, 8, 8, 2, (2, 2), (1, 1), (0, 0), (1, 1)),
+    (10, 4, 3, 32, 32, 6, (5, 5), (1, 1), (0, 0), (1, 1)),        # LeNet conv1: 784 output positions (> one LDS chunk)
+    (1, 5, 16, 16, 16, 32, (3, 3), (2, 2), (1, 1), (1, 1)),       # ResNet stage transition
+    (3, 2, 4, 9, 7, 5, (3, 2), (2, 1), (2, 0), (2, 3)),           # everything odd
+])
+def test_conv2d_weight_mjp(geom):
+    from vivit_amd import kernels
+
+    Vd, N, Cin, H, W, Cout, k, stride, padding, dilation = geom
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(geom[:6]))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    OH = (H + 2 * padding[0] - dilation[0] * (k[0] - 1) - 1) // stride[0] + 1
+    OW = (W + 2 * padding[1] - dilation[1] * (k[1] - 1) - 1) // stride[1] + 1
+    M = torch.randn(Vd, N, Cout, OH, OW, generator=g)
+    out = kernels.conv2d_weight_mjp(M.to(dev), x.to(dev), k, stride, padding, dilation)
+    xu = torch.nn.functional.unfold(x.double(), k, dilation=dilation, padding=padding, stride=stride)
+    ref = torch.einsum("vnol,nkl->vnok", M.double().flatten(3), xu).reshape(Vd, N, Cout, Cin, *k)
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * ref.abs().max().item())

@@ -138,3 +138,33 @@ def test_symeig_large_nan_raises():
         kernels.symeig(S.to(DEV), eigenvectors=True)
     with pytest.raises(RuntimeError):
         kernels.symeig(S.to(DEV), eigenvectors=False)
+
+
+@pytest.mark.parametrize("n", [300, 850, 2416])
+def test_graded_tridiagonal_with_underflowing_tail(n):
+    """Divide & conquer leaves that lie in the numerically-zero part of the spectrum (entries down to the fp32 denormal
+    range, as the tridiagonal form of a rank-deficient P x P GGN block has them: LeNet-5 fc3 / conv2 at BASELINE
+    config 3 made 13 / 8 leaf eigenvalues 'not converge' before the deflation tolerance used the norm of the WHOLE
+    matrix) must converge, and the eigenpairs must match fp64 LAPACK."""
+    from vivit_amd import kernels
+
+    dev = torch.device("cuda:0")
+    i = torch.arange(n, dtype=torch.float64)
+    d = 10.0 ** (-i / 20.0)
+    e = 0.3 * torch.sqrt(d[:-1] * d[1:])
+    d32, e32 = d.float(), e.float()
+    w, Z = kernels.stedc(d32.to(dev), e32.to(dev), eigenvectors=True)
+    T = torch.diag(d32.double()) + torch.diag(e32.double(), 1) + torch.diag(e32.double(), -1)
+    ref = torch.linalg.eigvalsh(T)
+    assert (w.cpu().double() - ref).abs().max().item() <= 1e-6 * ref[-1].item()
+    Zd = Z.cpu().double()
+    assert (T @ Zd - Zd * w.cpu().double()).abs().max().item() <= 1e-5 * ref[-1].item()
+    assert (Zd.T @ Zd - torch.eye(n, dtype=torch.float64)).abs().max().item() <= 1e-4
+    # the same through the full solver (dense matrix with that spectrum, rank-deficient half)
+    g = torch.Generator().manual_seed(n)
+    Q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    lam = torch.cat([torch.zeros(n // 2, dtype=torch.float64), 10.0 ** (-torch.arange(n - n // 2, dtype=torch.float64) / 30.0)])
+    A = ((Q * lam) @ Q.T).float()
+    w2, Z2 = kernels.symeig(A.to(dev), eigenvectors=True)
+    ref2 = torch.linalg.eigvalsh(A.double())
+    assert (w2.cpu().double() - ref2).abs().max().item() <= 1e-5 * ref2[-1].item()

@@ -31,6 +31,8 @@ SIGNATURES = {
     "vivit_gram_hadamard_block_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _ptr]),
     "vivit_class_contract_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
     "vivit_class_expand_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
+    "vivit_linear_weight_mjp_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
+    "vivit_conv2d_weight_mjp_f32": (_int, [_ptr, _ptr, _ptr] + [_i64] * 16 + [_ptr]),
     "vivit_symeig_f32_workspace_bytes": (_sz, [_i64, _int]),
     "vivit_symeig_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
     "vivit_symeig_rows_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr, _sz, _ptr, _ptr]),

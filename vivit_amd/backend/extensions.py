@@ -93,15 +93,15 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
         if name == "bias":
             return M if M.dim() == 3 else M.flatten(2, -2).sum(2)
         if M.dim() == 3:
-            return torch.einsum("vno,ni->vnoi", M, x)
+            return kernels.linear_weight_mjp(M, x)           # "vno,ni->vnoi" (HIP store-stream kernel)
         return torch.einsum("vnao,nai->vnoi", M.flatten(2, -2), x.flatten(1, -2))
     if isinstance(module, _CONVS):
         if name == "bias":
             return M.flatten(3).sum(3)
-        if isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple):
-            xu = F.unfold(x, module.kernel_size, dilation=module.dilation, padding=module.padding, stride=module.stride)
-            out = torch.einsum("vnol,nkl->vnok", M.flatten(3), xu)
-            return out.reshape(*M.shape[:2], *module.weight.shape)
+        if (isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple)
+                and module.padding_mode == "zeros" and module.out_channels * 129 * 4 <= 64 * 1024):
+            # unfold + "vnol,nkl->vnok" in one HIP kernel (patch values gathered on the fly, no im2col buffer)
+            return kernels.conv2d_weight_mjp(M, x, module.kernel_size, module.stride, module.padding, module.dilation)
         return _conv_weight_factor(module, M, x)
     if isinstance(module, _BATCHNORM):
         if module.training:

@@ -48,9 +48,13 @@ __device__ __forceinline__ float block_max(float v, float *red, int tid) {
 // their null-space block is rounding noise of size eps * ||G|| on which a purely relative test
 // can stagnate in fp32, while the Householder stage has already committed a backward error of
 // that size, so nothing is lost.
-__device__ inline int ql_implicit(float *d, float *e, int n, float *z) {
+// `norm_floor`: a lower bound for the norm the absolute deflation tolerance is taken from.  A LEAF of a divide &
+// conquer tree must pass the norm of the WHOLE tridiagonal matrix: a leaf that lies in the numerically-zero part of a
+// rank-deficient spectrum has entries of 1e-20 ||T|| and below, its own norm is meaningless as a yardstick (and the
+// squares of such entries underflow in the rotations: 60 sweeps without progress, "did not converge").
+__device__ inline int ql_implicit(float *d, float *e, int n, float *z, float norm_floor = 0.f) {
   int nfail = 0;
-  float tn = 0.f;
+  float tn = norm_floor;
   for (int i = 0; i < n; ++i) tn = fmaxf(tn, fabsf(d[i]) + (i + 1 < n ? fabsf(e[i]) : 0.f));
   const float abs_tol = 0.5f * EPS32 * tn;
   for (int l = 0; l < n; ++l) {

@@ -125,8 +125,13 @@ __global__ __launch_bounds__(64) void dc_leaf_kernel(const float *__restrict__ d
     el[lane] = (lane < s - 1) ? e[lo + lane] : 0.f;
     for (int c = 0; c < s; ++c) Z[lane * (LEAF + 1) + c] = (c == lane) ? 1.f : 0.f;
   }
+  // norm of the whole tridiagonal matrix (fixed order: every leaf gets the same value)
+  float tn = 0.f;
+  for (int i = lane; i < n; i += 64) tn = fmaxf(tn, fabsf(d[i]) + (i + 1 < n ? fabsf(e[i]) : 0.f) + (i > 0 ? fabsf(e[i - 1]) : 0.f));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tn = fmaxf(tn, __shfl_xor(tn, off, 64));
   __syncthreads();
-  const int nfail = ql_implicit(dl, el, s, lane < s ? Z + lane * (LEAF + 1) : nullptr);
+  const int nfail = ql_implicit(dl, el, s, lane < s ? Z + lane * (LEAF + 1) : nullptr, tn);
   __syncthreads();
   // row c of Qt = eigenvector c = column c of Z
   for (int c = 0; c < s; ++c)

@@ -311,6 +311,44 @@ def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False,
     return w, Z
 
 
+@_launcher
+def linear_weight_mjp(s, z):
+    """``V_t[c,n,o,i] = s[c,n,o] z[n,i]`` materialised (``param_mjp`` of a Linear weight, einsum "vno,ni->vnoi")."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.linear_weight_mjp(s, z)
+    _require_device(s, z)
+    s, z = s.contiguous(), z.contiguous()
+    C, N, O = s.shape
+    if z.shape[0] != N:
+        raise ValueError(f"z must be [{N}, in], got {tuple(z.shape)}")
+    I = z.shape[1]
+    V = torch.empty((C, N, O, I), dtype=torch.float32, device=s.device)
+    st = _lib.load().vivit_linear_weight_mjp_f32(s.data_ptr(), z.data_ptr(), V.data_ptr(), C, N, O, I, _stream(s))
+    _lib.check(st, "vivit_linear_weight_mjp_f32")
+    return V
+
+
+@_launcher
+def conv2d_weight_mjp(M, x, kernel_size, stride, padding, dilation):
+    """``param_mjp`` of a Conv2d weight (groups = 1, zero padding): ``M [V, N, Cout, OH, OW]``, ``x [N, Cin, H, W]`` ->
+    ``[V, N, Cout, Cin, KH, KW]`` (unfold + einsum "vnol,nkl->vnok" without the im2col buffer)."""
+    if _TEST_BACKEND is not None:
+        return _TEST_BACKEND.conv2d_weight_mjp(M, x, kernel_size, stride, padding, dilation)
+    _require_device(M, x)
+    M, x = M.contiguous(), x.contiguous()
+    Vd, N, Cout, OH, OW = M.shape
+    Nx, Cin, H, W = x.shape
+    if Nx != N:
+        raise ValueError(f"x must have batch size {N}, got {Nx}")
+    KH, KW = kernel_size
+    out = torch.empty((Vd, N, Cout, Cin, KH, KW), dtype=torch.float32, device=M.device)
+    st = _lib.load().vivit_conv2d_weight_mjp_f32(
+        M.data_ptr(), x.data_ptr(), out.data_ptr(), Vd * N, N, Cin, H, W, Cout, KH, KW, OH, OW, stride[0], stride[1],
+        padding[0], padding[1], dilation[0], dilation[1], _stream(M))
+    _lib.check(st, "vivit_conv2d_weight_mjp_f32")
+    return out
+
+
 class SymeigPlan:
     """A symmetric matrix reduced to tridiagonal form with ALL eigenvalues known (``evals``, ascending), waiting for
     the caller to say which eigenvectors it wants: the two launches around the reference's ``criterion`` callback

@@ -26,7 +26,10 @@ namespace vivit {
 
 constexpr int SNB = 64;     // half bandwidth = panel width (must equal sb2st.hip's NB)
 constexpr int QT = 128;     // rows per workgroup tile in the panel QR
-constexpr int SGRP = 2;     // panels per delayed trailing-matrix update (measured at n = 40 960: 1 -> 2.00 s,
+#ifndef VIVIT_SGRP
+#define VIVIT_SGRP 2
+#endif
+constexpr int SGRP = VIVIT_SGRP;  // panels per delayed trailing-matrix update (measured at n = 40 960: 1 -> 2.00 s,
                             // 2 -> 1.52 s, 4 -> 1.52 s: beyond pairs the update is MFMA-bound)
 
 struct QrPart {

@@ -40,6 +40,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spe
 # was measured on.
 SYRK_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * 3695931059.375 + 276639882.25) * 1024.0}
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
+MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 MFMA peak (256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz; same guide)
 
 WORKLOADS = {
     # name: (layers, batch, classes)
@@ -595,22 +596,41 @@ def main():
             }
         else:
             achieved = syrk_flops / (syrk_ms / 1e3) / 1e12
-            roofline = {
-                "kernel": "gemm256_kernel<LAY_K,LAY_K> (Gram SYRK, fp32 MFMA)",
-                "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_F32_PEAK_TF,
-                "traffic": SYRK_TRAFFIC_BYTES_PMC.get((args.workload, world)),
-                "traffic_note": "bytes of the first-layer weight's SYRK launch (98.6 % of the Gram flops, 4.73 s), separate "
-                                "rocprofv3 --pmc passes (profiles/r01_pmc), FETCH_SIZE includes Infinity-Cache hits",
+            split = int(lib.vivit_gemm_split_mode())
+            if split == 0:
+                roofline = {
+                    "kernel": "gemm256_kernel<LAY_K,LAY_K> (Gram SYRK, fp32 MFMA)",
+                    "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": achieved / MFMA_F32_PEAK_TF,
+                    "traffic": SYRK_TRAFFIC_BYTES_PMC.get((args.workload, world)),
+                    "traffic_note": "bytes of the first-layer weight's SYRK launch (98.6 % of the Gram flops, 4.73 s), separate "
+                                    "rocprofv3 --pmc passes (profiles/r01_pmc), FETCH_SIZE includes Infinity-Cache hits",
+                }
+            else:
+                # fp32 products on the bf16 pipe: `split` bf16 MFMAs (exact partial products of the three-way operand
+                # split) per fp32 multiply-add, so the pipe's roofline for ALGORITHMIC fp32 flops is its peak / split
+                peak = MFMA_BF16_PEAK_TF / split
+                roofline = {
+                    "kernel": f"gemm256_bx_kernel<{split}> (Gram SYRK: fp32 operands split exactly into 3 bf16 pieces, {split} of 9 "
+                              f"partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation) + bx_split_kernel",
+                    "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "peak_note": f"dense bf16 MFMA peak {MFMA_BF16_PEAK_TF} TFLOP/s / {split} partial products per fp32 product; "
+                                 f"achieved = algorithmic fp32 flops n(n+1)P per second",
+                    "issued_bf16_tflops": achieved * split,
+                    "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
+                    "traffic": None,
+                }
+            roofline.update({
                 "launches_sampled": int(syrk_cnt), "avg_launch_ms": syrk_ms / max(syrk_cnt, 1),
                 "est_share_of_step": syrk_total_s / (elapsed / args.steps),
-            }
+            })
+        gram_peak = roofline["peak"] if roofline["bound"] == "mfma" else MFMA_F32_PEAK_TF
         phases_roof = [{"stage": "Gram build (SYRK over all parameters)", "seconds": syrk_total_s, "bound": "mfma",
                         "flops": syrk_flops / max(args.steps, 1), "achieved": roofline["achieved"] if roofline["bound"] == "mfma" else
-                        (syrk_flops / (syrk_ms / 1e3) / 1e12 if syrk_ms > 0 else None), "peak": MFMA_F32_PEAK_TF,
+                        (syrk_flops / (syrk_ms / 1e3) / 1e12 if syrk_ms > 0 else None), "peak": gram_peak,
                         "unit": "TFLOP/s"}]
         if phases_roof[0]["achieved"]:
-            phases_roof[0]["frac"] = phases_roof[0]["achieved"] / MFMA_F32_PEAK_TF
+            phases_roof[0]["frac"] = phases_roof[0]["achieved"] / gram_peak
         phases_roof += _stage_rooflines(list(stage_ms), n, args.steps, vectors, row_frac=1.0 / world)
         secondary = {
             "gram_syrk_tflops": (syrk_flops / (syrk_ms / 1e3) / 1e12) if syrk_ms > 0 else None,
@@ -628,6 +648,10 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
+            "arithmetic": ("fp32 in, fp32 accumulate, fp32 out; the large Gram products form every fp32 product from the exact "
+                           "three-way bf16 split of its operands (6 of the 9 partial products, the dropped ones < 2^-24 of the "
+                           "product) on the bf16 MFMA pipe -- see verified.gram for the measured accuracy")
+                          if int(lib.vivit_gemm_split_mode()) else "fp32 MFMA throughout",
             "data": "synthetic (seeded random-init MLP, uniform random inputs, materialised exact sqrt-GGN factors)",
             "config": {
                 "workload": args.workload,

@@ -54,6 +54,14 @@ const char *vivit_hip_status_string(int status);
  * Only the lower-triangular tiles (256x256 for large outputs with a long contraction, 128x128 otherwise) are
  * computed on MFMA (n(n+1)p flops); the mirror tiles are transposed through LDS and stored as well.
  * ------------------------------------------------------------------------------------------- */
+/* Matrix pipe of the large K-contiguous products (the Gram SYRK above a few hundred 256 x 256 tiles and K >= 1024, the NT
+ * GEMMs of the same size): 6 (default) = bf16 MFMA pipe -- every fp32 operand is split EXACTLY into three bf16 pieces
+ * (a = hi + mid + lo, 24 significand bits) and a product is the sum of the six partial products that are >= 2^-16 of it,
+ * each exact in the MFMA, accumulated in fp32 (the three dropped ones are < 2^-24 |a b|, below the rounding of an fp32
+ * product); 9 = all nine partial products; 0 = v_mfma_f32_32x32x2_f32 on the fp32 operands.  Set once per process by
+ * the environment variable VIVIT_GEMM_SPLIT.  The split pieces of a 32 768-column chunk live in the workspace
+ * (6 bytes per element of the chunk). */
+int vivit_gemm_split_mode(void);
 size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p);
 int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float *G, int64_t ldg,
                         float alpha, float beta, void *workspace, size_t workspace_bytes,

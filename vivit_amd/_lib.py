@@ -21,6 +21,7 @@ SIGNATURES = {
     "vivit_hip_abi_version": (_int, []),
     "vivit_hip_target": (ctypes.c_char_p, []),
     "vivit_hip_status_string": (ctypes.c_char_p, [_int]),
+    "vivit_gemm_split_mode": (_int, []),
     "vivit_gram_syrk_f32_workspace_bytes": (_sz, [_i64, _i64]),
     "vivit_gram_syrk_f32": (_int, [_ptr, _i64, _i64, _i64, _ptr, _i64, _f32, _f32, _ptr, _sz, _ptr]),
     "vivit_gemm_f32_workspace_bytes": (_sz, [_i64, _i64, _i64]),

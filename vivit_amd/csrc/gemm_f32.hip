@@ -743,6 +743,345 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp32 GEMM / SYRK on the bf16 matrix pipe ("bf16 x 6"): the fp32 MFMA (v_mfma_f32_32x32x2_f32) retires 64 flop per
+// SIMD-cycle, v_mfma_f32_32x32x16_bf16 1024.  Every fp32 operand is split EXACTLY into three bf16 pieces,
+//   a = a_hi + a_mid + a_lo    (a_hi = bf16(a), a_mid = bf16(a - a_hi), a_lo = bf16(a - a_hi - a_mid); 3 x 8 = 24
+//                               significand bits, the two subtractions are exact in fp32),
+// and a product a b is the sum of the partial products whose weight is at least 2^-16 of it,
+//   hi hi + hi mid + mid hi + hi lo + lo hi + mid mid          (each EXACT in the MFMA: 8 x 8 -> 16 bits, fp32 accumulate);
+// the three dropped ones (mid lo, lo mid, lo lo) are below 2^-24 |a b|, i.e. below the rounding error the fp32 MFMA
+// commits on the product itself.  Six bf16 MFMAs replace eight fp32 MFMAs per 16 k: 2.67x the matrix-pipe rate for the
+// same accumulation arithmetic (fp32 accumulators, the same two-level flush into C, tile map and epilogues of
+// gemm256_kernel).  Operands are K-contiguous (LAY_K) on both sides: the Gram SYRK and the NT products.
+//
+// Two kernels: bx_split_kernel writes the three pieces of a column chunk of an operand as bf16 matrices (HBM-bound:
+// 4 B read + 6 B written per element, 1-2 % of the product's time); gemm256_bx_kernel is then a pure bf16 GEMM on the
+// data path of gemm256_kernel: global -> LDS DMA, three stages, requested two K tiles ahead, no VALU work per
+// element at all.  (A first version split inside the GEMM, global -> registers -> 3 bf16 -> LDS: hipcc would not
+// overlap the ~300 VALU operations per K tile with the 96 MFMAs of a one-wave-per-SIMD kernel, and kept the
+// prefetched values in scratch: 207 TFLOP/s-equivalent at best against 149 for the fp32 MFMA kernel.)
+// LDS: per stage and operand 3 pieces x 8 blocks of 1 KB; block b = rows 32 b .. 32 b + 31 as [k half][32 rows][8 bf16]:
+// ONE DMA instruction fills a block (lane -> (row lane % 32, half lane / 32), 16 B each), ONE conflict-free
+// ds_read_b128 per lane reads an MFMA operand (row r, the 8 k of half h).  A and B use the same assignment of k to
+// (half, slot), which is all the MFMA needs (the sum over k is order independent).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef const unsigned short __attribute__((address_space(1))) *gcptr16;
+constexpr int BX_PIECE = 8 * 1024;               // bytes of one piece of one operand tile (256 rows x 16 k bf16)
+constexpr int BX_OPER = 3 * BX_PIECE;            // 24 KB
+constexpr int BX_STAGE = 2 * BX_OPER;            // A and B: 48 KB
+constexpr int GEMM256BX_LDS_BYTES = 3 * BX_STAGE;  // three stages: 144 KB
+
+__device__ __forceinline__ void bx_split2(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo) {
+  const bf16x2 h = {(__bf16)a, (__bf16)b};
+  hi = __builtin_bit_cast(unsigned, h);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  const bf16x2 m = {(__bf16)ra, (__bf16)rb};
+  mid = __builtin_bit_cast(unsigned, m);
+  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+  const bf16x2 l = {(__bf16)sa, (__bf16)sb};
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// Pieces of the column chunk [k0, k0 + kc) of A (rows x ., row stride lda) in the BLOCKED layout the GEMM's DMA wants:
+//   P[pc][k tile kt (16 k)][row block rb (32 rows)] = 1 KB = [k half][32 rows][8 bf16]
+// so that one global_load_lds instruction of the GEMM reads 1 KB of consecutive bytes (a row-major piece matrix made
+// every lane fetch 16 bytes from a different cache line: 4x the L2 traffic, the product ran at 105 TFLOP/s-equivalent).
+// One workgroup converts 32 rows x 64 k: coalesced 32-byte reads per lane, transposition through LDS, 1 KB bursts out.
+// Rows beyond `rows` are written as zeros.  kc % 16 == 0; grid.x = row blocks, grid.y = groups of 4 k tiles.
+__global__ __launch_bounds__(256) void bx_split_kernel(const float *__restrict__ A, int64_t rows, int64_t lda, int64_t k0,
+                                                       int64_t kc, unsigned short *__restrict__ P, int64_t piece_stride,
+                                                       int64_t nrb) {
+  __shared__ __attribute__((aligned(16))) unsigned char sp[3][4][1024];
+  const int tid = threadIdx.x;
+  const int64_t rb = blockIdx.x;
+  const int64_t kt0 = (int64_t)blockIdx.y * 4;
+  const int64_t nkt = kc >> 4;
+  {
+    const int rl = tid >> 3, seg = tid & 7;           // row in the block, 8-float segment of the 64 k
+    const int64_t row = rb * 32 + rl;
+    const int64_t k = kt0 * 16 + seg * 8;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (row < rows && k < kc) {
+      const float4 *src = reinterpret_cast<const float4 *>(A + row * lda + k0 + k);
+      v0 = src[0];
+      v1 = src[1];
+    }
+    unsigned h[4], m[4], l[4];
+    bx_split2(v0.x, v0.y, h[0], m[0], l[0]);
+    bx_split2(v0.z, v0.w, h[1], m[1], l[1]);
+    bx_split2(v1.x, v1.y, h[2], m[2], l[2]);
+    bx_split2(v1.z, v1.w, h[3], m[3], l[3]);
+    const int kt = seg >> 1, half = seg & 1;
+    const int o = half * 512 + rl * 16;
+    *reinterpret_cast<uint4 *>(&sp[0][kt][o]) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4 *>(&sp[1][kt][o]) = make_uint4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<uint4 *>(&sp[2][kt][o]) = make_uint4(l[0], l[1], l[2], l[3]);
+  }
+  __syncthreads();
+  // 12 KB out: thread t moves 16 bytes of (piece, k tile) = (j / 4, j % 4) for j = t / 64 + 4 i
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = (tid >> 6) + 4 * i, pc = j >> 2, kt = j & 3;
+    if (kt0 + kt < nkt) {
+      unsigned char *dst = reinterpret_cast<unsigned char *>(P + pc * piece_stride) + ((kt0 + kt) * nrb + rb) * 1024 + (tid & 63) * 16;
+      *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(&sp[pc][kt][(tid & 63) * 16]);
+    }
+  }
+}
+
+// The partial products of a split product are accumulated in a fixed order of (A piece, B piece); element (r, c) and
+// element (c, r) of a DIAGONAL tile of a SYRK see that order with the roles swapped and may differ in the last bit
+// (off-diagonal tiles are mirrored exactly).  The lower triangle of every diagonal 256 x 256 tile is copied up.
+__global__ __launch_bounds__(256) void bx_sym_diag_kernel(float *__restrict__ C, int64_t n, int64_t ldc) {
+  const int64_t base = (int64_t)blockIdx.x * B2;
+  for (int idx = threadIdx.x; idx < B2 * B2; idx += 256) {
+    const int64_t rr = base + idx / B2, cc = base + idx % B2;
+    if (rr < n && cc < n && cc > rr) C[rr * ldc + cc] = C[cc * ldc + rr];
+  }
+}
+
+struct GemmBxArgs {
+  const unsigned short *A, *B;   // piece 0 of each operand (blocked layout of bx_split_kernel); pieces 1, 2 at + strideA / strideB elements
+  int64_t strideA, strideB;
+  int64_t nrbA, nrbB;            // 32-row blocks per k tile of each operand
+  float *C;
+  int64_t M, N, K, ldc;          // K = contraction length of THIS launch (multiple of 16)
+  float alpha, beta;
+  int tiles_m, tiles_n, syrk, sbw;
+};
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
+  int ti, tj;
+  if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)ti * B2, col0 = (int64_t)tj * B2;
+  const int nt = (int)(p.K / BK);
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  gptr Cout = (gptr)p.C;
+  const int64_t ldc = p.ldc;
+  const float alpha_ = p.alpha, beta_ = p.beta;
+  const bool full_tile = row0 + B2 <= p.M && col0 + B2 <= p.N;
+  // C <- C' + alpha * acc with C' = beta * C on the first flush and C afterwards; acc <- final value
+  auto flush_to_c = [&](bool first) __attribute__((always_inline)) {
+    const float beta = first ? beta_ : 1.f;
+    int opaque = 0;
+    __asm__ volatile("" : "+v"(opaque));  // keeps the 256 output addresses out of LICM's reach (see gemm256_kernel)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __asm__ volatile("" ::: "memory");
+        const int64_t rbase = row0 + wm * 128 + i * 32 + 4 * h + opaque, col = col0 + wn * 128 + j * 32 + r;
+        if (full_tile) {
+          gptr cbase = Cout + rbase * ldc + col;
+          float old[16];
+          if (beta != 0.f) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) old[e] = cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc];
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = alpha_ * acc[i][j][e];
+            if (beta != 0.f) v += beta * old[e];
+            cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc] = v;
+            acc[i][j][e] = v;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
+            float v = alpha_ * acc[i][j][e];
+            if (row < p.M && col < p.N) {
+              gptr c = Cout + row * ldc + col;
+              if (beta != 0.f) v += beta * *c;
+              *c = v;
+            }
+            acc[i][j][e] = v;
+          }
+        }
+      }
+  };
+  auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+
+  // ---- DMA sources: wave w fills blocks w and w + 4 of every piece of both operands (12 instructions per K tile),
+  // each instruction 1 KB of consecutive global bytes (blocked piece layout).  Row blocks beyond the matrix read the
+  // last block (their outputs are never stored).  The pointers advance by one k tile per request.
+  gcptr16 srcA[2], srcB[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int blk = wave + 4 * u;
+    int64_t ba = row0 / 32 + blk, bb = col0 / 32 + blk;   // 32-row block of the operand (clamped: never stored rows)
+    ba = ba < p.nrbA ? ba : p.nrbA - 1;
+    bb = bb < p.nrbB ? bb : p.nrbB - 1;
+    srcA[u] = (gcptr16)p.A + ba * 512 + 8 * lane;          // 1 KB block = 512 bf16; lane -> its 16 bytes
+    srcB[u] = (gcptr16)p.B + bb * 512 + 8 * lane;
+  }
+  const int64_t stepA = p.nrbA * 512, stepB = p.nrbB * 512;  // one k tile further
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx +
+                                                       (unsigned)(wave * 1024));
+  auto dma16b = [&](gcptr16 src, unsigned lds_byte_addr) __attribute__((always_inline)) {
+    __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory");
+  };
+  auto issue = [&](int st) __attribute__((always_inline)) {  // the next not yet requested K tile into stage st
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        dma16b(srcA[u] + pc * p.strideA, lds0 + (unsigned)(st * BX_STAGE + pc * BX_PIECE + 4 * u * 1024));
+        dma16b(srcB[u] + pc * p.strideB, lds0 + (unsigned)(st * BX_STAGE + BX_OPER + pc * BX_PIECE + 4 * u * 1024));
+      }
+      srcA[u] += stepA;
+      srcB[u] += stepB;
+    }
+  };
+  // ---- one K tile of 16: 16 output tiles x NPROD bf16 MFMAs per wave; the smallest partial products go in first.
+  // The B pieces of the wave's four column tiles stay in registers for the tile (48), the A pieces stream per row tile.
+  const unsigned fofsA = (unsigned)((wm * 4) * 1024 + h * 512 + r * 16), fofsB = (unsigned)((wn * 4) * 1024 + h * 512 + r * 16);
+  struct FragB {
+    bf16x8 v[3][4];
+  };
+  struct FragA {
+    bf16x8 v[3];
+  };
+  auto load_b = [&](int st) __attribute__((always_inline)) -> FragB {
+    const unsigned char *sB = smem_bx + st * BX_STAGE + BX_OPER;
+    FragB f;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sB + pc * BX_PIECE + fofsB + j * 1024);
+    return f;
+  };
+  auto load_a = [&](int st, int i) __attribute__((always_inline)) -> FragA {
+    const unsigned char *sA = smem_bx + st * BX_STAGE;
+    FragA f;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) f.v[pc] = *reinterpret_cast<const bf16x8 *>(sA + pc * BX_PIECE + fofsA + i * 1024);
+    return f;
+  };
+  auto mfma_row = [&](auto iconst, const FragA &fa, const FragB &fb) __attribute__((always_inline)) {
+    constexpr int i = decltype(iconst)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x16 c = acc[i][j];
+      if (NPROD >= 9) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2], fb.v[2][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2], fb.v[1][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1], fb.v[2][j], c, 0, 0, 0);
+      }
+      if (NPROD >= 6) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2], fb.v[0][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0], fb.v[2][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1], fb.v[1][j], c, 0, 0, 0);
+      }
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1], fb.v[0][j], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0], fb.v[1][j], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0], fb.v[0][j], c, 0, 0, 0);
+      acc[i][j] = c;
+    }
+  };
+  using J0 = std::integral_constant<int, 0>;
+  using J1 = std::integral_constant<int, 1>;
+  using J2 = std::integral_constant<int, 2>;
+  using J3 = std::integral_constant<int, 3>;
+  // Pipeline (tile t lives in stage t % 3).  The fragment reads of a row tile are issued BEFORE the MFMAs of the
+  // previous one, and the first fragments of tile t + 1 during the second half of tile t, so the matrix pipe never
+  // waits for LDS.  In the middle of tile t every wave waits for its own share of tile t + 1 (requested one tile ago);
+  // the barrier there publishes tile t + 1 and certifies that every wave is completely past tile t - 1, whose stage then
+  // receives the requests for tile t + 2.
+  auto chunk = [&](int t0, int t1) __attribute__((always_inline)) {
+    __syncthreads();  // every wave is done with the LDS stages of the previous chunk
+    issue(0);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __asm__ volatile("s_barrier" ::: "memory");
+    if (t0 + 1 < t1) issue(1);
+    // two named fragment sets in ping-pong (tile t uses one and fills the other for tile t + 1)
+    FragB fbX = load_b(0), fbY;
+    FragA faX = load_a(0, 0), faY;
+    int st = 0, t = t0;
+    auto tile = [&](const FragB &fb, const FragA &fa, FragB &fbn, FragA &fan) __attribute__((always_inline)) {
+      const int st1 = st == 2 ? 0 : st + 1, st2 = st == 0 ? 2 : st - 1;   // stages of tiles t + 1 and t + 2 (= t - 1)
+      const int stn = t + 1 < t1 ? st1 : st;                              // (last tile: harmless re-read of its own stage)
+      FragA fa1 = load_a(st, 1);
+      mfma_row(J0{}, fa, fb);
+      FragA fa2 = load_a(st, 2);
+      mfma_row(J1{}, fa1, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile t + 1 has landed
+      __asm__ volatile("s_barrier" ::: "memory");
+      if (t + 2 < t1) issue(st2);
+      __builtin_amdgcn_sched_barrier(0);
+      FragA fa3 = load_a(st, 3);
+      fbn = load_b(stn);
+      mfma_row(J2{}, fa2, fb);
+      fan = load_a(stn, 0);
+      mfma_row(J3{}, fa3, fb);
+      st = st1;
+      ++t;
+    };
+    while (t < t1) {
+      tile(fbX, faX, fbY, faY);
+      if (t >= t1) break;
+      tile(fbY, faY, fbX, faX);
+    }
+  };
+  bool first_flush = true;
+  for (int t0 = 0; t0 < nt; t0 += FLUSH2_TILES) {
+    const int t1 = t0 + FLUSH2_TILES < nt ? t0 + FLUSH2_TILES : nt;
+    if (t0 > 0) clear_acc();
+    chunk(t0, t1);
+    flush_to_c(first_flush);
+    first_flush = false;
+  }
+
+  if (p.syrk == 1 && ti != tj) {
+    __syncthreads();
+    float *ts = reinterpret_cast<float *>(smem_bx) + wave * (32 * 33);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ts[r * 33 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[i][j][e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int64_t mrow0 = col0 + wn * 128 + j * 32;
+        const int64_t mcol = row0 + wm * 128 + i * 32 + r;
+#pragma unroll
+        for (int rr = 0; rr < 32; rr += 2) {
+          const int64_t mrow = mrow0 + rr + h;
+          if (mrow < p.N && mcol < p.M) {
+            gptr c = (gptr)p.C + mrow * p.ldc + mcol;
+            *c = ts[(rr + h) * 33 + r];
+          }
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Streaming variant for outputs with at most 64 rows (the panel product P^T = V^T A22 of the band
 // reduction: 64 x m x m, its big operand read exactly once from HBM, 32 flop/byte).  Such a product is
 // HBM-bound and needs ~100 KB in flight per CU; the register-staged tile has 20-40.  Same global -> LDS
@@ -938,6 +1277,8 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
 static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out);
 static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit_out, int64_t *kchunk_out, int max_split = 32);
 
+static int gemm_split_mode();
+static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same);
 size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int ksplit;
@@ -947,9 +1288,14 @@ size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
   {
     int s256;
     int64_t kc256;
-    if (gemm256_plan(M, N, K / BK * BK, syrk, &s256, &kc256) && s256 > 1) {
-      const size_t b256 = (size_t)s256 * (size_t)M * (size_t)N * sizeof(float);
-      if (b256 > b) b = b256;
+    if (gemm256_plan(M, N, K / BK * BK, syrk, &s256, &kc256)) {
+      if (s256 > 1) {
+        const size_t b256 = (size_t)s256 * (size_t)M * (size_t)N * sizeof(float);
+        if (b256 > b) b = b256;
+      } else if (gemm_split_mode() != 0) {  // operand pieces of the bf16-pipe path (gemm256_launch)
+        const size_t bb = bx_workspace_bytes(M, N, K / BK * BK, syrk);
+        if (bb > b) b = bb;
+      }
     }
   }
   if (!syrk && M <= 64 && N >= 2048 && K >= 2048) {  // the streaming kernel may be chosen instead (gemm64_launch)
@@ -1015,6 +1361,32 @@ static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit
   return true;
 }
 
+// Which matrix pipe the 256-tile NT products (Gram SYRK, K-contiguous GEMMs) use: 6 (default) = bf16 pipe with exact
+// three-way operand splits and the 6 partial products that are >= 2^-16 of a product; 9 = all nine; 0 = fp32 MFMA
+// (gemm256_kernel); 3 = hi hi + hi mid + mid hi of the three-way split (per-product error 2^-16: experiments only).
+// VIVIT_GEMM_SPLIT overrides.
+static int gemm_split_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("VIVIT_GEMM_SPLIT");
+    mode = e ? atoi(e) : 6;
+    if (mode != 0 && mode != 3 && mode != 6 && mode != 9) mode = 6;
+  }
+  return mode;
+}
+
+// columns of an operand split at a time (workspace: 6 bytes per element of the chunk and operand)
+static int64_t bx_chunk_cols(int64_t K) {
+  static int64_t kc = -1;
+  if (kc < 0) { const char *e = getenv("VIVIT_GEMM_SPLIT_KC"); kc = e ? atoll(e) : 32768; kc = kc / 16 * 16; if (kc < 16) kc = 16; }
+  return K < kc ? K : kc;
+}
+static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same) {
+  const int64_t kc = bx_chunk_cols(K);
+  const int64_t ra = cdiv(M, 32) * 32, rb = cdiv(N, 32) * 32;
+  return (size_t)6 * (size_t)kc * (size_t)(same ? ra : ra + rb) + 256;
+}
+
 static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
   static unsigned long long attr_done = 0;
   {
@@ -1027,6 +1399,10 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
                             reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_M>)};
       for (const void *f : fns)
         if (!ensure_dynamic_lds(f, GEMM256_LDS_BYTES, attr_done)) return VIVIT_E_LAUNCH;
+      const void *bx[3] = {reinterpret_cast<const void *>(gemm256_bx_kernel<3>), reinterpret_cast<const void *>(gemm256_bx_kernel<6>),
+                           reinterpret_cast<const void *>(gemm256_bx_kernel<9>)};
+      for (const void *f : bx)
+        if (!ensure_dynamic_lds(f, GEMM256BX_LDS_BYTES, attr_done)) return VIVIT_E_LAUNCH;
       attr_done |= 1ull << (dev & 63);
     }
   }
@@ -1053,6 +1429,45 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
   dim3 grid((unsigned)(nsb * 256), (unsigned)p.ksplit, 1);
   const bool prof = syrk && p.A == p.B && prof_enabled();
   if (prof) prof_begin(0, (double)p.M * (double)(p.M + 1) * (double)p.K, stream);
+  const int bx = gemm_split_mode();
+  if (bx != 0 && alay == LAY_K && blay == LAY_K && p.ksplit == 1 && workspace &&
+      workspace_bytes >= bx_workspace_bytes(p.M, p.N, p.K, p.A == p.B && p.lda == p.ldb && p.M == p.N)) {
+    // fp32 product on the bf16 pipe: K in chunks of BX_KC columns, per chunk the operand pieces (bx_split_kernel)
+    // and one pure-bf16 launch that accumulates into C (beta = 1 from the second chunk on)
+    const bool same = p.A == p.B && p.lda == p.ldb && p.M == p.N;
+    const int64_t kc_max = bx_chunk_cols(p.K);
+    const int64_t nrbA = cdiv(p.M, 32), nrbB = cdiv(p.N, 32);
+    unsigned short *PA = static_cast<unsigned short *>(workspace);
+    const int64_t strideA = nrbA * 32 * kc_max, strideB = nrbB * 32 * kc_max;
+    unsigned short *PB = same ? PA : PA + 3 * strideA;
+    GemmBxArgs q;
+    q.A = PA; q.B = PB; q.strideA = strideA; q.strideB = same ? strideA : strideB;
+    q.nrbA = nrbA; q.nrbB = same ? nrbA : nrbB;
+    q.C = p.C; q.M = p.M; q.N = p.N; q.ldc = p.ldc; q.alpha = p.alpha;
+    q.tiles_m = p.tiles_m; q.tiles_n = p.tiles_n; q.syrk = p.syrk; q.sbw = p.sbw;
+    int st = VIVIT_OK;
+    for (int64_t k0 = 0; k0 < p.K && st == VIVIT_OK; k0 += kc_max) {
+      const int64_t kc = (p.K - k0) < kc_max ? (p.K - k0) : kc_max;
+      const unsigned gy = (unsigned)cdiv(kc / 16, 4);
+      bx_split_kernel<<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, k0, kc, PA, strideA, nrbA);
+      if (!same) bx_split_kernel<<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB);
+      q.K = kc;
+      q.beta = k0 == 0 ? p.beta : 1.f;
+      if (bx == 6)
+        gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+      else if (bx == 9)
+        gemm256_bx_kernel<9><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+      else
+        gemm256_bx_kernel<3><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+      st = launch_status();
+    }
+    if (st == VIVIT_OK && p.syrk == 1) {
+      bx_sym_diag_kernel<<<(unsigned)p.tiles_m, 256, 0, stream>>>(p.C, p.M, p.ldc);
+      st = launch_status();
+    }
+    if (prof) prof_end(0, stream);
+    return st;
+  }
   if (alay == LAY_K && blay == LAY_K)
     gemm256_kernel<LAY_K, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(p);
   else if (alay == LAY_K && blay == LAY_M)
@@ -1293,6 +1708,8 @@ int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int
 using namespace vivit;
 
 extern "C" {
+
+int vivit_gemm_split_mode(void) { return gemm_split_mode(); }
 
 size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p) { return gemm_workspace_bytes(n, n, p, true); }
 

@@ -162,9 +162,10 @@ def verify_symeig(G, w, Z, block=4096):
 
 
 # what "verified" means (tests/test_headline_gpu.py asserts the same bounds)
-# entries: fp32 contraction of length 4e5 with two accumulation levels, relative to sqrt(G_ii G_jj) (measured
-# 1.3e-6 off the diagonal, 2.5e-6 on it where all terms are positive and rounding cannot cancel)
-VERIFY_BOUNDS = {"entry_err": 5e-6, "diag_err": 1e-5, "trace_err": 2e-6, "eig_trace_err": 1e-5, "fro_err": 1e-4,
+# entries: fp32 contraction of length 4e5 with two accumulation levels, relative to sqrt(G_ii G_jj) (measured with
+# the fp32 MFMA kernel / the bf16-pipe kernel: 1.3e-6 / 2.6e-6 off the diagonal, 2.5e-6 / 3.7e-6 on it where all terms
+# are positive and rounding cannot cancel, 3.5e-7 / 1.2e-6 for the trace)
+VERIFY_BOUNDS = {"entry_err": 5e-6, "diag_err": 1e-5, "trace_err": 4e-6, "eig_trace_err": 1e-5, "fro_err": 1e-4,
                  "orth_err": 1e-4, "residual_err": 3e-5}
 
 

@@ -1041,11 +1041,11 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       st = st1;
       ++t;
     };
-    while (t < t1) {
+    while (t + 2 <= t1) {  // two tiles per trip, no exit in between (the sets swap roles and are back in place)
       tile(fbX, faX, fbY, faY);
-      if (t >= t1) break;
       tile(fbY, faY, fbX, faX);
     }
+    if (t < t1) tile(fbX, faX, fbY, faY);
   };
   bool first_flush = true;
   for (int t0 = 0; t0 < nt; t0 += FLUSH2_TILES) {

@@ -229,3 +229,38 @@ def test_conv2d_weight_mjp(geom):
     ref = torch.einsum("vnol,nkl->vnok", M.double().flatten(3), xu).reshape(Vd, N, Cout, Cin, *k)
     assert out.shape == ref.shape
     np.testing.assert_allclose(out.cpu().double().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("kind", ["nt", "nn", "tn", "syrk"])
+def test_large_products_on_the_256_tile_path(kind):
+    """Products big enough for the 256 x 256 tile kernels (>= 200 tiles, K >= 1024), i.e. the bf16-pipe path with the
+    exact three-way operand split (default) for every operand layout, ragged edges included; sampled against fp64."""
+    from vivit_amd import kernels
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(7)
+    m, n, k = 4100, 3900, 2064
+    if kind == "nt":
+        A, B = torch.randn(m, k, device=dev, generator=g), torch.randn(n, k, device=dev, generator=g)
+        C = kernels.gemm_nt(A, B)
+        ref = lambda I, J: A[I].double() @ B[J].double().T  # noqa: E731
+    elif kind == "nn":
+        A, B = torch.randn(m, k, device=dev, generator=g), torch.randn(k, n, device=dev, generator=g)
+        C = kernels.gemm_nn(A, B)
+        ref = lambda I, J: A[I].double() @ B[:, J].double()  # noqa: E731
+    elif kind == "tn":
+        A, B = torch.randn(k, m, device=dev, generator=g), torch.randn(k, n, device=dev, generator=g)
+        C = kernels.gemm_tn(A, B)
+        ref = lambda I, J: A[:, I].double().T @ B[:, J].double()  # noqa: E731
+    else:
+        m = n = 4100
+        A = torch.randn(m, k, device=dev, generator=g)
+        C0 = torch.randn(m, m, device=dev, generator=g)
+        C0 = C0 + C0.T
+        C = kernels.gram_syrk(A, out=C0.clone(), alpha=0.5, beta=2.0)
+        assert torch.equal(C, C.T)
+        ref = lambda I, J: 0.5 * (A[I].double() @ A[J].double().T) + 2.0 * C0[I][:, J].double()  # noqa: E731
+    I = torch.tensor([0, 1, 255, 256, 257, 2047, 2048, m - 257, m - 2, m - 1], device=dev)
+    J = torch.arange(0, n, 13, device=dev)
+    err = (C[I][:, J].double() - ref(I, J)).abs().max().item()
+    assert err <= 2e-5 * k ** 0.5, err   # fp32 accumulation of k unit-variance products

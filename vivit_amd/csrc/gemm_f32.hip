@@ -789,16 +789,19 @@ __device__ __forceinline__ void bx_split2(float a, float b, unsigned &hi, unsign
 // every lane fetch 16 bytes from a different cache line: 4x the L2 traffic, the product ran at 105 TFLOP/s-equivalent).
 // One workgroup converts 32 rows x 64 k: coalesced 32-byte reads per lane, transposition through LDS, 1 KB bursts out.
 // Rows beyond `rows` are written as zeros.  kc % 16 == 0; grid.x = row blocks, grid.y = groups of 4 k tiles.
+template <int LAY>
 __global__ __launch_bounds__(256) void bx_split_kernel(const float *__restrict__ A, int64_t rows, int64_t lda, int64_t k0,
                                                        int64_t kc, unsigned short *__restrict__ P, int64_t piece_stride,
                                                        int64_t nrb) {
   __shared__ __attribute__((aligned(16))) unsigned char sp[3][4][1024];
+  __shared__ float tr[LAY == LAY_M ? 64 * 33 : 1];
   const int tid = threadIdx.x;
   const int64_t rb = blockIdx.x;
   const int64_t kt0 = (int64_t)blockIdx.y * 4;
   const int64_t nkt = kc >> 4;
-  {
-    const int rl = tid >> 3, seg = tid & 7;           // row in the block, 8-float segment of the 64 k
+  const int rl = tid >> 3, seg = tid & 7;           // row in the block, 8-float segment of the 64 k
+  float v[8];
+  if (LAY == LAY_K) {
     const int64_t row = rb * 32 + rl;
     const int64_t k = kt0 * 16 + seg * 8;
     float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
@@ -807,11 +810,35 @@ __global__ __launch_bounds__(256) void bx_split_kernel(const float *__restrict__
       v0 = src[0];
       v1 = src[1];
     }
+    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+  } else {
+    // k-major source X[k][row]: coalesced reads along the rows (8 rows per thread), transposition through LDS
+    const int kk = tid >> 2, rs = tid & 3;
+    const int64_t k = kt0 * 16 + kk, row = rb * 32 + rs * 8;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (k < kc && row + 8 <= rows) {
+      const float4 *src = reinterpret_cast<const float4 *>(A + (k0 + k) * lda + row);
+      v0 = src[0];
+      v1 = src[1];
+    } else if (k < kc) {
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = row + j < rows ? A[(k0 + k) * lda + row + j] : 0.f;
+      v0 = make_float4(e[0], e[1], e[2], e[3]);
+      v1 = make_float4(e[4], e[5], e[6], e[7]);
+    }
+    float *d = tr + kk * 33 + rs * 8;
+    d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tr[(seg * 8 + j) * 33 + rl];
+  }
+  {
     unsigned h[4], m[4], l[4];
-    bx_split2(v0.x, v0.y, h[0], m[0], l[0]);
-    bx_split2(v0.z, v0.w, h[1], m[1], l[1]);
-    bx_split2(v1.x, v1.y, h[2], m[2], l[2]);
-    bx_split2(v1.z, v1.w, h[3], m[3], l[3]);
+    bx_split2(v[0], v[1], h[0], m[0], l[0]);
+    bx_split2(v[2], v[3], h[1], m[1], l[1]);
+    bx_split2(v[4], v[5], h[2], m[2], l[2]);
+    bx_split2(v[6], v[7], h[3], m[3], l[3]);
     const int kt = seg >> 1, half = seg & 1;
     const int o = half * 512 + rl * 16;
     *reinterpret_cast<uint4 *>(&sp[0][kt][o]) = make_uint4(h[0], h[1], h[2], h[3]);
@@ -1430,11 +1457,11 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
   const bool prof = syrk && p.A == p.B && prof_enabled();
   if (prof) prof_begin(0, (double)p.M * (double)(p.M + 1) * (double)p.K, stream);
   const int bx = gemm_split_mode();
-  if (bx != 0 && alay == LAY_K && blay == LAY_K && p.ksplit == 1 && workspace &&
-      workspace_bytes >= bx_workspace_bytes(p.M, p.N, p.K, p.A == p.B && p.lda == p.ldb && p.M == p.N)) {
+  if (bx != 0 && p.ksplit == 1 && workspace &&
+      workspace_bytes >= bx_workspace_bytes(p.M, p.N, p.K, p.A == p.B && p.lda == p.ldb && p.M == p.N && alay == blay)) {
     // fp32 product on the bf16 pipe: K in chunks of BX_KC columns, per chunk the operand pieces (bx_split_kernel)
     // and one pure-bf16 launch that accumulates into C (beta = 1 from the second chunk on)
-    const bool same = p.A == p.B && p.lda == p.ldb && p.M == p.N;
+    const bool same = p.A == p.B && p.lda == p.ldb && p.M == p.N && alay == blay;
     const int64_t kc_max = bx_chunk_cols(p.K);
     const int64_t nrbA = cdiv(p.M, 32), nrbB = cdiv(p.N, 32);
     unsigned short *PA = static_cast<unsigned short *>(workspace);
@@ -1449,8 +1476,16 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
     for (int64_t k0 = 0; k0 < p.K && st == VIVIT_OK; k0 += kc_max) {
       const int64_t kc = (p.K - k0) < kc_max ? (p.K - k0) : kc_max;
       const unsigned gy = (unsigned)cdiv(kc / 16, 4);
-      bx_split_kernel<<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, k0, kc, PA, strideA, nrbA);
-      if (!same) bx_split_kernel<<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB);
+      if (alay == LAY_K)
+        bx_split_kernel<LAY_K><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, k0, kc, PA, strideA, nrbA);
+      else
+        bx_split_kernel<LAY_M><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, k0, kc, PA, strideA, nrbA);
+      if (!same) {
+        if (blay == LAY_K)
+          bx_split_kernel<LAY_K><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB);
+        else
+          bx_split_kernel<LAY_M><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB);
+      }
       q.K = kc;
       q.beta = k0 == 0 ? p.beta : 1.f;
       if (bx == 6)

@@ -971,17 +971,24 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   auto dma16b = [&](gcptr16 src, unsigned lds_byte_addr) __attribute__((always_inline)) {
     __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory");
   };
-  auto issue = [&](int st) __attribute__((always_inline)) {  // the next not yet requested K tile into stage st
+  // part q of the 12 requests of one K tile: q = 0..3 -> (block u = q / 2, operand q % 2), three pieces each
+  auto issue_part = [&](int st, int q) __attribute__((always_inline)) {
+    const int u = q >> 1;
+    if ((q & 1) == 0) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < 3; ++pc)
         dma16b(srcA[u] + pc * p.strideA, lds0 + (unsigned)(st * BX_STAGE + pc * BX_PIECE + 4 * u * 1024));
-        dma16b(srcB[u] + pc * p.strideB, lds0 + (unsigned)(st * BX_STAGE + BX_OPER + pc * BX_PIECE + 4 * u * 1024));
-      }
       srcA[u] += stepA;
+    } else {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        dma16b(srcB[u] + pc * p.strideB, lds0 + (unsigned)(st * BX_STAGE + BX_OPER + pc * BX_PIECE + 4 * u * 1024));
       srcB[u] += stepB;
     }
+  };
+  auto issue = [&](int st) __attribute__((always_inline)) {  // the next not yet requested K tile into stage st
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_part(st, q);
   };
   // ---- one K tile of 16: 16 output tiles x NPROD bf16 MFMAs per wave; the smallest partial products go in first.
   // The B pieces of the wave's four column tiles stay in registers for the tile (48), the A pieces stream per row tile.
@@ -1008,10 +1015,11 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     for (int pc = 0; pc < 3; ++pc) f.v[pc] = *reinterpret_cast<const bf16x8 *>(sA + pc * BX_PIECE + fofsA + i * 1024);
     return f;
   };
-  auto mfma_row = [&](auto iconst, const FragA &fa, const FragB &fb) __attribute__((always_inline)) {
+  auto mfma_row = [&](auto iconst, const FragA &fa, const FragB &fb, auto &&between) __attribute__((always_inline)) {
     constexpr int i = decltype(iconst)::value;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      between(j);
       f32x16 c = acc[i][j];
       if (NPROD >= 9) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2], fb.v[2][j], c, 0, 0, 0);
@@ -1051,20 +1059,33 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     auto tile = [&](const FragB &fb, const FragA &fa, FragB &fbn, FragA &fan) __attribute__((always_inline)) {
       const int st1 = st == 2 ? 0 : st + 1, st2 = st == 0 ? 2 : st - 1;   // stages of tiles t + 1 and t + 2 (= t - 1)
       const int stn = t + 1 < t1 ? st1 : st;                              // (last tile: harmless re-read of its own stage)
+      auto nothing = [](int) {};
       FragA fa1 = load_a(st, 1);
-      mfma_row(J0{}, fa, fb);
+      mfma_row(J0{}, fa, fb, nothing);
       FragA fa2 = load_a(st, 2);
-      mfma_row(J1{}, fa1, fb);
+      mfma_row(J1{}, fa1, fb, nothing);
       __builtin_amdgcn_sched_barrier(0);
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile t + 1 has landed
       __asm__ volatile("s_barrier" ::: "memory");
-      if (t + 2 < t1) issue(st2);
       __builtin_amdgcn_sched_barrier(0);
       FragA fa3 = load_a(st, 3);
-      fbn = load_b(stn);
-      mfma_row(J2{}, fa2, fb);
+      // the 12 requests of tile t + 2 go out three at a time between the column tiles of row 2 (a burst right behind the
+      // barrier stalls the wave at issue while the matrix pipe runs dry)
+      const bool req = t + 2 < t1;
+      mfma_row(J2{}, fa2, fb, [&](int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (req) issue_part(st2, j);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // first fragments of tile t + 1: the B pieces of column tile j behind the MFMAs of column tile j of row 3
+      {
+        const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
+        mfma_row(J3{}, fa3, fb, [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
+        });
+      }
       fan = load_a(stn, 0);
-      mfma_row(J3{}, fa3, fb);
       st = st1;
       ++t;
     };
@@ -1405,7 +1426,7 @@ static int gemm_split_mode() {
 // columns of an operand split at a time (workspace: 6 bytes per element of the chunk and operand)
 static int64_t bx_chunk_cols(int64_t K) {
   static int64_t kc = -1;
-  if (kc < 0) { const char *e = getenv("VIVIT_GEMM_SPLIT_KC"); kc = e ? atoll(e) : 32768; kc = kc / 16 * 16; if (kc < 16) kc = 16; }
+  if (kc < 0) { const char *e = getenv("VIVIT_GEMM_SPLIT_KC"); kc = e ? atoll(e) : 65536; kc = kc / 16 * 16; if (kc < 16) kc = 16; }
   return K < kc ? K : kc;
 }
 static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same) {
@@ -1488,6 +1509,8 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
       }
       q.K = kc;
       q.beta = k0 == 0 ? p.beta : 1.f;
+      // SYRK: only the last chunk mirrors the finished lower tiles into the upper triangle (2 = lower tiles, no mirror)
+      q.syrk = (p.syrk == 1 && k0 + kc < p.K) ? 2 : p.syrk;
       if (bx == 6)
         gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
       else if (bx == 9)

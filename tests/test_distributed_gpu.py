@@ -1,0 +1,83 @@
+"""The data-parallel path on the HIP kernels: two ranks share the one GPU of the test box (gloo; collectives on device
+tensors are staged through the host by vivit_amd.distributed), every rank back-propagates ITS batch shard on cuda:0.
+Results must equal the single-process HIP run on the whole batch (same kernels, different assembly order)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vivit_amd
+    from helpers import constant_damping, top_k_criterion
+    from torch import nn
+    from vivit_amd import distributed as vd
+    from vivit_amd.backend import backpack, extend
+
+    dev = torch.device("cuda:0")
+    ok = {}
+    # (1) raw accumulators: all-to-all path, block rows, factorised Linear, V^T g -- against one-process kernels
+    C, Ng = 10, 96
+    N = Ng * world
+    g = torch.Generator().manual_seed(3)
+    V1 = torch.randn(C, N, 40, 130, generator=g).to(dev)     # 5200 columns: all-to-all to parameter shards
+    V2 = torch.randn(C, N, 40, generator=g).to(dev)          # narrow: block rows
+    s = torch.randn(C, N, 24, generator=g).to(dev)
+    z = torch.randn(N, 50, generator=g).to(dev)
+    g1 = torch.randn(N, 40, 130, generator=g).to(dev)
+    lo, hi = rank * Ng, (rank + 1) * Ng
+    acc = vd.BatchShardedGram(C, Ng, N_grad_local=Ng)
+    acc.add_factor(V1[:, lo:hi].contiguous(), g1[lo:hi].contiguous())
+    acc.add_factor_rows(V2[:, lo:hi].contiguous())
+    acc.add_linear(s[:, lo:hi].contiguous(), z[lo:hi].contiguous())
+    G = acc.finalize().reshape(C * N, C * N)
+    VtG = acc.finalize_vtg().reshape(C * N, N)
+    Vw = torch.einsum("cno,ni->cnoi", s, z)
+    ref = sum((F.reshape(C * N, -1).double() @ F.reshape(C * N, -1).double().T) for F in (V1, V2, Vw))
+    ok["gram"] = bool((G.double() - ref).abs().max() <= 1e-5 * ref.abs().max())
+    refg = V1.reshape(C * N, -1).double() @ g1.reshape(N, -1).double().T
+    ok["vtg"] = bool((VtG.double() - refg).abs().max() <= 1e-5 * refg.abs().max())
+
+    # (2) DirectionalDampedNewtonComputation(data_parallel=True, factorised) vs the one-process run on the whole batch
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(30, 24), nn.ReLU(), nn.Linear(24, 10)).to(dev)
+    Nb = 64 * world
+    X, y = torch.rand(Nb, 30, generator=torch.Generator().manual_seed(1)).to(dev), torch.randint(0, 10, (Nb,), generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def run(Xs, ys, **kw):
+        m, lossf = extend(model), extend(nn.CrossEntropyLoss())
+        comp = vivit_amd.DirectionalDampedNewtonComputation(warn_small_eigvals=0.0, factorised=True, **kw)
+        group = {"params": list(m.parameters()), "criterion": top_k_criterion(4, must_exceed=1e-6),
+                 "damping": constant_damping(1.0)}
+        m.zero_grad()
+        with backpack(*comp.get_extensions(), extension_hook=comp.get_extension_hook([group])):
+            lossf(m(Xs), ys).backward()
+        return comp.get_result(group)
+
+    full = run(X, y)
+    lo, hi = rank * 64, (rank + 1) * 64
+    shard = run(X[lo:hi], y[lo:hi], data_parallel=True)
+    ok["newton"] = all(bool((a - b).abs().max() <= 1e-4 * b.abs().max() + 1e-7) for a, b in zip(shard, full))
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_data_parallel_on_hip_kernels_world2():
+    world = 2
+    port = 29500 + (os.getpid() % 1000)
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert r in ret and all(ret[r].values()), dict(ret)

@@ -1459,6 +1459,12 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
   const size_t slab1 = (size_t)p.M * (size_t)p.N * sizeof(float);
   const int max_split = workspace ? (int)(workspace_bytes / slab1 < 32 ? workspace_bytes / slab1 : 32) : 1;
   gemm256_plan(p.M, p.N, p.K, syrk, &p.ksplit, &p.kchunk, max_split < 1 ? 1 : max_split);
+  // the bf16-pipe kernel has no split-K: a last round of workgroups that is not full costs less than its 1.6x speed
+  const bool bx_same = p.A == p.B && p.lda == p.ldb && p.M == p.N && alay == blay;
+  if (gemm_split_mode() != 0 && workspace && workspace_bytes >= bx_workspace_bytes(p.M, p.N, p.K, bx_same)) {
+    p.ksplit = 1;
+    p.kchunk = cdiv(p.K, BK) * BK;
+  }
   p.slab = p.ksplit > 1 ? static_cast<float *>(workspace) : nullptr;
   if (getenv("VIVIT_GEMM_DEBUG"))
     fprintf(stderr, "gemm256: M=%lld N=%lld K=%lld syrk=%d ksplit=%d kchunk=%lld max_split=%d\n", (long long)p.M, (long long)p.N,

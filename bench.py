@@ -39,6 +39,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spe
 # bound).  PMC collection cannot run inside this process; the constant is only attached to the exact shape it
 # was measured on.
 SYRK_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * 3695931059.375 + 276639882.25) * 1024.0}
+# the same launch on the bf16-pipe path (profiles/r02_pmc/syrkbx_n40960_p401408_*.csv: 7 chunk launches of
+# gemm256_bx_kernel<6> + 7 of bx_split_kernel, summed)
+SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.9126e9 + 3.2269e7) + (2.6200e8 + 9.6339e7)) * 1024.0}
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
 MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 MFMA peak (256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz; same guide)
 
@@ -619,7 +622,9 @@ def main():
                                  f"achieved = algorithmic fp32 flops n(n+1)P per second",
                     "issued_bf16_tflops": achieved * split,
                     "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
-                    "traffic": None,
+                    "traffic": SYRK_BX_TRAFFIC_BYTES_PMC.get((args.workload, world)) if split == 6 else None,
+                    "traffic_note": "bytes of the first-layer weight's SYRK (98.6 % of the Gram flops: split pass + 7 chunk launches), "
+                                    "separate rocprofv3 --pmc passes (profiles/r02_pmc), FETCH_SIZE includes Infinity-Cache hits",
                 }
             roofline.update({
                 "launches_sampled": int(syrk_cnt), "avg_launch_ms": syrk_ms / max(syrk_cnt, 1),

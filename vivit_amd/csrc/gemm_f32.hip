@@ -1377,7 +1377,7 @@ static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit
   if (ksplit_out) *ksplit_out = 1;
   if (kchunk_out) *kchunk_out = cdiv(K, BK) * BK;
   static int kmin = -1;
-  if (kmin < 0) { const char *e = getenv("VIVIT_GEMM256_KMIN"); kmin = e ? atoi(e) : 1024; }
+  if (kmin < 0) { const char *e = getenv("VIVIT_GEMM256_KMIN"); kmin = e ? atoi(e) : 512; }
   if (forced == 0 || K < kmin) return false;
   const int64_t tm = cdiv(M, B2), tn = cdiv(N, B2);
   const int64_t tiles = syrk ? tm * (tm + 1) / 2 : tm * tn;

@@ -27,10 +27,11 @@ namespace vivit {
 constexpr int SNB = 64;     // half bandwidth = panel width (must equal sb2st.hip's NB)
 constexpr int QT = 128;     // rows per workgroup tile in the panel QR
 #ifndef VIVIT_SGRP
-#define VIVIT_SGRP 2
+#define VIVIT_SGRP 4
 #endif
-constexpr int SGRP = VIVIT_SGRP;  // panels per delayed trailing-matrix update (measured at n = 40 960: 1 -> 2.00 s,
-                            // 2 -> 1.52 s, 4 -> 1.52 s: beyond pairs the update is MFMA-bound)
+constexpr int SGRP = VIVIT_SGRP;  // panels per delayed trailing-matrix update (measured at n = 40 960 with the fp32 MFMA
+                            // kernels: 1 -> 2.00 s, 2 -> 1.52 s, 4 -> 1.52 s; with the rank-512 update of 4 panels on
+                            // the 256-tile kernels (K >= 512): 1.43 s)
 
 struct QrPart {
   float *u;     // [2][nwg][SNB]
@@ -241,6 +242,8 @@ static size_t sy2sb_gemm_ws_bytes(int64_t n) {
     }
     m = a > m ? a : m; m = b > m ? b : m; m = c > m ? c : m;
     m = d > m ? d : m; m = e > m ? e : m; m = f > m ? f : m;
+    const size_t u = gemm_workspace_bytes(q, q, (int64_t)2 * SNB * SGRP, true);  // trailing update (operand pieces of the bf16 pipe)
+    m = u > m ? u : m;
   }
   size_t a = gemm_workspace_bytes(SNB, SNB, n, false), b = gemm_workspace_bytes(SNB, n, n, false);
   m = a > m ? a : m; m = b > m ? b : m;

@@ -1340,7 +1340,8 @@ size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
       if (s256 > 1) {
         const size_t b256 = (size_t)s256 * (size_t)M * (size_t)N * sizeof(float);
         if (b256 > b) b = b256;
-      } else if (gemm_split_mode() != 0) {  // operand pieces of the bf16-pipe path (gemm256_launch)
+      }
+      if (gemm_split_mode() != 0) {  // operand pieces of the bf16-pipe path (gemm256_launch prefers it to split-K)
         const size_t bb = bx_workspace_bytes(M, N, K / BK * BK, syrk);
         if (bb > b) b = bb;
       }
@@ -1467,8 +1468,9 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
   }
   p.slab = p.ksplit > 1 ? static_cast<float *>(workspace) : nullptr;
   if (getenv("VIVIT_GEMM_DEBUG"))
-    fprintf(stderr, "gemm256: M=%lld N=%lld K=%lld syrk=%d ksplit=%d kchunk=%lld max_split=%d\n", (long long)p.M, (long long)p.N,
-            (long long)p.K, (int)syrk, p.ksplit, (long long)p.kchunk, max_split);
+    fprintf(stderr, "gemm256: M=%lld N=%lld K=%lld syrk=%d ksplit=%d kchunk=%lld max_split=%d lay=%d%d bxws=%d\n", (long long)p.M,
+            (long long)p.N, (long long)p.K, (int)syrk, p.ksplit, (long long)p.kchunk, max_split, alay, blay,
+            (int)(workspace && workspace_bytes >= bx_workspace_bytes(p.M, p.N, p.K, bx_same)));
   p.tiles_m = (int)cdiv(p.M, B2);
   p.tiles_n = (int)cdiv(p.N, B2);
   p.syrk = syrk ? 1 : 0;

@@ -357,7 +357,7 @@ def _spawn_ranks(nranks):
     return rc
 
 
-def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0):
+def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
     """Per-stage roofline of the eigensolver from the library's stage marks (ms summed over the timed steps).
     Algorithmic work per stage: band reduction (4/3) n^3 flop on MFMA; bulge chasing: n^2/(2 nb)
     tasks that each read and write two nb x nb blocks; the two back-transformations 2 n^3 flop each on MFMA."""
@@ -385,7 +385,10 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0):
         row = {"stage": names[k], "seconds": sec, "bound": bound}
         if bound == "mfma":
             ach = amount / sec / 1e12
-            row.update({"flops": amount, "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TF})
+            # Q1's three products per super-block run on the bf16 pipe when the operand split is on (its roofline is then
+            # the bf16 peak / split); band reduction and Q2 are fp32 MFMA kernels
+            peak = MFMA_BF16_PEAK_TF / split if (k == 6 and split) else MFMA_F32_PEAK_TF
+            row.update({"flops": amount, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak})
         elif bound == "hbm":
             ach = amount / sec / 1e9
             row.update({"bytes": amount, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
@@ -676,7 +679,8 @@ def main():
                         "unit": "TFLOP/s"}]
         if phases_roof[0]["achieved"]:
             phases_roof[0]["frac"] = phases_roof[0]["achieved"] / gram_peak
-        phases_roof += _stage_rooflines(list(stage_ms), n, args.steps, vectors, row_frac=1.0 / world)
+        phases_roof += _stage_rooflines(list(stage_ms), n, args.steps, vectors, row_frac=1.0 / world,
+                                        split=int(lib.vivit_gemm_split_mode()))
         secondary = {
             "gram_syrk_tflops": (syrk_flops / (syrk_ms / 1e3) / 1e12) if syrk_ms > 0 else None,
             "symv_gbs": (symv_bytes / (symv_ms / 1e3) / 1e9) if symv_ms > 0 else None,

@@ -586,6 +586,40 @@ def main():
         del Gs, Z_top
         if rank == 0:
             _progress(f"secondary: eigvalsh {t_vals:.2f} s, eigh top-10 {t_top:.2f} s (residual {res:.1e}, orth {orth:.1e})")
+        # (ii-b) the FACTORISED Gram build of the same MLP (what ViViTGGNExact does for Linear weights,
+        # vivit/extensions/secondorder/vivit/linear.py:72-75: (z z^T) o (s s^T) per layer + the bias Grams s s^T) -- the
+        # like-for-like partner of cpu_baseline.factorised_eigenpairs_per_s; never mixed with the materialised line
+        fz = mlp_factorised_factors(dims, batch, device)
+        Gf = torch.empty((n, n), dtype=torch.float32, device=device)
+
+        def fact_gram():
+            first = True
+            for s_, z_ in fz:
+                Gz = kernels.gram_syrk(z_)
+                Gs = kernels.gram_syrk(s_.reshape(n, -1))
+                kernels.gram_hadamard(Gz, Gs, C, batch, out=Gf, alpha=1.0, beta=0.0 if first else 1.0)   # weight
+                Gf.add_(Gs)                                                                         # bias: V_t = s
+                first = False
+            return Gf
+
+        fact_gram()
+        torch.cuda.synchronize()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        fact_gram()
+        b_.record()
+        torch.cuda.synchronize()
+        t_fact = a_.elapsed_time(b_) / 1e3
+        Gm = build_gram()
+        fact_err = float((Gf - Gm).abs().max() / Gm.abs().max())
+        secondary_lines.update({
+            "factorised_gram_s": t_fact, "factorised_vs_materialised_gram_err": fact_err,
+            "factorised_eigenpairs_per_s": n / (t_fact + eig_s),
+            "factorised_note": "Gram by the Linear fast path (2 SYRKs + fused Hadamard per layer, bias Grams) + the same symeig",
+        })
+        del Gf, Gm, fz
+        if rank == 0:
+            _progress(f"secondary: factorised Gram {t_fact * 1e3:.1f} ms (max deviation from the materialised Gram {fact_err:.1e})")
         # (iii) the same through the PUBLIC API: EighComputation's extension hook on the four parameters' materialised
         # factors (hook scheduling, Gram accumulation over the parameters, criterion callback on the host, back-projection
         # V e of the kept directions -- a 66.7 GB stream -- and normalisation are all inside the timed region)

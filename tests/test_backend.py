@@ -308,3 +308,33 @@ def test_eigvalsh_mc_with_supplied_samples(problem, device):
     w = comp.get_result(group).cpu().double()
     assert w.numel() == M * N
     np.testing.assert_allclose(w.numpy(), ref_w.numpy(), rtol=1e-4, atol=1e-5 * ref_w.abs().max().item())
+
+
+@pytest.mark.parametrize("factorised", [False, True], ids=["materialised", "factorised"])
+def test_damped_newton_optimizer_loop(factorised, device):
+    """torch.optim-style loop (the hand-written loop of docs/examples/basic_usage/example_directional_damped_newton.py:
+    144-187 behind ``Optimizer.step(closure)``): the first update equals the Newton step of the Computation class and the
+    loss of a small classification problem goes down."""
+    from vivit_amd.optim import DirectionalDampedNewton
+
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(10, 8), nn.Sigmoid(), nn.Linear(8, 3)).to(device)
+    X, y = torch.rand(16, 10).to(device), torch.randint(0, 3, (16,)).to(device)
+    m, lossf = extend(model), extend(nn.CrossEntropyLoss())
+    crit = top_k_criterion(4, must_exceed=1e-7)
+    # reference step from the Computation class on the initial parameters
+    comp = vivit_amd.DirectionalDampedNewtonComputation(warn_small_eigvals=0.0, factorised=factorised)
+    group = {"params": list(m.parameters()), "criterion": crit, "damping": constant_damping(1.0)}
+    run_backward(m, X, y, lossf, comp.get_extensions(), comp.get_extension_hook([group]))
+    expect = [p.detach().clone() + s for p, s in zip(m.parameters(), comp.get_result(group))]
+
+    opt = DirectionalDampedNewton(m.parameters(), criterion=crit, damping=constant_damping(1.0), backpack=backpack, lr=1.0,
+                                  warn_small_eigvals=0.0, factorised=factorised)
+    losses = [opt.step(lambda: lossf(m(X), y)).item()]
+    for p, e in zip(m.parameters(), expect):
+        close(p, e, rtol=1e-4, atol=1e-6)
+    for _ in range(4):
+        losses.append(opt.step(lambda: lossf(m(X), y)).item())
+    assert losses[-1] < losses[0]
+    with pytest.raises(ValueError):
+        opt.step()

@@ -49,6 +49,17 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
   const int L = (n - c0) < NB ? (n - c0) : NB;
   if (k < 0 || L <= 0 || s > n - 3) return;
 
+  // the previous level's reflector and its tau (k > 0) resp. column s of the band (k = 0) are requested BEFORE the
+  // block loads and the barrier: their global-load latency (~0.7 us, the next thing wave 0 would wait for) overlaps
+  float pv_pre = 0.f, ptau_pre = 0.f, x0_pre = 0.f;
+  if (wave == 0) {
+    if (k > 0) {
+      pv_pre = R2[(int64_t)(s % rmod) * ldr + (c0 - NB + lane)];
+      ptau_pre = tau2[(int64_t)s * nk + (k - 1)];
+    } else {
+      x0_pre = lane < L ? AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] : 0.f;
+    }
+  }
   // ---- load: wave w takes band rows r = w, w + 4, ...
 #pragma unroll
   for (int rr = 0; rr < NB / 4; ++rr) {
@@ -79,8 +90,8 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
     if (k > 0) {
 #pragma unroll
       for (int r = 0; r < NB; ++r) ec[r] = sE[r * LDT + lane];
-      pv = R2[(int64_t)(s % rmod) * ldr + (c0 - NB + lane)];
-      const float ptau = tau2[(int64_t)s * nk + (k - 1)];
+      pv = pv_pre;
+      const float ptau = ptau_pre;
       // (i) E <- E (I - ptau pv pv^T): row copy and column copy
       float dot = 0.f;
 #pragma unroll
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
       for (int r = 0; r < NB; ++r) ec[r] -= rl(g, r) * pv;
       x = er[0];
     } else {
-      x = lane < L ? AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] : 0.f;  // column s of the band
+      x = x0_pre;  // column s of the band
     }
     // (ii) Householder reflector from x
     const float ssq = wave_sum(lane >= 1 ? x * x : 0.f);

@@ -21,3 +21,21 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory(request):
+    """Full-size GPU tests size themselves against the free HBM and skip when it is short: give every GPU test a clean
+    slate (tensors kept alive by an earlier failure's traceback, cached kernel workspaces, the allocator's cache)."""
+    if "gpu" in request.keywords:
+        import gc
+
+        import torch
+
+        if torch.cuda.is_available():
+            from vivit_amd import kernels
+
+            gc.collect()
+            kernels._WORKSPACES.clear()
+            torch.cuda.empty_cache()
+    yield

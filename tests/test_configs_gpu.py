@@ -44,7 +44,8 @@ def ggn_block_vec(model, lossname, X, params, vecs, samples=None):
         if samples is not None:
             p = out.softmax(1)
             S = (p.unsqueeze(0) - samples) / math.sqrt(samples.shape[0] * N)       # [M, N, C]
-            HJv = torch.einsum("mnc,mnd,nd->nc", S, S, Jv)
+            t = (S * Jv.unsqueeze(0)).sum(2)                                        # [M, N]: s_mn . (J v)_n
+            HJv = (S * t.unsqueeze(2)).sum(0)                                       # [N, C]: sum_m s_mn (s_mn . J_n v)
         elif lossname == "ce":
             p = out.softmax(1)
             HJv = (p * Jv - p * (p * Jv).sum(1, keepdim=True)) / N

@@ -11,7 +11,7 @@
 // Task (s, k) only depends on (s, k-1) and (s-1, k+1), so all tasks with equal t = 2 s + k are
 // independent: the host launches one kernel per wavefront step t (about 2 n launches of up to
 // n / (2 NB - 1) workgroups; a dependent launch boundary costs less than an in-kernel grid barrier
-// and cannot deadlock).  Each task is one 256-thread workgroup: cooperative load/store, one wave computes.
+// and cannot deadlock).  Each task is one 256-thread workgroup (four waves, each a quarter of the columns).
 //
 // The reflectors are kept for the back-transformation: v(s,k) at R2[s][R_k], tau at tau2[s][k].
 #include "common.h"
@@ -20,6 +20,9 @@
 
 namespace vivit {
 
+#ifndef SB2ST_VARIANT
+#define SB2ST_VARIANT 0
+#endif
 constexpr int NB = 64;             // half bandwidth
 constexpr int LDAB = 2 * NB + 1;   // band row length
 
@@ -30,129 +33,187 @@ __device__ __forceinline__ float rl(float v, int l) {
 
 constexpr int LDT = NB + 4;  // LDS row stride: 16-byte aligned rows, conflict-free row-per-lane ds_read_b128
 
+// value of lane `l` (wave-uniform, run-time) as a wave-uniform scalar
+__device__ __forceinline__ float rlu(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// Sum over the 64 lanes, identical in every lane: four DPP adds inside each row of 16 lanes (xor 1, xor 2, mirror in 8,
+// mirror in 16) and one readlane per row - about a tenth of the latency of the ds_bpermute butterfly.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
+}
+
+// 1 / x and sqrt(x) from the hardware approximations (1 ulp) plus one Newton step: the IEEE division / square-root
+// expansions are ~100 dependent cycles each on the critical path of every task.
+__device__ __forceinline__ float rcp_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(r, fmaf(-x, r, 1.f), r);
+}
+__device__ __forceinline__ float sqrt_nr(float x) {
+  const float y = __builtin_amdgcn_sqrtf(x);
+  return y > 0.f ? fmaf(fmaf(-y, y, x), 0.5f * __builtin_amdgcn_rcpf(y), y) : y;
+}
+
 // One task per 256-thread workgroup.  The four waves load the two 64 x 64 blocks from the band (one
 // coalesced 256-byte segment per band row: row r of the band holds [E row r | lower D row r]
-// contiguously) into LDS; wave 0 then takes row `lane` of E and of D and column `lane` of E into
-// registers and runs the whole task without a single barrier - every cross-row quantity is a
-// v_readlane broadcast or a wave reduction - and the four waves store the blocks back.  (The first
-// version kept E and D in LDS and needed ten barrier-separated phases: 12 us per wavefront step, most
-// of it synchronisation latency.)
+// contiguously; all 32 loads of a thread are in flight together) into LDS.  Thread (wave q, lane r) then
+// owns columns 16 q .. 16 q + 15 of row r of E and of D in registers.  Every matrix-vector product is a
+// 16-term partial sum per thread, completed across the four waves through LDS (two barriers: one for
+// g = E pv, one for E^T v and D v together); the small vector work (reflector, tau, w) is done redundantly
+// and bit-identically by every wave, so no broadcast barrier is needed.  (History: ten barrier-separated
+// phases on LDS-resident blocks: 12 us per wavefront step; one wave with the blocks in registers and
+// v_readlane broadcasts, no barrier: 11.5 us of which 6.7 us were that single wave's 512 FMAs + 450
+// readlanes and 4.7 us the serialised loads - scripts/probe/run_variant_sb2st.py.)
 __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB, int n, int t, int s_lo,
                                                          float *__restrict__ R2, int64_t ldr, float *__restrict__ tau2,
                                                          int nk, int rmod) {
   __shared__ __attribute__((aligned(16))) float sE[NB * LDT];
   __shared__ __attribute__((aligned(16))) float sD[NB * LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float red[3][4][NB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = s_lo + blockIdx.x;
   const int k = t - 2 * s;
   const int c0 = s + 1 + k * NB;
   const int L = (n - c0) < NB ? (n - c0) : NB;
   if (k < 0 || L <= 0 || s > n - 3) return;
+  const int q0 = 16 * wave;
 
-  // the previous level's reflector and its tau (k > 0) resp. column s of the band (k = 0) are requested BEFORE the
-  // block loads and the barrier: their global-load latency (~0.7 us, the next thing wave 0 would wait for) overlaps
-  float pv_pre = 0.f, ptau_pre = 0.f, x0_pre = 0.f;
-  if (wave == 0) {
-    if (k > 0) {
-      pv_pre = R2[(int64_t)(s % rmod) * ldr + (c0 - NB + lane)];
-      ptau_pre = tau2[(int64_t)s * nk + (k - 1)];
-    } else {
-      x0_pre = lane < L ? AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] : 0.f;
-    }
+  // ---- load: wave w takes band rows r = w, w + 4, ...; every address is inside the band array whatever
+  // r, lane and k are, so the loads are unconditional (all in flight at once) and masked afterwards
+  float pv = 0.f, ptau = 0.f, x = 0.f;
+  if (k > 0) {
+    pv = R2[(int64_t)(s % rmod) * ldr + (c0 - NB + lane)];
+    ptau = tau2[(int64_t)s * nk + (k - 1)];
+  } else {
+    x = lane < L ? AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] : 0.f;  // column s of the band
   }
-  // ---- load: wave w takes band rows r = w, w + 4, ...
+#if SB2ST_VARIANT != 2
+  float ev[NB / 4], dv[NB / 4];
 #pragma unroll
   for (int rr = 0; rr < NB / 4; ++rr) {
     const int r = 4 * rr + wave;
     const float *row = AB + (int64_t)(c0 + (r < L ? r : 0)) * LDAB;
+    ev[rr] = row[NB - r + lane];                                   // E[r][lane]
+    dv[rr] = row[lane <= r ? 2 * NB - r + lane : 2 * NB];          // D[r][lane], lane <= r
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep the consumers behind ALL loads (hipcc hoists the first one otherwise)
+#endif
+#pragma unroll
+  for (int rr = 0; rr < NB / 4; ++rr) {
+    const int r = 4 * rr + wave;
     const bool in = r < L;
-    const float ev = (in && k > 0) ? row[NB - r + lane] : 0.f;           // E[r][lane]
-    const float dv = (in && lane <= r) ? row[2 * NB - r + lane] : 0.f;   // D[r][lane], lane <= r
-    sE[r * LDT + lane] = ev;
+#if SB2ST_VARIANT == 2   // timing attribution only (results invalid): no block loads
+    const float e1 = in ? 0.001f * (r + lane) : 0.f, d1 = in ? 0.002f * (r - lane) : 0.f;
+#else
+    const float e1 = (in && k > 0) ? ev[rr] : 0.f, d1 = in ? dv[rr] : 0.f;
+#endif
+    sE[r * LDT + lane] = e1;
     if (lane <= r) {
-      sD[r * LDT + lane] = dv;
-      sD[lane * LDT + r] = dv;
+      sD[r * LDT + lane] = d1;
+      sD[lane * LDT + r] = d1;
     }
   }
   __syncthreads();
 
+#if SB2ST_VARIANT != 1     // (variant 1: timing attribution only, results invalid: no compute)
+  float er[16], d[16];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    const float4 a = *reinterpret_cast<const float4 *>(sE + lane * LDT + q0 + 4 * c4);
+    er[4 * c4] = a.x; er[4 * c4 + 1] = a.y; er[4 * c4 + 2] = a.z; er[4 * c4 + 3] = a.w;
+    const float4 b = *reinterpret_cast<const float4 *>(sD + lane * LDT + q0 + 4 * c4);
+    d[4 * c4] = b.x; d[4 * c4 + 1] = b.y; d[4 * c4 + 2] = b.z; d[4 * c4 + 3] = b.w;
+  }
+  float g = 0.f;
+  if (k > 0) {
+    // (i) g = ptau E pv;  E <- E - g pv^T
+    float pvq[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pvq[j] = rlu(pv, q0 + j);
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) part += er[j] * pvq[j];
+    red[0][wave][lane] = part;
+    __syncthreads();
+    g = ptau * ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) er[j] -= g * pvq[j];
+    x = sE[lane * LDT] - g * rl(pv, 0);   // first column of the updated E
+  }
+  // (ii) Householder reflector from x (every wave, identically)
+  const float ssq = wave_sum_dpp(lane >= 1 ? x * x : 0.f);
+  const float alpha = rl(x, 0);
+  float tau = 0.f, beta = alpha, scal = 0.f;
+  if (ssq > 0.f) {
+    beta = -copysignf(sqrt_nr(alpha * alpha + ssq), alpha);
+    tau = (beta - alpha) * rcp_nr(beta);
+    scal = rcp_nr(alpha - beta);
+  }
+  const float v = lane < L ? (lane == 0 ? 1.f : x * scal) : 0.f;
+  float vq[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) vq[j] = rlu(v, q0 + j);
+  if (k > 0) {
+    // z = tau E'^T v with E' = E - g pv^T (E still unchanged in LDS): this wave's 16 rows, lane = column
+    float zp = 0.f, gv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      zp += vq[j] * sE[(q0 + j) * LDT + lane];
+      gv += vq[j] * rlu(g, q0 + j);
+    }
+    red[1][wave][lane] = zp - pv * gv;
+  }
+  {
+    // (iii) p = tau D v: this wave's 16 columns, lane = row
+    float pp = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pp += d[j] * vq[j];
+    red[2][wave][lane] = pp;
+  }
+  __syncthreads();
+  if (k > 0) {
+    const float z = tau * ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) er[j] -= v * rlu(z, q0 + j);
+    if (wave == 0 && lane < L) er[0] = (lane == 0) ? beta : 0.f;  // exact zeros below the new sub-band entry
+  } else if (wave == 0 && lane < L) {
+    AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] = (lane == 0) ? beta : 0.f;
+  }
+  // w = p - tau/2 (p.v) v;  D -= v w^T + w v^T
+  const float p = tau * ((red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]));
+  const float pdotv = wave_sum_dpp(p * v);
+  const float w = p - 0.5f * tau * pdotv * v;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) d[j] -= v * rlu(w, q0 + j) + w * vq[j];
+  // results back to LDS (rows), reflector to global memory
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    if (k > 0)
+      *reinterpret_cast<float4 *>(sE + lane * LDT + q0 + 4 * c4) = make_float4(er[4 * c4], er[4 * c4 + 1], er[4 * c4 + 2], er[4 * c4 + 3]);
+    *reinterpret_cast<float4 *>(sD + lane * LDT + q0 + 4 * c4) = make_float4(d[4 * c4], d[4 * c4 + 1], d[4 * c4 + 2], d[4 * c4 + 3]);
+  }
   if (wave == 0) {
-    float er[NB], ec[NB], d[NB];
-#pragma unroll
-    for (int c4 = 0; c4 < NB / 4; ++c4) {
-      const float4 a = *reinterpret_cast<const float4 *>(sE + lane * LDT + 4 * c4);
-      er[4 * c4] = a.x; er[4 * c4 + 1] = a.y; er[4 * c4 + 2] = a.z; er[4 * c4 + 3] = a.w;
-      const float4 b = *reinterpret_cast<const float4 *>(sD + lane * LDT + 4 * c4);
-      d[4 * c4] = b.x; d[4 * c4 + 1] = b.y; d[4 * c4 + 2] = b.z; d[4 * c4 + 3] = b.w;
-    }
-    float x;
-    float pv = 0.f;
-    if (k > 0) {
-#pragma unroll
-      for (int r = 0; r < NB; ++r) ec[r] = sE[r * LDT + lane];
-      pv = pv_pre;
-      const float ptau = ptau_pre;
-      // (i) E <- E (I - ptau pv pv^T): row copy and column copy
-      float dot = 0.f;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) dot += er[c] * rl(pv, c);
-      const float g = dot * ptau;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) er[c] -= g * rl(pv, c);
-#pragma unroll
-      for (int r = 0; r < NB; ++r) ec[r] -= rl(g, r) * pv;
-      x = er[0];
-    } else {
-      x = x0_pre;  // column s of the band
-    }
-    // (ii) Householder reflector from x
-    const float ssq = wave_sum(lane >= 1 ? x * x : 0.f);
-    const float alpha = rl(x, 0);
-    float tau = 0.f, beta = alpha, scal = 0.f;
-    if (ssq > 0.f) {
-      beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
-      tau = (beta - alpha) / beta;
-      scal = 1.f / (alpha - beta);
-    }
-    const float v = lane < L ? (lane == 0 ? 1.f : x * scal) : 0.f;
-    if (k > 0) {
-      // z[c] = tau sum_r v[r] E[r][c] (lane c, column copy); E <- E - v z^T (row copy)
-      float z = 0.f;
-#pragma unroll
-      for (int r = 0; r < NB; ++r) z += rl(v, r) * ec[r];
-      z *= tau;
-#pragma unroll
-      for (int c = 0; c < NB; ++c) er[c] -= v * rl(z, c);
-      if (lane < L) er[0] = (lane == 0) ? beta : 0.f;  // exact zeros below the new sub-band entry
-    } else if (lane < L) {
-      AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] = (lane == 0) ? beta : 0.f;
-    }
-    // (iii) D <- H D H:  p = tau D v;  w = p - tau/2 (p.v) v;  D -= v w^T + w v^T
-    float p = 0.f;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) p += d[c] * rl(v, c);
-    p *= tau;
-    const float pdotv = wave_sum(p * v);
-    const float w = p - 0.5f * tau * pdotv * v;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) d[c] -= v * rl(w, c) + w * rl(v, c);
-    // results back to LDS (rows), reflector to global memory
-#pragma unroll
-    for (int c4 = 0; c4 < NB / 4; ++c4) {
-      if (k > 0)
-        *reinterpret_cast<float4 *>(sE + lane * LDT + 4 * c4) = make_float4(er[4 * c4], er[4 * c4 + 1], er[4 * c4 + 2], er[4 * c4 + 3]);
-      *reinterpret_cast<float4 *>(sD + lane * LDT + 4 * c4) = make_float4(d[4 * c4], d[4 * c4 + 1], d[4 * c4 + 2], d[4 * c4 + 3]);
-    }
     if (lane < L) R2[(int64_t)(s % rmod) * ldr + c0 + lane] = v;
     if (lane == 0) tau2[(int64_t)s * nk + k] = tau;
   }
+#endif
   __syncthreads();
 
   // ---- store: lower part of D and E, same segments as loaded
 #pragma unroll
   for (int rr = 0; rr < NB / 4; ++rr) {
     const int r = 4 * rr + wave;
+#if SB2ST_VARIANT == 2
+    if (r < L && sE[r * LDT + lane] == 12345.678f) {
+#else
     if (r < L) {
+#endif
       float *row = AB + (int64_t)(c0 + r) * LDAB;
       if (k > 0) row[NB - r + lane] = sE[r * LDT + lane];
       if (lane <= r) row[2 * NB - r + lane] = sD[r * LDT + lane];

@@ -16,6 +16,17 @@ __device__ __forceinline__ unsigned sort_key(float f) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// 1 / x and sqrt(x) from the hardware approximations (1 ulp) plus one Newton step: the IEEE division / square-root
+// expansions are ~100 dependent cycles each on the critical path of every task.
+__device__ __forceinline__ float rcp_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(r, fmaf(-x, r, 1.f), r);
+}
+__device__ __forceinline__ float sqrt_nr(float x) {
+  const float y = __builtin_amdgcn_sqrtf(x);
+  return y > 0.f ? fmaf(fmaf(-y, y, x), 0.5f * __builtin_amdgcn_rcpf(y), y) : y;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -48,17 +48,6 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
 }
 
-// 1 / x and sqrt(x) from the hardware approximations (1 ulp) plus one Newton step: the IEEE division / square-root
-// expansions are ~100 dependent cycles each on the critical path of every task.
-__device__ __forceinline__ float rcp_nr(float x) {
-  const float r = __builtin_amdgcn_rcpf(x);
-  return fmaf(r, fmaf(-x, r, 1.f), r);
-}
-__device__ __forceinline__ float sqrt_nr(float x) {
-  const float y = __builtin_amdgcn_sqrtf(x);
-  return y > 0.f ? fmaf(fmaf(-y, y, x), 0.5f * __builtin_amdgcn_rcpf(y), y) : y;
-}
-
 // One task per 256-thread workgroup.  The four waves load the two 64 x 64 blocks from the band (one
 // coalesced 256-byte segment per band row: row r of the band holds [E row r | lower D row r]
 // contiguously; all 32 loads of a thread are in flight together) into LDS.  Thread (wave q, lane r) then

@@ -81,57 +81,81 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
   __shared__ __attribute__((aligned(16))) float zq16[16][SNB];
   const int tid = threadIdx.x;
   const int64_t r0 = (int64_t)blockIdx.x * QT;
-  for (int idx = tid; idx < QT * (SNB / 4); idx += 256) {
+  // Every global load of the launch is issued before anything waits (the panel was written by the previous launch on
+  // other XCDs, so each load is a trip to the memory side: serialised, the 8 tile loads + the partials + din were
+  // ~5 of the launch's 8.3 us): tile quads and din into registers first, the partials right behind them.
+  constexpr int NTL = QT * (SNB / 4) / 256;
+  float4 tl[NTL];
+#pragma unroll
+  for (int i = 0; i < NTL; ++i) {
+    const int idx = tid + 256 * i;
     const int rl = idx / (SNB / 4), c4 = (idx - rl * (SNB / 4)) * 4;
     const int64_t r = r0 + rl;
-    const bool ok = r < mp;
-    const float4 x = *reinterpret_cast<const float4 *>(pan + (ok ? r : 0) * SNB + c4);
-    tile[rl][c4 + 0] = ok ? x.x : 0.f;
-    tile[rl][c4 + 1] = ok ? x.y : 0.f;
-    tile[rl][c4 + 2] = ok ? x.z : 0.f;
-    tile[rl][c4 + 3] = ok ? x.w : 0.f;
+    tl[i] = *reinterpret_cast<const float4 *>(pan + (r < mp ? r : 0) * SNB + c4);
+  }
+  // first batch of the partial vectors of column c (prologue launch c = -1: loaded and ignored, so that the tile is
+  // written to LDS at ONE place behind all loads - with several call sites hipcc hoists the masking selects, and
+  // with them the wait for the tile loads, in front of the partial loads).  Thread (group q of 16, column quad c4)
+  // takes partials q, q + 16, ... as float4, 20 independent loads in flight per batch (with 4 scalar loads in
+  // flight this reduction was 6.6 of the launch's 12.4 us: pure L2 latency)
+  const int par = c & 1;
+  const float *uin = pt.u + (int64_t)par * nwg * SNB;
+  const float *din = pt.diag + par * SNB;
+  const int cq4 = tid & 15, q16 = tid >> 4;
+  float4 pv[20];
+#pragma unroll
+  for (int i = 0; i < 20; ++i) {
+    const int w = q16 + 16 * i;
+    pv[i] = *reinterpret_cast<const float4 *>(uin + (int64_t)(w < nwg ? w : 0) * SNB + 4 * cq4);
+  }
+  const float din_c = din[c >= 0 ? c : 0], din_t = din[tid & (SNB - 1)];
+  __builtin_amdgcn_sched_barrier(0);  // every load in flight before the first one is consumed
+#pragma unroll
+  for (int i = 0; i < NTL; ++i) {
+    const int idx = tid + 256 * i;
+    const int rl = idx / (SNB / 4), c4 = (idx - rl * (SNB / 4)) * 4;
+    const bool ok = r0 + rl < mp;
+    tile[rl][c4 + 0] = ok ? tl[i].x : 0.f;
+    tile[rl][c4 + 1] = ok ? tl[i].y : 0.f;
+    tile[rl][c4 + 2] = ok ? tl[i].z : 0.f;
+    tile[rl][c4 + 3] = ok ? tl[i].w : 0.f;
   }
   if (c >= 0) {
-    const int par = c & 1;
-    const float *uin = pt.u + (int64_t)par * nwg * SNB;
-    const float *din = pt.diag + par * SNB;
     {
-      // u = sum over the nwg partial vectors: thread (group q of 16, column quad c4) takes partials q, q+16, ...
-      // as float4, 20 independent loads in flight per batch (with 4 scalar loads in flight this reduction was
-      // 6.6 of the launch's 12.4 us: pure L2 latency)
-      const int c4 = tid & 15, q = tid >> 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int w0 = q; w0 < nwg; w0 += 16 * 20) {
+#pragma unroll
+      for (int i = 0; i < 20; ++i)
+        if (q16 + 16 * i < nwg) { acc.x += pv[i].x; acc.y += pv[i].y; acc.z += pv[i].z; acc.w += pv[i].w; }
+      for (int w0 = q16 + 16 * 20; w0 < nwg; w0 += 16 * 20) {   // (more than 320 workgroups: n > 40 960)
         float4 v[20];
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
           const int w = w0 + 16 * i;
-          const bool ok = w < nwg;
-          const float4 x = *reinterpret_cast<const float4 *>(uin + (int64_t)(ok ? w : 0) * SNB + 4 * c4);
-          v[i] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[i] = *reinterpret_cast<const float4 *>(uin + (int64_t)(w < nwg ? w : 0) * SNB + 4 * cq4);
         }
 #pragma unroll
-        for (int i = 0; i < 20; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+        for (int i = 0; i < 20; ++i)
+          if (w0 + 16 * i < nwg) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
       }
-      *reinterpret_cast<float4 *>(&zq16[q][4 * c4]) = acc;
+      *reinterpret_cast<float4 *>(&zq16[q16][4 * cq4]) = acc;
     }
     __syncthreads();  // tile and zq16 complete
     // ||x||^2 is the partial sum of column c itself: u[c] = sum_{r>c} x_r pan[r][c] = sum x_r^2
     float ssq = 0.f;
 #pragma unroll
     for (int g2 = 0; g2 < 16; ++g2) ssq += zq16[g2][c];
-    const float alpha = din[c];
+    const float alpha = din_c;
     float tau = 0.f, beta = alpha, scal = 0.f;
     if (ssq > 0.f) {
-      beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
-      tau = (beta - alpha) / beta;
-      scal = 1.f / (alpha - beta);
+      beta = -copysignf(sqrt_nr(alpha * alpha + ssq), alpha);
+      tau = (beta - alpha) * rcp_nr(beta);
+      scal = rcp_nr(alpha - beta);
     }
     if (tid < SNB) {
       float u = 0.f;
 #pragma unroll
       for (int g2 = 0; g2 < 16; ++g2) u += zq16[g2][tid];
-      zs[tid] = tid > c ? tau * (din[tid] + scal * u) : 0.f;
+      zs[tid] = tid > c ? tau * (din_t + scal * u) : 0.f;
     }
     if (tid < QT) {
       const int64_t r = r0 + tid;

@@ -909,26 +909,36 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     int opaque = 0;
     __asm__ volatile("" : "+v"(opaque));  // keeps the 256 output addresses out of LICM's reach (see gemm256_kernel)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      // one row of four 32 x 32 tiles at a time: 64 loads in flight, then 64 stores (tile by tile - 16 loads, wait,
+      // 16 stores - the read-modify-write cost ~40 us per 256 x 256 tile: half of a K = 512 update's time)
+      __asm__ volatile("" ::: "memory");
+      const int64_t rbase = row0 + wm * 128 + i * 32 + 4 * h + opaque;
+      if (full_tile) {
+        float old[4][16];
+        if (beta != 0.f) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        __asm__ volatile("" ::: "memory");
-        const int64_t rbase = row0 + wm * 128 + i * 32 + 4 * h + opaque, col = col0 + wn * 128 + j * 32 + r;
-        if (full_tile) {
-          gptr cbase = Cout + rbase * ldc + col;
-          float old[16];
-          if (beta != 0.f) {
+          for (int j = 0; j < 4; ++j) {
+            gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + r);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) old[e] = cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc];
+            for (int e = 0; e < 16; ++e) old[j][e] = cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc];
           }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + r);
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             float v = alpha_ * acc[i][j][e];
-            if (beta != 0.f) v += beta * old[e];
+            if (beta != 0.f) v += beta * old[j][e];
             cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc] = v;
             acc[i][j][e] = v;
           }
-        } else {
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t col = col0 + wn * 128 + j * 32 + r;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
@@ -942,6 +952,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
           }
         }
       }
+    }
   };
   auto clear_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll

@@ -1,0 +1,18 @@
+"""symeig (vectors) at n = 40960 once on a Gram matrix, printing the library's stage marks (ms)."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import torch
+from vivit_amd import kernels, _lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40960
+V = torch.randn(n, n // 2, device="cuda")
+G = kernels.gram_syrk(V); del V
+lib = _lib.load()
+kernels.symeig(G, eigenvectors=True)
+torch.cuda.synchronize()
+lib.vivit_profile_begin(64)
+w, Z = kernels.symeig(G, eigenvectors=True)
+torch.cuda.synchronize()
+ms = (ctypes.c_double * 16)()
+lib.vivit_profile_stages(ms, 16)
+lib.vivit_profile_end((ctypes.c_double * 6)())
+print(os.environ.get("TAG", ""), " ".join("%.0f" % x for x in ms), "total %.0f ms" % sum(ms), flush=True)

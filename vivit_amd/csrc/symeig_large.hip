@@ -57,7 +57,19 @@ __global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict_
 // reflectors) so that the three products of the back-transformation have a long contraction / wide
 // output (the 256 x 256 tile kernel; Zt is streamed once per 1024 instead of once per 128 reflectors):
 //   H_1 H_2 = I - [Y1 Y2] [[T1, -T1 (Y1^T Y2) T2], [0, T2]] [Y1 Y2]^T        (applied recursively).
-static int bt_nsub(int64_t n) { return n >= 8192 ? 8 : (n >= 2048 ? 2 : 1); }
+static int bt_nsub(int64_t n) {   // largest super-block (workspace sizing)
+  static int forced = -2;
+  if (forced == -2) { const char *e = getenv("VIVIT_BT_NSUB"); forced = e ? atoi(e) : -1; }
+  if (forced > 0 && n >= 8192) return forced;   // (power of two; experiments)
+  return n >= 16384 ? 16 : (n >= 8192 ? 8 : (n >= 2048 ? 2 : 1));
+}
+// Super-block actually used for `nrows` rows of Zt: the read-modify-write of Zt per super-block favours 2048
+// reflectors when (nearly) all rows are transformed (Q1 at n = 40 960: 1037 / 816 / 767 / 757 ms for 512 / 1024 /
+// 2048 / 4096), while the T factor work (2 KS n^2 flop, independent of nrows) favours 1024 for a few selected rows.
+static int bt_nsub_rows(int64_t n, int64_t nrows) {
+  const int nmax = bt_nsub(n);
+  return (nmax > 8 && nrows < 4096) ? 8 : nmax;
+}
 
 // split-K slab of the products for ANY nrows <= n (row-range mode): a one-tile-wide output gets up to
 // 2048 / tiles splits, so splits * nrows <= 2048 * 128 and the slab is bounded by 2048 * 128 * KS floats
@@ -87,14 +99,14 @@ template <class Take>
 static int backtransform_launch(const float *A, int64_t n, int64_t lda, const float *tau, int shift, int64_t jmax,
                                 float *Qt, int64_t ldq, int64_t nrows, Take &take, hipStream_t stream) {
   const int ni = (int)n;
-  const int nsub = bt_nsub(n);
-  const int64_t KS = (int64_t)KB * nsub;
-  float *Yt = (float *)take(sizeof(float) * KS * n);
-  float *W1 = (float *)take(sizeof(float) * n * KS);
-  float *W2 = (float *)take(sizeof(float) * n * KS);
-  float *S = (float *)take(sizeof(float) * KS * KS);
-  float *T = (float *)take(sizeof(float) * KS * KS);
-  float *X = (float *)take(sizeof(float) * KS * KS);
+  const int nsub = bt_nsub_rows(n, nrows);
+  const int64_t KS = (int64_t)KB * nsub, KSmax = (int64_t)KB * bt_nsub(n);   // (buffers are carved for the largest)
+  float *Yt = (float *)take(sizeof(float) * KSmax * n);
+  float *W1 = (float *)take(sizeof(float) * n * KSmax);
+  float *W2 = (float *)take(sizeof(float) * n * KSmax);
+  float *S = (float *)take(sizeof(float) * KSmax * KSmax);
+  float *T = (float *)take(sizeof(float) * KSmax * KSmax);
+  float *X = (float *)take(sizeof(float) * KSmax * KSmax);
   const size_t gws_bytes = bt_gemm_ws_bytes(n);
   void *gws = take(gws_bytes);
   if (jmax < 0 || nrows <= 0) return VIVIT_OK;

@@ -264,3 +264,23 @@ def test_large_products_on_the_256_tile_path(kind):
     J = torch.arange(0, n, 13, device=dev)
     err = (C[I][:, J].double() - ref(I, J)).abs().max().item()
     assert err <= 2e-5 * k ** 0.5, err   # fp32 accumulation of k unit-variance products
+
+
+@pytest.mark.parametrize("m,n,k,pad", [(64, 64, 40960, 0), (64, 384, 20480, 64), (33, 100, 4100, 0), (64, 1024, 2048, 0),
+                                       (7, 64, 8196, 4), (64, 128, 2052, 0)])
+def test_deep_k_small_output_product(m, n, k, pad):
+    """``A B^T`` with at most 64 output rows and a deep K-contiguous contraction (the band reduction's panel Gram blocks:
+    the dedicated split-K kernel with 128-k steps); ragged M / N / K tails, padded leading dimensions, alpha / beta."""
+    from vivit_amd import kernels
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(m + n + k)
+    A = torch.randn(m, k + pad, device=dev, generator=g)[:, :k]
+    B = torch.randn(n, k + pad, device=dev, generator=g)[:, :k]
+    ref = A.double() @ B.double().T
+    out = kernels.gemm_nt(A, B)
+    scale = (A.double().norm(dim=1)[:, None] * B.double().norm(dim=1)[None, :])
+    assert ((out.double() - ref).abs() / scale).max().item() < 2e-6
+    C0 = torch.randn(m, n, device=dev, generator=g)
+    out2 = kernels.gemm_nt(A, B, out=C0.clone(), alpha=-0.5, beta=2.0)
+    assert ((out2.double() - (-0.5 * ref + 2.0 * C0.double())).abs() / (scale + 1.0)).max().item() < 2e-6

@@ -1296,6 +1296,171 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
   C[i * ldc + j] = v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deep-K products with a small output, both operands K-contiguous (the band reduction's 64 x 64 ... 64 x 384 Gram
+// blocks over m = 4e4 rows: S = V^T V, V^T [V1 W1 ...], X^T V).  The general tile kernels move one 16-k tile (64 bytes
+// per operand row) per pipeline step and are latency-bound here (0.2-0.5 TB/s; 105-140 us per product at m = 40 960).
+// This kernel gives every workgroup a 64 x 64 output block and a K range, and streams 128 k at a time: each operand
+// row contributes 512 contiguous bytes per step, all 16 float4 loads of a thread are in flight while the previous
+// step's 64 MFMAs run from LDS (row stride 132 floats: conflict-free ds_read_b128 rows).  MFMA step pairs
+// k = 8 j + i (lanes 0-31) with k = 8 j + 4 + i (lanes 32-63) for both operands, so fragments are plain float4 reads.
+// Split-K partials go to a slab [split][M][N] and are summed in a fixed order by gemm_tsk_reduce_kernel.
+constexpr int TSK_KC = 128, TSK_LD = TSK_KC + 4, TSK_NL = 64 * (TSK_KC / 4) / 256;  // 8 float4 per thread and operand
+struct TskArgs {
+  const float *A, *B;
+  float *C, *slab;
+  int64_t lda, ldb, ldc, K, kchunk;
+  int M, N, nsplit;
+  float alpha, beta;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tsk_kernel(TskArgs p) {
+  __shared__ __attribute__((aligned(16))) float sA[64 * TSK_LD];
+  __shared__ __attribute__((aligned(16))) float sB[64 * TSK_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int jb = blockIdx.y, ks = blockIdx.x;
+  const int64_t kbeg = (int64_t)ks * p.kchunk;
+  const int64_t kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float4 ra[TSK_NL], rb[TSK_NL];
+  // loads are unconditional (clamped addresses) and masked only when they are written to LDS: a select right behind
+  // each load makes hipcc wait for it before issuing the next one (16 serialised round trips: 10 us per step)
+  auto gload = [&](int64_t k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TSK_NL; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / (TSK_KC / 4), c = (idx - row * (TSK_KC / 4)) * 4;
+      const int64_t k = k0 + c;
+      const int64_t kc = k < kend ? k : kbeg;  // K % 4 == 0: all four lanes of the float4 in or out
+      const int brow = 64 * jb + row;
+      ra[i] = *reinterpret_cast<const float4 *>(p.A + (int64_t)(row < p.M ? row : 0) * p.lda + kc);
+      rb[i] = *reinterpret_cast<const float4 *>(p.B + (int64_t)(brow < p.N ? brow : 0) * p.ldb + kc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  gload(kbeg);
+  for (int64_t k0 = kbeg; k0 < kend; k0 += TSK_KC) {
+    __syncthreads();  // every wave is done with the previous step's fragments
+#pragma unroll
+    for (int i = 0; i < TSK_NL; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / (TSK_KC / 4), c = (idx - row * (TSK_KC / 4)) * 4;
+      const bool kok = k0 + c < kend;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(sA + row * TSK_LD + c) = (kok && row < p.M) ? ra[i] : z;
+      *reinterpret_cast<float4 *>(sB + row * TSK_LD + c) = (kok && 64 * jb + row < p.N) ? rb[i] : z;
+    }
+    __syncthreads();
+    if (k0 + TSK_KC < kend) gload(k0 + TSK_KC);  // in flight during the MFMAs
+    const float *pa = sA + (32 * wm + r) * TSK_LD + 4 * h, *pb = sB + (32 * wn + r) * TSK_LD + 4 * h;
+#pragma unroll
+    for (int j = 0; j < TSK_KC / 8; ++j) {
+      const float4 a4 = *reinterpret_cast<const float4 *>(pa + 8 * j), b4 = *reinterpret_cast<const float4 *>(pb + 8 * j);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+  }
+  const bool direct = p.nsplit == 1;
+  float *out = direct ? p.C : p.slab + (int64_t)ks * p.M * p.N;
+  const int64_t ldo = direct ? p.ldc : p.N;
+  const int j = 64 * jb + 32 * wn + r;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int i = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * h;
+    if (i < p.M && j < p.N) {
+      float v = acc[e];
+      if (direct) {
+        v *= p.alpha;
+        if (p.beta != 0.f) v += p.beta * out[(int64_t)i * ldo + j];
+      }
+      out[(int64_t)i * ldo + j] = v;
+    }
+  }
+}
+
+// C = alpha * sum_z slab[z] + beta * C: 32 consecutive output elements x 8 interleaved split subsets per workgroup
+// (coalesced 128-byte reads, 8 x fewer dependent loads per thread than one thread per element), fixed summation order.
+__global__ __launch_bounds__(256) void gemm_tsk_reduce_kernel(const float *__restrict__ slab, float *__restrict__ C, int64_t MN,
+                                                              int N, int64_t ldc, int nsplit, float alpha, float beta) {
+  __shared__ float part[8][32];
+  const int tid = threadIdx.x, e = tid & 31, sub = tid >> 5;
+  const int64_t idx = (int64_t)blockIdx.x * 32 + e;
+  float s0 = 0.f, s1 = 0.f;
+  if (idx < MN) {
+    int z = sub;
+    for (; z + 8 < nsplit; z += 16) {
+      s0 += slab[(int64_t)z * MN + idx];
+      s1 += slab[(int64_t)(z + 8) * MN + idx];
+    }
+    if (z < nsplit) s0 += slab[(int64_t)z * MN + idx];
+  }
+  part[sub][e] = s0 + s1;
+  __syncthreads();
+  if (sub == 0 && idx < MN) {
+    const float s = ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) + ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e]));
+    const int64_t i = idx / N, j = idx - i * N;
+    float v = alpha * s;
+    if (beta != 0.f) v += beta * C[i * ldc + j];
+    C[i * ldc + j] = v;
+  }
+}
+
+static bool tsk_shape(int64_t M, int64_t N, int64_t K) { return M <= 64 && N <= 1024 && K >= 2048 && (K & 3) == 0; }
+
+static void tsk_plan(int64_t N, int64_t K, int &nsplit, int64_t &kchunk) {
+  const int64_t nblk = cdiv(N, 64);
+  static int total = -1;
+  if (total < 0) { const char *e = getenv("VIVIT_TSK_WGS"); total = e ? atoi(e) : 512; }
+  int64_t want = total / nblk, maxs = K / (2 * TSK_KC);   // two workgroups per CU; at least two steps per split
+  if (want < 1) want = 1;
+  int64_t s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  kchunk = cdiv(cdiv(K, s), TSK_KC) * TSK_KC;
+  nsplit = (int)cdiv(K, kchunk);
+}
+
+static size_t tsk_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (!tsk_shape(M, N, K)) return 0;
+  int ns;
+  int64_t kc;
+  tsk_plan(N, K, ns, kc);
+  return ns > 1 ? (size_t)ns * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+static bool use_tsk(int alay, int blay, const float *A, const float *B, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                    bool syrk) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char *e = getenv("VIVIT_GEMM_TSK");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced == 0 || syrk || alay != LAY_K || blay != LAY_K || !tsk_shape(M, N, K)) return false;
+  return (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (lda & 3) == 0 && (ldb & 3) == 0;
+}
+
+static int tsk_launch(const float *A, const float *B, float *C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                      float alpha, float beta, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  TskArgs p;
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.K = K; p.M = (int)M; p.N = (int)N;
+  p.alpha = alpha; p.beta = beta;
+  tsk_plan(N, K, p.nsplit, p.kchunk);
+  p.slab = nullptr;
+  if (p.nsplit > 1) {
+    if (!workspace || workspace_bytes < (size_t)p.nsplit * (size_t)M * (size_t)N * sizeof(float)) return VIVIT_E_WORKSPACE;
+    p.slab = static_cast<float *>(workspace);
+  }
+  gemm_tsk_kernel<<<dim3((unsigned)p.nsplit, (unsigned)cdiv(N, 64)), 256, 0, stream>>>(p);
+  int st = launch_status();
+  if (st != VIVIT_OK || p.nsplit == 1) return st;
+  gemm_tsk_reduce_kernel<<<(unsigned)cdiv(M * N, 32), 256, 0, stream>>>(p.slab, C, M * N, (int)N, ldc, p.nsplit, alpha, beta);
+  return launch_status();
+}
+
 // wave grid of the tile: 1 x 4 waves (64 x 256) when the output has at most 64 rows and is wide
 static int pick_wm(int64_t M, int64_t N, bool syrk) { return (!syrk && M <= 64 && N > 128) ? 1 : 2; }
 
@@ -1357,6 +1522,10 @@ size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
         if (bb > b) b = bb;
       }
     }
+  }
+  if (!syrk) {  // the deep-K small-output kernel may be chosen instead (tsk_launch)
+    const size_t bt = tsk_workspace_bytes(M, N, K);
+    if (bt > b) b = bt;
   }
   if (!syrk && M <= 64 && N >= 2048 && K >= 2048) {  // the streaming kernel may be chosen instead (gemm64_launch)
     const size_t b64 = gemm64_workspace_bytes(M, N, K / BK * BK, nullptr, nullptr);
@@ -1673,6 +1842,8 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
     }
   }
   if (!syrk && use_gemm64(alay, blay, A, B, M, N, K, lda, ldb)) return gemm64_launch(alay, blay, p, workspace, workspace_bytes, stream);
+  if (use_tsk(alay, blay, A, B, M, N, K, lda, ldb, syrk))
+    return tsk_launch(A, B, C, M, N, K, lda, ldb, ldc, alpha, beta, workspace, workspace_bytes, stream);
   choose_split(M, N, K, syrk, p.ksplit, p.kchunk);
   p.slab = nullptr;
   if (p.ksplit > 1) {

@@ -23,6 +23,7 @@ __device__ __forceinline__ float rcp_nr(float x) {
   return fmaf(r, fmaf(-x, r, 1.f), r);
 }
 __device__ __forceinline__ float sqrt_nr(float x) {
+  if (x < 1e-30f) return sqrtf(x);  // (v_sqrt_f32 does not take denormals; the library call rescales)
   const float y = __builtin_amdgcn_sqrtf(x);
   return y > 0.f ? fmaf(fmaf(-y, y, x), 0.5f * __builtin_amdgcn_rcpf(y), y) : y;
 }

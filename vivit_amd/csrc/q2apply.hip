@@ -141,15 +141,44 @@ __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const fl
   const bool haveB = g0 + 1 + (2 * K + 1) * QB < a.n;  // level 2K+1 exists for this group
   const int nslab = (nrows + Q2_SLAB - 1) / Q2_SLAB;
 
-  for (int idx = tid; idx < 2 * QW * QWIN; idx += Q2_THREADS) {
-    const int b = idx / (QW * QWIN), rem = idx - b * (QW * QWIN);
-    const int t = rem / QWIN, w = rem - t * QWIN;
-    sV[(b * QW + t) * LDS_V + w] = (w >= 1) ? q2_v(a, g0, g0 + 1 + (2 * K + b) * QB, t, w - 1) : 0.f;
-  }
-  const float *TV = Tbuf + (int64_t)blockIdx.y * 2 * QW * QWIN;  // [2][64][128], window index i = w - 1
-  for (int idx = tid; idx < 2 * QW * QWIN; idx += Q2_THREADS) {
-    const int bt = idx / QWIN, w = idx - bt * QWIN;  // bt = 64 b + t'
-    sTV[bt * LDS_V + w] = (w >= 1) ? TV[bt * QWIN + w - 1] : 0.f;
+  {
+    // V and T V of both blocks into LDS: 32 + 32 loads per thread, ALL in flight before the first LDS write (clamped
+    // addresses, masked afterwards).  As two plain loops (load, wait, ds_write per element: 64 serialised L2 round
+    // trips, ~50 us per workgroup against ~60 us of MFMA work on its slabs) this prologue was most of the gap
+    // between the kernel and its MFMA bound.
+    constexpr int NV = 2 * QW * QWIN / Q2_THREADS;  // 32
+    const float *TV = Tbuf + (int64_t)blockIdx.y * 2 * QW * QWIN;  // [2][64][128], window index i = w - 1
+    float vv[NV], tv[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + Q2_THREADS * u;
+      const int b = idx / (QW * QWIN), rem = idx - b * (QW * QWIN);
+      const int t = rem / QWIN, w = rem - t * QWIN;
+      // q2_v(a, g0, c_start, t, w - 1) with the address clamped instead of the load skipped
+      const int c_start = g0 + 1 + (2 * K + b) * QB;
+      const int sw = g0 + t, c0 = c_start + t;
+      const bool live = sw <= a.n - 3 && c0 < a.n;
+      const int L = (a.n - c0) < QB ? (a.n - c0) : QB;
+      const int i = w - 1;
+      const bool in = live && i >= t && i < t + L;
+      vv[u] = a.R2[in ? (int64_t)sw * a.ldr + c_start + i : 0];
+      tv[u] = TV[(idx - rem) + t * QWIN + (w >= 1 ? w - 1 : 0)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + Q2_THREADS * u;
+      const int b = idx / (QW * QWIN), rem = idx - b * (QW * QWIN);
+      const int t = rem / QWIN, w = rem - t * QWIN;
+      const int c_start = g0 + 1 + (2 * K + b) * QB;
+      const int sw = g0 + t, c0 = c_start + t;
+      const bool live = sw <= a.n - 3 && c0 < a.n;
+      const int L = (a.n - c0) < QB ? (a.n - c0) : QB;
+      const int i = w - 1;
+      const bool in = live && i >= t && i < t + L;
+      sV[(b * QW + t) * LDS_V + w] = in ? vv[u] : 0.f;
+      sTV[(b * QW + t) * LDS_V + w] = (w >= 1) ? tv[u] : 0.f;
+    }
   }
   __syncthreads();
 

@@ -76,9 +76,10 @@ static int bt_nsub_rows(int64_t n, int64_t nrows) {
 static size_t bt_gemm_ws_bytes(int64_t n) {
   const int64_t KS = (int64_t)KB * bt_nsub(n);
   size_t b = gemm_workspace_bytes(n, KS, n, false);
-  const size_t b2 = gemm_workspace_bytes(KS, KS, n, false);
+  const size_t b2 = gemm_workspace_bytes(KS, KS, n, false), b3 = gemm_workspace_bytes(KS, KS, n, true);
   const size_t bound = (size_t)2048 * 128 * KS * sizeof(float);
   if (b2 > b) b = b2;
+  if (b3 > b) b = b3;
   return b > bound ? b : bound;
 }
 
@@ -123,7 +124,7 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
   for (int64_t a = (jmax / KS) * KS; a >= 0; a -= KS) {
     // reflector rows of the super-block (zero rows for indices beyond jmax), their Gram matrix, block T factors
     bt_extract_kernel<<<dim3((unsigned)cdiv(n, 256), (unsigned)KS), 256, 0, stream>>>(A, lda, ni, (int)a, Yt, shift, (int)jmax);
-    st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KS, KS, n, n, n, KS, 1.f, 0.f, false, gws, gws_bytes, stream);
+    st = gemm_launch(LAY_K, LAY_K, Yt, Yt, S, KS, KS, n, n, n, KS, 1.f, 0.f, true, gws, gws_bytes, stream);  // SYRK: lower tiles + mirror
     if (st != VIVIT_OK) return st;
     if (nsub > 1 && hipMemsetAsync(T, 0, sizeof(float) * KS * KS, stream) != hipSuccess) return VIVIT_E_LAUNCH;
     // block T factors of the nsub diagonal blocks: one workgroup each, one launch

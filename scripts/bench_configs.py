@@ -22,13 +22,23 @@ def timed(fn, reps=2):
     return (time.perf_counter() - t0) / reps, out
 
 
+def gram(V):
+    """Gram matrix of one factor, or of a list of per-parameter factors accumulated in-kernel (beta = 1) like the hooks do."""
+    if not isinstance(V, (list, tuple)):
+        return kernels.gram_syrk(V)
+    G = kernels.gram_syrk(V[0])
+    for Vp in V[1:]:
+        kernels.gram_syrk(Vp, out=G, beta=1.0)
+    return G
+
+
 def gram_side(V):
-    G = kernels.gram_syrk(V)
+    G = gram(V)
     return kernels.symeig(G, eigenvectors=True, overwrite=True)
 
 
 def gram_side_top10(V):
-    G = kernels.gram_syrk(V)
+    G = gram(V)
     plan = kernels.symeig_reduce(G, overwrite=True)
     n = plan.n
     return plan.evals, plan.select(list(range(n - 10, n)))
@@ -41,7 +51,8 @@ def param_side(V):
 
 which = sys.argv[1:] or ["cfg1", "cfg3", "cfg4", "cfg5"]
 if "cfg1" in which:
-    V = torch.randn(1280, 407050, device=dev) / 128**0.5
+    # the four parameters of the MLP (weight 512 x 784, bias 512, weight 10 x 512, bias 10), one factor each as in the API
+    V = [torch.randn(1280, p, device=dev) / 128**0.5 for p in (401408, 512, 5120, 10)]
     t, _ = timed(lambda: gram_side(V))
     t10, _ = timed(lambda: gram_side_top10(V))
     print(f"cfg1 n=1280 P=407050: Gram+symeig(vectors) {t*1e3:.1f} ms -> {1280/t:.0f} eigenpairs/s; top-10: {t10*1e3:.1f} ms")

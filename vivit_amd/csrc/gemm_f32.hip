@@ -876,6 +876,10 @@ struct GemmBxArgs {
   int64_t M, N, K, ldc;          // K = contraction length of THIS launch (multiple of 16)
   float alpha, beta;
   int tiles_m, tiles_n, syrk, sbw;
+  // split-K over blockIdx.y for small outputs with a deep contraction (kt_split > 0): split z takes k tiles
+  // [z kt_split, (z + 1) kt_split) and writes its partial tile (alpha = 1, beta = 0) to slab[z][M][N]
+  float *slab;
+  int kt_split;
 };
 
 template <int NPROD>
@@ -889,7 +893,12 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)ti * B2, col0 = (int64_t)tj * B2;
-  const int nt = (int)(p.K / BK);
+  int nt = (int)(p.K / BK);
+  int64_t kt0 = 0;
+  if (p.kt_split > 0) {
+    kt0 = (int64_t)blockIdx.y * p.kt_split;
+    nt = nt - (int)kt0 < p.kt_split ? nt - (int)kt0 : p.kt_split;
+  }
 
   f32x16 acc[4][4];
 #pragma unroll
@@ -899,9 +908,9 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  gptr Cout = (gptr)p.C;
-  const int64_t ldc = p.ldc;
-  const float alpha_ = p.alpha, beta_ = p.beta;
+  gptr Cout = p.kt_split > 0 ? (gptr)p.slab + (int64_t)blockIdx.y * p.M * p.N : (gptr)p.C;
+  const int64_t ldc = p.kt_split > 0 ? p.N : p.ldc;
+  const float alpha_ = p.kt_split > 0 ? 1.f : p.alpha, beta_ = p.kt_split > 0 ? 0.f : p.beta;
   const bool full_tile = row0 + B2 <= p.M && col0 + B2 <= p.N;
   // C <- C' + alpha * acc with C' = beta * C on the first flush and C afterwards; acc <- final value
   auto flush_to_c = [&](bool first) __attribute__((always_inline)) {
@@ -973,8 +982,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     int64_t ba = row0 / 32 + blk, bb = col0 / 32 + blk;   // 32-row block of the operand (clamped: never stored rows)
     ba = ba < p.nrbA ? ba : p.nrbA - 1;
     bb = bb < p.nrbB ? bb : p.nrbB - 1;
-    srcA[u] = (gcptr16)p.A + ba * 512 + 8 * lane;          // 1 KB block = 512 bf16; lane -> its 16 bytes
-    srcB[u] = (gcptr16)p.B + bb * 512 + 8 * lane;
+    srcA[u] = (gcptr16)p.A + (kt0 * p.nrbA + ba) * 512 + 8 * lane;          // 1 KB block = 512 bf16; lane -> its 16 bytes
+    srcB[u] = (gcptr16)p.B + (kt0 * p.nrbB + bb) * 512 + 8 * lane;
   }
   const int64_t stepA = p.nrbA * 512, stepB = p.nrbB * 512;  // one k tile further
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx +
@@ -1503,6 +1512,8 @@ static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit
 
 static int gemm_split_mode();
 static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same);
+static bool bx_splitk_shape(int64_t M, int64_t N, int64_t K, bool syrk, bool same, int *nsplit_out, int *kt_split_out,
+                            size_t *bytes_out);
 size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   int ksplit;
@@ -1522,6 +1533,11 @@ size_t gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, bool syrk) {
         if (bb > b) b = bb;
       }
     }
+  }
+  {  // bf16-pipe split-K for small outputs with a deep contraction (bx_splitk_launch)
+    size_t bs = 0;
+    if (bx_splitk_shape(M, N, K / BK * BK, syrk, syrk, nullptr, nullptr, &bs) && bs > b) b = bs;
+    if (!syrk && bx_splitk_shape(M, N, K / BK * BK, false, false, nullptr, nullptr, &bs) && bs > b) b = bs;
   }
   if (!syrk) {  // the deep-K small-output kernel may be chosen instead (tsk_launch)
     const size_t bt = tsk_workspace_bytes(M, N, K);
@@ -1616,25 +1632,30 @@ static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same) {
   return (size_t)6 * (size_t)kc * (size_t)(same ? ra : ra + rb) + 256;
 }
 
-static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+static bool gemm256_attrs() {
   static unsigned long long attr_done = 0;
   {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
     if (!(attr_done & (1ull << (dev & 63)))) {
       const void *fns[4] = {reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_K>),
                             reinterpret_cast<const void *>(gemm256_kernel<LAY_K, LAY_M>),
                             reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_K>),
                             reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_M>)};
       for (const void *f : fns)
-        if (!ensure_dynamic_lds(f, GEMM256_LDS_BYTES, attr_done)) return VIVIT_E_LAUNCH;
+        if (!ensure_dynamic_lds(f, GEMM256_LDS_BYTES, attr_done)) return false;
       const void *bx[3] = {reinterpret_cast<const void *>(gemm256_bx_kernel<3>), reinterpret_cast<const void *>(gemm256_bx_kernel<6>),
                            reinterpret_cast<const void *>(gemm256_bx_kernel<9>)};
       for (const void *f : bx)
-        if (!ensure_dynamic_lds(f, GEMM256BX_LDS_BYTES, attr_done)) return VIVIT_E_LAUNCH;
+        if (!ensure_dynamic_lds(f, GEMM256BX_LDS_BYTES, attr_done)) return false;
       attr_done |= 1ull << (dev & 63);
     }
   }
+  return true;
+}
+
+static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!gemm256_attrs()) return VIVIT_E_LAUNCH;
   // never more splits than the caller's workspace holds (callers size it for their largest problem; the plan
   // of a smaller one may differ)
   const size_t slab1 = (size_t)p.M * (size_t)p.N * sizeof(float);
@@ -1681,6 +1702,7 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
     q.nrbA = nrbA; q.nrbB = same ? nrbA : nrbB;
     q.C = p.C; q.M = p.M; q.N = p.N; q.ldc = p.ldc; q.alpha = p.alpha;
     q.tiles_m = p.tiles_m; q.tiles_n = p.tiles_n; q.syrk = p.syrk; q.sbw = p.sbw;
+    q.slab = nullptr; q.kt_split = 0;
     int st = VIVIT_OK;
     for (int64_t k0 = 0; k0 < p.K && st == VIVIT_OK; k0 += kc_max) {
       const int64_t kc = (p.K - k0) < kc_max ? (p.K - k0) : kc_max;
@@ -1726,6 +1748,86 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
   if (st == VIVIT_OK && p.ksplit > 1) {
     gemm_reduce_kernel<<<(unsigned)cdiv(p.M * p.N, 256), 256, 0, stream>>>(p.slab, p.C, p.M, p.N, p.ldc, p.ksplit, p.alpha,
                                                                            p.beta, p.syrk, B2);
+    st = launch_status();
+  }
+  if (prof) prof_end(0, stream);
+  return st;
+}
+
+// ---- bf16-pipe split-K for SMALL outputs with a deep contraction (Gram matrices of small batches: n = 1280,
+// P = 4e5 has 15 lower 256-tiles).  The whole operand is split into its three bf16 pieces once (blocked layout: a k
+// tile of a 256-row block is 8 KB contiguous per piece, so a K split streams long runs, unlike the 1280 row streams
+// 1.6 MB apart of the fp32 operand), one launch with the k tiles divided over blockIdx.y writes partial tiles to a slab,
+// and the fixed-order reduce mirrors the lower tiles of a SYRK.
+static bool bx_splitk_shape(int64_t M, int64_t N, int64_t K, bool syrk, bool same, int *nsplit_out, int *kt_split_out,
+                            size_t *bytes_out) {
+  static int forced = -2;
+  if (forced == -2) { const char *e = getenv("VIVIT_GEMM_BXSPLITK"); forced = e ? atoi(e) : -1; }
+  if (forced == 0 || gemm_split_mode() != 6) return false;
+  if (K < 16384 || (K % BK) != 0 || M < 256 || N < 256) return false;
+  const int64_t tm = cdiv(M, B2), tn = cdiv(N, B2);
+  const int64_t tiles = syrk ? tm * (tm + 1) / 2 : tm * tn;
+  if (tiles > 100) return false;                       // enough tiles: the plain bf16-pipe launch fills the chip
+  const int64_t ra = cdiv(M, 32) * 32, rb = cdiv(N, 32) * 32;
+  const size_t pieces = (size_t)6 * (size_t)K * (size_t)(same ? ra : ra + rb);
+  if (pieces > ((size_t)8 << 30)) return false;        // whole-K pieces: bounded scratch
+  const int64_t nt = K / BK;
+  int64_t s = 512 / tiles;                             // ~2 rounds of one workgroup per CU
+  if (s > nt / 64) s = nt / 64;                        // at least 64 k tiles per split
+  if (s < 2) return false;
+  const int64_t kts = cdiv(nt, s);
+  s = cdiv(nt, kts);
+  if (nsplit_out) *nsplit_out = (int)s;
+  if (kt_split_out) *kt_split_out = (int)kts;
+  if (bytes_out) *bytes_out = pieces + 256 + (size_t)s * (size_t)M * (size_t)N * sizeof(float) + 256;
+  return true;
+}
+
+static int bx_splitk_launch(int alay, int blay, const GemmArgs &p, bool syrk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!gemm256_attrs()) return VIVIT_E_LAUNCH;
+  const bool same = p.A == p.B && p.lda == p.ldb && p.M == p.N && alay == blay;
+  int nsplit, kts;
+  size_t need;
+  if (!bx_splitk_shape(p.M, p.N, p.K, syrk, same, &nsplit, &kts, &need)) return VIVIT_E_UNSUPPORTED;
+  if (!workspace || workspace_bytes < need) return VIVIT_E_WORKSPACE;
+  const int64_t nrbA = cdiv(p.M, 32), nrbB = cdiv(p.N, 32);
+  const int64_t strideA = nrbA * 32 * p.K, strideB = nrbB * 32 * p.K;
+  unsigned short *PA = static_cast<unsigned short *>(workspace);
+  unsigned short *PB = same ? PA : PA + 3 * strideA;
+  const size_t pieces = (size_t)6 * (size_t)p.K * (size_t)(same ? nrbA * 32 : (nrbA + nrbB) * 32);
+  float *slab = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(workspace) + pieces, 256));
+  const bool prof = syrk && same && prof_enabled();
+  if (prof) prof_begin(0, (double)p.M * (double)(p.M + 1) * (double)p.K, stream);
+  const unsigned gy = (unsigned)cdiv(p.K / 16, 4);
+  if (alay == LAY_K)
+    bx_split_kernel<LAY_K><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, 0, p.K, PA, strideA, nrbA);
+  else
+    bx_split_kernel<LAY_M><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, 0, p.K, PA, strideA, nrbA);
+  if (!same) {
+    if (blay == LAY_K)
+      bx_split_kernel<LAY_K><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, 0, p.K, PB, strideB, nrbB);
+    else
+      bx_split_kernel<LAY_M><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, 0, p.K, PB, strideB, nrbB);
+  }
+  GemmBxArgs q;
+  q.A = PA; q.B = PB; q.strideA = strideA; q.strideB = same ? strideA : strideB;
+  q.nrbA = nrbA; q.nrbB = same ? nrbA : nrbB;
+  q.C = p.C; q.M = p.M; q.N = p.N; q.K = p.K; q.ldc = p.ldc; q.alpha = 1.f; q.beta = 0.f;
+  q.tiles_m = (int)cdiv(p.M, B2); q.tiles_n = (int)cdiv(p.N, B2);
+  q.syrk = syrk ? 2 : 0;   // lower tiles only; the reduce mirrors
+  const int sbw = syrk ? 16 : sb_width(q.tiles_m, q.tiles_n), sbh = 256 / sbw;
+  q.sbw = sbw;
+  q.slab = slab; q.kt_split = kts;
+  const int64_t sbm = cdiv(q.tiles_m, sbh), sbn = cdiv(q.tiles_n, sbw);
+  const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
+  gemm256_bx_kernel<6><<<dim3((unsigned)(nsb * 256), (unsigned)nsplit), 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+  int st = launch_status();
+  if (st != VIVIT_OK) return st;
+  gemm_reduce_kernel<<<(unsigned)cdiv(p.M * p.N, 256), 256, 0, stream>>>(slab, p.C, p.M, p.N, p.ldc, nsplit, p.alpha, p.beta,
+                                                                       syrk ? 1 : 0, B2);
+  st = launch_status();
+  if (st == VIVIT_OK && syrk) {
+    bx_sym_diag_kernel<<<(unsigned)q.tiles_m, 256, 0, stream>>>(p.C, p.M, p.ldc);
     st = launch_status();
   }
   if (prof) prof_end(0, stream);
@@ -1837,6 +1939,20 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
       int st = gemm256_launch(alay, blay, p, syrk, workspace, workspace_bytes, stream);
       if (st != VIVIT_OK || Kmain == K) return st;
       // ragged K tail (< 16) through the small-tile kernel, accumulating
+      const float *At = A + (alay == LAY_K ? Kmain : Kmain * lda), *Bt = B + (blay == LAY_K ? Kmain : Kmain * ldb);
+      return gemm_launch(alay, blay, At, Bt, C, M, N, K - Kmain, lda, ldb, ldc, alpha, 1.f, syrk, workspace, workspace_bytes, stream);
+    }
+  }
+  {
+    const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 &&
+                     (ldb & 3) == 0 && (alay == LAY_K || (M & 3) == 0) && (blay == LAY_K || (N & 3) == 0);
+    const int64_t Kmain = K / BK * BK;
+    const bool same = A == B && lda == ldb && M == N && alay == blay;
+    size_t need = 0;
+    if (vec && bx_splitk_shape(M, N, Kmain, syrk, same, nullptr, nullptr, &need) && workspace && workspace_bytes >= need) {
+      p.K = Kmain;
+      int st = bx_splitk_launch(alay, blay, p, syrk, workspace, workspace_bytes, stream);
+      if (st != VIVIT_OK || Kmain == K) return st;
       const float *At = A + (alay == LAY_K ? Kmain : Kmain * lda), *Bt = B + (blay == LAY_K ? Kmain : Kmain * ldb);
       return gemm_launch(alay, blay, At, Bt, C, M, N, K - Kmain, lda, ldb, ldc, alpha, 1.f, syrk, workspace, workspace_bytes, stream);
     }

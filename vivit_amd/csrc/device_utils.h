@@ -34,6 +34,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sum over the 64 lanes, identical in every lane: four DPP adds inside each row of 16 lanes (xor 1, xor 2, mirror in 8,
+// mirror in 16) and one readlane per row - about a tenth of the latency of the ds_bpermute butterfly.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  auto lane_of = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
+  return (lane_of(v, 0) + lane_of(v, 16)) + (lane_of(v, 32) + lane_of(v, 48));
+}
+
 // Sum over the 256 threads, fixed order; red needs 4 floats. Every thread must call.
 __device__ __forceinline__ float block_sum(float v, float *red, int tid) {
   v = wave_sum(v);

@@ -38,16 +38,6 @@ __device__ __forceinline__ float rlu(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// Sum over the 64 lanes, identical in every lane: four DPP adds inside each row of 16 lanes (xor 1, xor 2, mirror in 8,
-// mirror in 16) and one readlane per row - about a tenth of the latency of the ds_bpermute butterfly.
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
-  return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48));
-}
-
 // One task per 256-thread workgroup.  The four waves load the two 64 x 64 blocks from the band (one
 // coalesced 256-byte segment per band row: row r of the band holds [E row r | lower D row r]
 // contiguously; all 32 loads of a thread are in flight together) into LDS.  Thread (wave q, lane r) then

@@ -133,14 +133,14 @@ struct Refl {
 __device__ __forceinline__ Refl wave_reflector(const SytrdWs &ws, int npart, int lane) {
   float s = 0.f;
   for (int t = lane; t < npart; t += 64) s += ws.ssqpart[t];
-  const float ssq = wave_sum(s);
   const float alpha = ws.scal[0];
+  const float ssq = wave_sum_dpp(s);
   Refl r;
   r.beta = alpha; r.tau = 0.f; r.sc = 0.f;
   if (ssq > 0.f) {
-    r.beta = -copysignf(sqrtf(alpha * alpha + ssq), alpha);
-    r.tau = (r.beta - alpha) / r.beta;
-    r.sc = 1.f / (alpha - r.beta);
+    r.beta = -copysignf(sqrt_nr(alpha * alpha + ssq), alpha);
+    r.tau = (r.beta - alpha) * rcp_nr(r.beta);
+    r.sc = rcp_nr(alpha - r.beta);
   }
   return r;
 }
@@ -211,10 +211,28 @@ __device__ __forceinline__ int rho_of(int lane) {
 
 // One TRR x 256 tile: returns the lane's 4 column sums, leaves the TRR row sums in `rowsum`.
 // FAST = strictly-lower in-bounds tile: unconditional 16-byte loads, no masks.
+template <bool VEC, bool FAST>
+__device__ __forceinline__ void symv_load_group(const float *__restrict__ A, int64_t lda, int64_t N, int64_t R0, int64_t c, int g,
+                                                float4 (&dst)[8]) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int64_t i = R0 + g * 8 + u;
+    if constexpr (FAST) {
+      dst[u] = *reinterpret_cast<const float4 *>(A + i * lda + c);
+    } else {
+      const bool rowok = i < N;
+      const float4 a = ld4_guard<VEC>(A + (rowok ? i : 0) * lda, c, N);
+      dst[u] = rowok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+// `bufa` arrives with row group 0 already requested (symv_load_group<..>(.., 0, bufa) by the caller, in front of the
+// reflector scalars: one memory round trip less on the launch's critical path).
 template <bool VEC, int TRR, bool FAST>
 __device__ __forceinline__ float4 symv_tile(const float *__restrict__ A, int64_t lda, int64_t N, int64_t R0, int64_t c,
                                             float4 vc, const float (&vr)[(TRR + 63) / 64], int lane,
-                                            float *__restrict__ rowsum) {
+                                            float *__restrict__ rowsum, float4 (&bufa)[8]) {
   float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_group = [&](int g, float4(&dst)[8]) {
 #pragma unroll
@@ -259,8 +277,7 @@ __device__ __forceinline__ float4 symv_tile(const float *__restrict__ A, int64_t
     if ((lane & 7) == 0) rowsum[g * 8 + rho_of(lane)] = tot;
   };
   constexpr int NG = TRR / 8;
-  float4 bufa[8], bufb[8];
-  load_group(0, bufa);
+  float4 bufb[8];
 #pragma unroll 1
   for (int g = 0; g < NG; g += 2) {
     load_group(g + 1, bufb);
@@ -291,8 +308,31 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(float *__restrict__ A, in
   const int64_t N = n;
   const int ntile = nrt * nct;
   const int widx = blockIdx.x * 4 + wave;
-  const Refl rf = wave_reflector(ws, npart, lane);
   const float *__restrict__ xb = ws.xbuf;
+  // tile coordinates, and everything the tile reads that does not depend on the reflector scalars (first row group of
+  // A, the x values behind v) requested BEFORE those scalars are reduced: the launch is latency-bound (4-5 dependent
+  // round trips at 12.9 us per column for n ~ 1000) and this takes one round trip off the chain
+  const bool is_tile = widx < ntile;
+  const int rt = rt0 + (is_tile ? widx / nct : 0), ct = ct0 + (is_tile ? widx % nct : 0);
+  const int64_t R0 = (int64_t)rt * TRR, C0 = (int64_t)ct * TC;
+  const bool active = is_tile && !(C0 > R0 + TRR - 1);   // (entirely above the diagonal: no partials are ever read from it)
+  const int64_t c = C0 + 4 * lane;
+  const bool interior = VEC && (C0 + TC - 1 < R0) && (R0 + TRR - 1 < N);  // strictly below the diagonal, in bounds
+  float4 bufa[8];
+  float4 xc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float xr[(TRR + 63) / 64];
+  if (active) {
+    if (interior) symv_load_group<VEC, true>(A, lda, N, R0, c, 0, bufa);
+    else symv_load_group<VEC, false>(A, lda, N, R0, c, 0, bufa);
+    xc4 = ld4_guard<VEC>(xb, c, N);
+#pragma unroll
+    for (int k = 0; k < (TRR + 63) / 64; ++k) {
+      const int64_t i = R0 + 64 * k + lane;
+      xr[k] = xb[(i < N && 64 * k + lane < TRR) ? i : 0];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const Refl rf = wave_reflector(ws, npart, lane);
 
   if (widx >= ntile) {
     // ---- auxiliary wave: materialise v for its chunks, then the panel dots V^T v, W^T v
@@ -344,25 +384,21 @@ __global__ __launch_bounds__(256) void trd_symv_kernel(float *__restrict__ A, in
   }
 
   // ---- symv tile
-  const int rt = rt0 + widx / nct, ct = ct0 + widx % nct;
-  const int64_t R0 = (int64_t)rt * TRR, C0 = (int64_t)ct * TC;
-  if (C0 > R0 + TRR - 1) return;  // entirely above the diagonal: no partials are ever read from it
-  const int64_t c = C0 + 4 * lane;
-  const float4 vc = v4_of<VEC>(xb, c, N, j, rf.sc);   // v[c..c+3]  (zero up to j and beyond n)
+  if (!active) return;
+  const float4 vc = make_float4(v_of(xc4.x, c, j, rf.sc), v_of(xc4.y, c + 1, j, rf.sc), v_of(xc4.z, c + 2, j, rf.sc),
+                                v_of(xc4.w, c + 3, j, rf.sc));   // v[c..c+3]  (zero up to j and beyond n)
   float vr[(TRR + 63) / 64];                          // v[R0 + 64*k + lane]
 #pragma unroll
   for (int k = 0; k < (TRR + 63) / 64; ++k) {
     const int64_t i = R0 + 64 * k + lane;
     const bool ok = i < N && 64 * k + lane < TRR;
-    const float xv = xb[ok ? i : 0];
-    vr[k] = ok ? v_of(xv, i, j, rf.sc) : 0.f;
+    vr[k] = ok ? v_of(xr[k], i, j, rf.sc) : 0.f;
   }
-  const bool interior = VEC && (C0 + TC - 1 < R0) && (R0 + TRR - 1 < N);  // strictly below the diagonal, in bounds
   float4 colacc;
   if (interior)
-    colacc = symv_tile<VEC, TRR, true>(A, lda, N, R0, c, vc, vr, lane, rowsum[wave]);
+    colacc = symv_tile<VEC, TRR, true>(A, lda, N, R0, c, vc, vr, lane, rowsum[wave], bufa);
   else
-    colacc = symv_tile<VEC, TRR, false>(A, lda, N, R0, c, vc, vr, lane, rowsum[wave]);
+    colacc = symv_tile<VEC, TRR, false>(A, lda, N, R0, c, vc, vr, lane, rowsum[wave], bufa);
   // column partials: one coalesced 1 KiB store per wave
   float *cp = ws.colpart + (int64_t)(rt - rt0) * N;
   if (VEC) {

@@ -284,3 +284,39 @@ def test_deep_k_small_output_product(m, n, k, pad):
     C0 = torch.randn(m, n, device=dev, generator=g)
     out2 = kernels.gemm_nt(A, B, out=C0.clone(), alpha=-0.5, beta=2.0)
     assert ((out2.double() - (-0.5 * ref + 2.0 * C0.double())).abs() / (scale + 1.0)).max().item() < 2e-6
+
+
+@pytest.mark.parametrize("kind,m,n,k", [("syrk", 1280, 1280, 40000), ("syrk", 300, 300, 100000), ("nt", 1000, 456, 20480),
+                                        ("tn", 2416, 2416, 20480), ("tn", 456, 850, 16400), ("nn", 700, 1300, 32768),
+                                        ("syrk", 1023, 1023, 65552)])
+def test_small_output_deep_contraction_split_k(kind, m, n, k):
+    """Small outputs (< 100 tiles of 256 x 256) with K >= 16384: the bf16-pipe split-K path (whole-operand pieces, k tiles
+    divided over blockIdx.y, slab + fixed-order reduce with SYRK mirror), all operand layouts, ragged M / N / K, alpha / beta."""
+    from vivit_amd import kernels
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(m + 3 * n + k)
+    C0 = torch.randn(m, n, device=dev, generator=g)
+    if kind == "syrk":
+        A = torch.randn(m, k, device=dev, generator=g)
+        C0 = C0 + C0.T
+        C = kernels.gram_syrk(A, out=C0.clone(), alpha=0.5, beta=-1.0)
+        assert torch.equal(C, C.T)
+        ref = 0.5 * (A.double() @ A.double().T) - C0.double()
+        scale = A.double().norm(dim=1)[:, None] * A.double().norm(dim=1)[None, :]
+    elif kind == "nt":
+        A, B = torch.randn(m, k, device=dev, generator=g), torch.randn(n, k, device=dev, generator=g)
+        C = kernels.gemm_nt(A, B, out=C0.clone(), alpha=0.5, beta=-1.0)
+        ref = 0.5 * (A.double() @ B.double().T) - C0.double()
+        scale = A.double().norm(dim=1)[:, None] * B.double().norm(dim=1)[None, :]
+    elif kind == "tn":
+        A, B = torch.randn(k, m, device=dev, generator=g), torch.randn(k, n, device=dev, generator=g)
+        C = kernels.gemm_tn(A, B, out=C0.clone(), alpha=0.5, beta=-1.0)
+        ref = 0.5 * (A.double().T @ B.double()) - C0.double()
+        scale = A.double().norm(dim=0)[:, None] * B.double().norm(dim=0)[None, :]
+    else:
+        A, B = torch.randn(m, k, device=dev, generator=g), torch.randn(k, n, device=dev, generator=g)
+        C = kernels.gemm_nn(A, B, out=C0.clone(), alpha=0.5, beta=-1.0)
+        ref = 0.5 * (A.double() @ B.double()) - C0.double()
+        scale = A.double().norm(dim=1)[:, None] * B.double().norm(dim=0)[None, :]
+    assert ((C.double() - ref).abs() / (scale + 1.0)).max().item() < 5e-6

@@ -11,6 +11,7 @@
 // last group, all blocks with equal tau = G + k are independent (validated in scripts/sb2st_proto.py);
 // two consecutive levels are paired into a super-block, and the host issues one prepare (T V per block)
 // + one apply launch per wavefront step of super-blocks.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -312,6 +313,145 @@ __global__ __launch_bounds__(Q2_THREADS) void q2_apply_kernel(Q2Step a, const fl
   }
 }
 
+// ---- the same super-block step with 16-row waves (v_mfma_f32_16x16x4_f32) ------------------------------------------
+// A 1024-thread workgroup = 16 waves x 16 rows (same 256-row slabs, same LDS images), 4 waves per SIMD instead of 2:
+// lane (n = lane & 15, kq = lane >> 4) keeps S[row n][16 q + 4 kq .. + 3], q = 0..11 (48 registers instead of 96), and
+// every global load instruction covers 64 contiguous bytes per row.  MFMA step (q, i) pairs k slot kq with window column
+// 16 q + 4 kq + i for both operands, so A fragments stay float4 reads and - as with the 32 x 32 x 2 form - the accumulator
+// of W2^T = (T V) S^T (lane (n, g) holds t' = 4 g + e) is the B operand of U^T = V^T W2^T as it stands, whose accumulator
+// (w = 16 wt + 4 g + e) is element e of s[wt].  16 x 16 tiles follow the parallelogram / trapezoid more closely: 184
+// MFMAs of 32 cycles per block and 16 rows = 11.5 % fewer matrix-pipe cycles than 208 x 64 per 32 rows.
+constexpr int Q2W_THREADS = 1024;
+constexpr int Q2W_NQ = 12;  // float4 per lane: 192 window columns
+
+__global__ __launch_bounds__(Q2W_THREADS) void q2_apply16_kernel(Q2Step a, const float *__restrict__ Tbuf,
+                                                                float *__restrict__ Zt, int64_t ldz, int nrows) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *sV = lds;                      // [2][64][LDS_V]   V[t][w]
+  float *sTV = sV + 2 * QW * LDS_V;     // [2][64][LDS_V]   (T V)[t'][w]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n16 = lane & 15, kq = lane >> 4;
+  int g0, K;
+  q2_sblock(a, blockIdx.y, g0, K);
+  const int wstart = g0 + 2 * K * QB;
+  const bool haveB = g0 + 1 + (2 * K + 1) * QB < a.n;  // level 2K+1 exists for this group
+  const int nslab = (nrows + Q2_SLAB - 1) / Q2_SLAB;
+  {
+    constexpr int NV = 2 * QW * QWIN / Q2W_THREADS;  // 16
+    const float *TV = Tbuf + (int64_t)blockIdx.y * 2 * QW * QWIN;  // [2][64][128], window index i = w - 1
+    float vv[NV], tv[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + Q2W_THREADS * u;
+      const int b = idx / (QW * QWIN), rem = idx - b * (QW * QWIN);
+      const int t = rem / QWIN, w = rem - t * QWIN;
+      const int c_start = g0 + 1 + (2 * K + b) * QB;
+      const int sw = g0 + t, c0 = c_start + t;
+      const bool live = sw <= a.n - 3 && c0 < a.n;
+      const int L = (a.n - c0) < QB ? (a.n - c0) : QB;
+      const int i = w - 1;
+      const bool in = live && i >= t && i < t + L;
+      vv[u] = a.R2[in ? (int64_t)sw * a.ldr + c_start + i : 0];
+      tv[u] = TV[(idx - rem) + t * QWIN + (w >= 1 ? w - 1 : 0)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int idx = tid + Q2W_THREADS * u;
+      const int b = idx / (QW * QWIN), rem = idx - b * (QW * QWIN);
+      const int t = rem / QWIN, w = rem - t * QWIN;
+      const int c_start = g0 + 1 + (2 * K + b) * QB;
+      const int sw = g0 + t, c0 = c_start + t;
+      const bool live = sw <= a.n - 3 && c0 < a.n;
+      const int L = (a.n - c0) < QB ? (a.n - c0) : QB;
+      const int i = w - 1;
+      const bool in = live && i >= t && i < t + L;
+      sV[(b * QW + t) * LDS_V + w] = in ? vv[u] : 0.f;
+      sTV[(b * QW + t) * LDS_V + w] = (w >= 1) ? tv[u] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int64_t colg = (int64_t)wstart + 4 * kq;  // + 16 q
+  const bool fast = wstart + 16 * Q2W_NQ <= a.n;   // window completely inside the matrix
+  float4 s[Q2W_NQ];
+  for (int slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
+    __asm__ volatile("" ::: "memory");  // keep the (slab-invariant) V/T fragment reads inside the loop
+    const int64_t row = (int64_t)slab * Q2_SLAB + wave * 16 + n16;
+    const bool rok = row < nrows;
+    float *base = Zt + (rok ? row * ldz : 0);
+    if (fast) {
+      const float4 *b4 = reinterpret_cast<const float4 *>(base + colg);
+#pragma unroll
+      for (int q = 0; q < Q2W_NQ; ++q) s[q] = b4[4 * q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < Q2W_NQ; ++q) {
+        const int64_t c = colg + 16 * q;
+        const bool ok = c < a.n;  // n % 4 == 0 and c % 4 == 0: all four in or out
+        const float4 x = *reinterpret_cast<const float4 *>(ok ? base + c : Zt);
+        s[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+
+    auto apply = [&](auto q0tag, const float *__restrict__ bV, const float *__restrict__ bTV) {
+      constexpr int Q0 = decltype(q0tag)::value;
+      // ---- W2^T = (T V) S^T: t'-tile ta needs the w-tiles q >= ta  ((T V)[t'][w] is non-zero for w >= t' + 1)
+      f32x4 acc2[4];
+      const float *pT = bTV + n16 * LDS_V + 4 * kq;
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc2[ta][e] = 0.f;
+#pragma unroll
+        for (int q = ta; q < 8; ++q) {
+          const float4 av = *reinterpret_cast<const float4 *>(pT + 16 * ta * LDS_V + 16 * q);
+          acc2[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, s[Q0 + q].x, acc2[ta], 0, 0, 0);
+          acc2[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, s[Q0 + q].y, acc2[ta], 0, 0, 0);
+          acc2[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, s[Q0 + q].z, acc2[ta], 0, 0, 0);
+          acc2[ta] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, s[Q0 + q].w, acc2[ta], 0, 0, 0);
+        }
+      }
+      // ---- U^T = V^T W2^T, one w-tile at a time: V[t][w] is non-zero for t + 1 <= w <= t + 64, i.e. t-tiles wt-4 .. wt
+      const float *pU = bV + 4 * kq * LDS_V + n16;
+#pragma unroll
+      for (int wt = 0; wt < 8; ++wt) {
+        f32x4 u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = 0.f;
+        const int lo = wt - 4 > 0 ? wt - 4 : 0, hi = wt < 3 ? wt : 3;
+#pragma unroll
+        for (int ta = lo; ta <= hi; ++ta) {
+          const float *q = pU + 16 * ta * LDS_V + 16 * wt;
+          const float a0 = q[0], a1 = q[LDS_V], a2 = q[2 * LDS_V], a3 = q[3 * LDS_V];
+          u = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, acc2[ta][0], u, 0, 0, 0);
+          u = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, acc2[ta][1], u, 0, 0, 0);
+          u = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, acc2[ta][2], u, 0, 0, 0);
+          u = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, acc2[ta][3], u, 0, 0, 0);
+        }
+        float4 &x = s[Q0 + wt];
+        x.x -= u[0]; x.y -= u[1]; x.z -= u[2]; x.w -= u[3];
+      }
+    };
+    apply(std::integral_constant<int, 0>{}, sV, sTV);
+    if (haveB) apply(std::integral_constant<int, 4>{}, sV + QW * LDS_V, sTV + QW * LDS_V);
+
+    if (rok) {
+      if (fast) {
+        float4 *b4 = reinterpret_cast<float4 *>(base + colg);
+#pragma unroll
+        for (int q = 0; q < Q2W_NQ; ++q) b4[4 * q] = s[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < Q2W_NQ; ++q) {
+          const int64_t c = colg + 16 * q;
+          if (c < a.n) *reinterpret_cast<float4 *>(base + c) = s[q];
+        }
+      }
+    }
+  }
+}
+
 constexpr int Q2_LDS_BYTES = 4 * QW * LDS_V * 4;  // V and T V of both blocks: 135 KB
 
 size_t q2_workspace_bytes(int64_t n) {
@@ -329,7 +469,8 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
     if (!(attr_done & (1ull << (dev & 63)))) {
       if (!ensure_dynamic_lds(reinterpret_cast<const void *>(q2_apply_kernel<true>), Q2_LDS_BYTES, attr_done) ||
-          !ensure_dynamic_lds(reinterpret_cast<const void *>(q2_apply_kernel<false>), Q2_LDS_BYTES, attr_done))
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(q2_apply_kernel<false>), Q2_LDS_BYTES, attr_done) ||
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(q2_apply16_kernel), Q2_LDS_BYTES, attr_done))
         return VIVIT_E_LAUNCH;
       attr_done |= 1ull << (dev & 63);
     }
@@ -386,7 +527,11 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
           if (score > best + 1e-9) { best = score; gx = c; }
         }
       }
-      if (vec)
+      static int wave16 = -1;
+      if (wave16 < 0) { const char *e = getenv("VIVIT_Q2_WAVE16"); wave16 = e ? atoi(e) : 1; }   // (0: the 32-row form)
+      if (vec && wave16)
+        q2_apply16_kernel<<<dim3((unsigned)gx, nblk), Q2W_THREADS, Q2_LDS_BYTES, stream>>>(a, TV, Zt, ldz, (int)nrows);
+      else if (vec)
         q2_apply_kernel<true><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, TV, Zt, ldz, (int)nrows);
       else
         q2_apply_kernel<false><<<dim3((unsigned)gx, nblk), Q2_THREADS, Q2_LDS_BYTES, stream>>>(a, TV, Zt, ldz, (int)nrows);

@@ -5,12 +5,15 @@ import torch
 from vivit_amd import kernels, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40960
 V = torch.randn(n, n // 2, device="cuda")
-G = kernels.gram_syrk(V); del V
+pad = int(os.environ.get("PAD", "0"))
+G = torch.empty(n, n + pad, device="cuda")[:, :n]
+kernels.gram_syrk(V, out=G)
 lib = _lib.load()
-kernels.symeig(G, eigenvectors=True)
+kernels.symeig(G, eigenvectors=True, overwrite=True)   # (in place: a padded leading dimension survives)
+kernels.gram_syrk(V, out=G); del V
 torch.cuda.synchronize()
 lib.vivit_profile_begin(64)
-w, Z = kernels.symeig(G, eigenvectors=True)
+w, Z = kernels.symeig(G, eigenvectors=True, overwrite=True)
 torch.cuda.synchronize()
 ms = (ctypes.c_double * 16)()
 lib.vivit_profile_stages(ms, 16)

@@ -88,9 +88,11 @@ def all_gather_cat(t: torch.Tensor, group=None, out: Optional[torch.Tensor] = No
     return out
 
 
-def all_to_all_flat(send: torch.Tensor, in_splits: Sequence[int], out_splits: Sequence[int], group=None) -> torch.Tensor:
-    """1-D all-to-all with per-peer element counts; returns the received flat buffer (peer order)."""
-    recv = torch.empty(int(sum(out_splits)), dtype=send.dtype, device=send.device)
+def all_to_all_flat(send: torch.Tensor, in_splits: Sequence[int], out_splits: Sequence[int], group=None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """1-D all-to-all with per-peer element counts; returns the received flat buffer (peer order), ``out`` if given
+    (contiguous, ``sum(out_splits)`` elements)."""
+    recv = torch.empty(int(sum(out_splits)), dtype=send.dtype, device=send.device) if out is None else out
     if _staged(send, group):
         h = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(h, send.cpu(), list(out_splits), list(in_splits), group=group)
@@ -165,15 +167,17 @@ def to_parameter_shard(local: torch.Tensor, lead_dims: int, group=None, index: i
     if R == 1:
         return F.reshape(C * Ng, P)
     slices = parameter_slices(P, R, index)
-    send = torch.cat([F[:, :, lo:hi].reshape(-1) for lo, hi in slices])
     w = slices[me][1] - slices[me][0]
-    recv = all_to_all_flat(send, [C * Ng * (hi - lo) for lo, hi in slices], [C * Ng * w] * R, group)
-    del send
-    # [R, C, N_g, w] -> class-major [C, R, N_g, w]  (for C == 1 the received order already is the row order)
-    recv = recv.view(R, C, Ng, w)
-    if C > 1:
-        recv = recv.permute(1, 0, 2, 3).contiguous()
-    return recv.reshape(C * R * Ng, w)
+    # one exchange per class, received straight into the class-major result [C, R, N_g, w]: the peak is the local factor
+    # plus the result plus one class worth of send buffer (a single exchange of the whole factor needed the factor four
+    # times over: send copy, receive buffer [R, C, N_g, w] and its permuted copy)
+    out = torch.empty((C, R, Ng, w), dtype=F.dtype, device=F.device)
+    in_splits = [Ng * (hi - lo) for lo, hi in slices]
+    for c in range(C):
+        send = torch.cat([F[c, :, lo:hi].reshape(-1) for lo, hi in slices])
+        all_to_all_flat(send, in_splits, [Ng * w] * R, group, out=out[c].reshape(-1))
+        del send
+    return out.reshape(C * R * Ng, w)
 
 
 def check_equal_shards(n_local: int, group=None) -> int:

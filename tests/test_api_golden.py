@@ -154,7 +154,7 @@ def test_gram_hooks(case, device):
         attach_sqrt(params, V, G, sf)
         hook = (GramSqrtGGNMC if mc else GramSqrtGGNExact)(layerwise=layerwise, free_sqrt_ggn=True)
         hook(FakeModule(params, int(g["N_total"])))
-        close(hook.get_result(), g["gram_hook"], rtol=1e-5, atol=1e-6)
+        close(hook.get_result(), g["gram_hook"], rtol=1e-5, atol=5e-6)   # (entries up to ~45: summation-order noise of the host BLAS)
         assert all(not hasattr(p, sf) for p in params)
         assert all((getattr(p, hook.savefield) is not None) == layerwise for p in params)
     for cls, key in [(GramBatchGrad, "gram_batch_grad"), (CenteredGramBatchGrad, "gram_batch_grad_centered")]:

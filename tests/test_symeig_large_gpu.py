@@ -100,7 +100,7 @@ def test_stedc(kind, n):
     assert np.abs(T @ Zc - Zc * w.cpu().double().numpy()[None, :]).max() <= 5e-6 * scale
 
 
-@pytest.mark.parametrize("n", [193, 256, 333, 1000, 2048])
+@pytest.mark.parametrize("n", [193, 256, 333, 1000, 2048, 4100])   # 4100: two-stage with vectors by default (n >= 4096)
 @pytest.mark.parametrize("kind", ["dense", "lowrank", "decay", "clustered"])
 def test_symeig_large(kind, n):
     from vivit_amd import kernels

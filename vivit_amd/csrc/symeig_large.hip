@@ -60,8 +60,8 @@ __global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict_
 static int bt_nsub(int64_t n) {   // largest super-block (workspace sizing)
   static int forced = -2;
   if (forced == -2) { const char *e = getenv("VIVIT_BT_NSUB"); forced = e ? atoi(e) : -1; }
-  if (forced > 0 && n >= 8192) return forced;   // (power of two; experiments)
-  return n >= 16384 ? 16 : (n >= 8192 ? 8 : (n >= 2048 ? 2 : 1));
+  if (forced > 0 && n >= 2048) return forced;   // (power of two; experiments)
+  return n >= 16384 ? 16 : (n >= 8192 ? 8 : (n >= 4096 ? 4 : (n >= 2048 ? 2 : 1)));
 }
 // Super-block actually used for `nrows` rows of Zt: the read-modify-write of Zt per super-block favours 2048
 // reflectors when (nearly) all rows are transformed (Q1 at n = 40 960: 1037 / 816 / 767 / 757 ms for 512 / 1024 /
@@ -157,9 +157,10 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
 constexpr int TS_NB = 64;
 
 // 1 = use the two-stage tridiagonalisation.  Values-only solves switch at n >= 2048 (the band
-// reduction is MFMA-bound, the one-stage reduction HBM-bound).  With eigenvectors the second
-// back-transformation (Q2, q2apply.hip) has to be paid for: measured (one-stage / two-stage, ms) n = 4096:
-// 143 / 187, 6144: 267 / 290, 8192: 420 / 403, 10240: 625 / 539, 16384: 1857 / 1048, 40960: 16400 / 6480.
+// reduction is MFMA-bound, the one-stage reduction HBM-bound; 53.1 / 53.6 ms at the crossover).  With eigenvectors the
+// second back-transformation (Q2, q2apply.hip) has to be paid for: measured at the end of round 2 (one-stage /
+// two-stage, ms) n = 2048: 58 / 63, 3072: 92 / 95, 4096: 137 / 130, 6144: 259 / 199, 8192: 420 / 272, 40960: 16400 / 4500
+// (round 1 had the crossover at 8192: bulge chasing, band reduction and Q2 have since become 1.5-2x faster).
 // VIVIT_TWO_STAGE=0/1 overrides.
 static bool use_two_stage(int64_t n, bool vectors) {
   static int forced = -2;
@@ -168,7 +169,7 @@ static bool use_two_stage(int64_t n, bool vectors) {
     forced = e ? atoi(e) : -1;
   }
   if (forced >= 0) return forced != 0 && n > 2 * TS_NB;
-  return vectors ? n >= 8192 : n >= 2048;
+  return vectors ? n >= 4096 : n >= 2048;
 }
 
 static size_t two_stage_workspace_bytes(int64_t n, bool vectors) {

@@ -37,7 +37,7 @@ extern "C" {
 #define VIVIT_E_UNSUPPORTED (-4)
 
 /* Library/ABI version (major*1000 + minor) and the gfx target it was compiled for. */
-int vivit_hip_abi_version(void);
+int vivit_hip_abi_version(void);   /* 1003 in this release; _lib.py refuses an older library */
 const char *vivit_hip_target(void);
 const char *vivit_hip_status_string(int status);
 
@@ -55,12 +55,22 @@ const char *vivit_hip_status_string(int status);
  * computed on MFMA (n(n+1)p flops); the mirror tiles are transposed through LDS and stored as well.
  * ------------------------------------------------------------------------------------------- */
 /* Matrix pipe of the large K-contiguous products (the Gram SYRK above a few hundred 256 x 256 tiles and K >= 1024, the NT
- * GEMMs of the same size): 6 (default) = bf16 MFMA pipe -- every fp32 operand is split EXACTLY into three bf16 pieces
- * (a = hi + mid + lo, 24 significand bits) and a product is the sum of the six partial products that are >= 2^-16 of it,
- * each exact in the MFMA, accumulated in fp32 (the three dropped ones are < 2^-24 |a b|, below the rounding of an fp32
- * product); 9 = all nine partial products; 0 = v_mfma_f32_32x32x2_f32 on the fp32 operands.  Set once per process by
- * the environment variable VIVIT_GEMM_SPLIT.  The split pieces of a 32 768-column chunk live in the workspace
- * (6 bytes per element of the chunk). */
+ * GEMMs of the same size, and Gram matrices of small batches with a deep contraction): 6 (default) = bf16 MFMA pipe --
+ * every fp32 operand is split EXACTLY into three bf16 pieces (a = hi + mid + lo, 24 significand bits) and a product is
+ * the sum of the six partial products that are >= 2^-16 of it, each exact in the MFMA, accumulated in fp32 (the three
+ * dropped ones are < 2^-24 |a b|, below the rounding of an fp32 product); 9 = all nine partial products; 3 = three
+ * (per-product error 2^-16: exists so that tests can show they would notice); 0 = v_mfma_f32_32x32x2_f32 on the fp32
+ * operands.  Set once per process by the environment variable VIVIT_GEMM_SPLIT.  The split pieces of a 65 536-column
+ * chunk live in the workspace (6 bytes per element of the chunk).
+ *
+ * INPUT RANGE CONTRACT (tests/test_gram_precision_gpu.py).  The split is exact only for finite values whose smallest
+ * piece is a normal bf16 number.  The split pass therefore flags, per column chunk, (bit 0) any value that is +-inf,
+ * NaN or rounds to +-inf as bf16 (|a| >= 3.3962e38) and (bit 1) any non-zero value below 2^-100; the bf16-pipe launch
+ * of a flagged chunk returns at once and the fp32 MFMA kernel, always launched behind it on the same columns (and
+ * returning at once for an unflagged chunk -- there is no host synchronisation), computes that chunk instead.  Every
+ * entry point in this header thus has the semantics of a k-ordered fp32 fma chain for EVERY input: inf/NaN propagate
+ * as in IEEE fp32, 3.4e38 * 0.5 is finite, denormal inputs are multiplied as fp32 denormals.  (Internal products of
+ * the eigensolver honour bit 0 only.) */
 int vivit_gemm_split_mode(void);
 size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p);
 int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float *G, int64_t ldg,

@@ -62,7 +62,7 @@ def constant_damping(d):
 
 class OracleBackend:
     """Same function names as ``vivit_amd.kernels``, computed with torch on CPU (oracle ops).
-    Injected with ``kernels.set_backend_for_testing`` to test the Python hook layer without a GPU."""
+    ``set_kernel_backend`` monkeypatches it over the launchers to test the Python hook layer without a GPU."""
 
     @staticmethod
     def _acc(res, out, alpha, beta):
@@ -112,6 +112,16 @@ class OracleBackend:
         w, Z = oracle.tensor_symeig(G, eigenvectors=eigenvectors, upper=False)
         return w, (Z if eigenvectors else None)
 
+    def symeig_reduce(self, G, overwrite=False):
+        from vivit_amd.kernels import SymeigPlan
+
+        w, Z = self.symeig(G, True)
+        return SymeigPlan(w, G.shape[0], full=Z)
+
+    def symeig_rows(self, G, row_begin, row_end, overwrite=False):
+        w, Z = self.symeig(G, True)
+        return w, Z.T[row_begin:row_end].contiguous()
+
     def dir_curvature(self, GE, evals, C, N, scale):
         K = evals.numel()
         return scale * (GE.view(C, N, K) ** 2).sum(0) / evals
@@ -126,6 +136,26 @@ class OracleBackend:
         for t in tensors:
             t.mul_((1 / sq.sqrt()).view(K, *([1] * (t.dim() - 1))))
         return tensors
+
+
+_PATCHED = {}
+
+
+def set_kernel_backend(backend):
+    """Monkeypatch the launcher functions of ``vivit_amd.kernels`` with ``backend``'s methods of the same names
+    (``None`` restores the HIP launchers).  The seam lives here, in tests/: the product module has no switch."""
+    from vivit_amd import kernels
+
+    for name, fn in _PATCHED.items():
+        setattr(kernels, name, fn)
+    _PATCHED.clear()
+    if backend is None:
+        return
+    for name in dir(backend):
+        if name.startswith("_") or not callable(getattr(backend, name)):
+            continue
+        _PATCHED[name] = getattr(kernels, name)
+        setattr(kernels, name, getattr(backend, name))
 
 
 def resnet32(num_classes=100):

@@ -16,7 +16,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in vivit_hip.h but not exported"
     missing = declared - set(_lib.SIGNATURES)
     assert not missing, f"no ctypes prototype for {missing}"
-    assert lib.vivit_hip_abi_version() >= 1000
+    assert lib.vivit_hip_abi_version() == _lib.ABI_VERSION
     assert lib.vivit_hip_target() == b"gfx950"
     assert b"workspace" in lib.vivit_hip_status_string(-2)
 

@@ -4,7 +4,7 @@ golden vectors were recorded (hand-made factors attached to parameters, ``hook(m
 Two flavours of every test:
   * ``hip``   (marked gpu): the product path, HIP kernels through the C ABI;
   * ``host``  (CPU): only the Python hook/scheduling/scaling layer, with the oracle standing in
-    for the kernels (kernels.set_backend_for_testing) -- keeps the host logic covered without a GPU.
+    for the kernels (helpers.set_kernel_backend monkeypatches the launchers) -- keeps the host logic covered without a GPU.
 """
 import numpy as np
 import pytest
@@ -15,6 +15,7 @@ from helpers import (
     CASES,
     FakeModule,
     OracleBackend,
+    set_kernel_backend,
     constant_damping,
     golden_factors,
     load_golden,
@@ -36,11 +37,11 @@ FLAVOURS = [pytest.param("host", id="host"), pytest.param("hip", id="hip", marks
 @pytest.fixture(params=FLAVOURS)
 def device(request):
     if request.param == "host":
-        kernels.set_backend_for_testing(OracleBackend())
+        set_kernel_backend(OracleBackend())
         yield torch.device("cpu")
-        kernels.set_backend_for_testing(None)
+        set_kernel_backend(None)
     else:
-        kernels.set_backend_for_testing(None)
+        set_kernel_backend(None)
         yield torch.device("cuda:0")
 
 

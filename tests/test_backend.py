@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 import vivit_amd
-from helpers import OracleBackend, constant_damping, keep_all, top_k_criterion
+from helpers import OracleBackend, constant_damping, keep_all, set_kernel_backend, top_k_criterion
 from oracle import vivit_oracle as oracle
 from vivit_amd import kernels
 from vivit_amd.backend import BatchGrad, SqrtGGNExact, SqrtGGNMC, ViViTGGNExact, backpack, extend
@@ -18,11 +18,11 @@ FLAVOURS = [pytest.param("host", id="host"), pytest.param("hip", id="hip", marks
 @pytest.fixture(params=FLAVOURS)
 def device(request):
     if request.param == "host":
-        kernels.set_backend_for_testing(OracleBackend())
+        set_kernel_backend(OracleBackend())
         yield torch.device("cpu")
-        kernels.set_backend_for_testing(None)
+        set_kernel_backend(None)
     else:
-        kernels.set_backend_for_testing(None)
+        set_kernel_backend(None)
         yield torch.device("cuda:0")
 
 

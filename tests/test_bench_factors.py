@@ -4,7 +4,7 @@ import torch
 from torch import nn
 
 import bench
-from helpers import OracleBackend
+from helpers import OracleBackend, set_kernel_backend
 from vivit_amd import kernels
 from vivit_amd.backend import SqrtGGNExact, backpack, extend
 
@@ -18,13 +18,13 @@ def test_bench_factors_match_backend():
         X = torch.rand(batch, 7)
     model = extend(nn.Sequential(lin1, nn.ReLU(), lin2))
     lossf = extend(nn.CrossEntropyLoss())
-    kernels.set_backend_for_testing(OracleBackend())
+    set_kernel_backend(OracleBackend())
     try:
         loss = lossf(model(X), torch.zeros(batch, dtype=torch.long))
         with backpack(SqrtGGNExact()):
             loss.backward()
     finally:
-        kernels.set_backend_for_testing(None)
+        set_kernel_backend(None)
     n = 5 * batch
     expect = [lin2.weight, lin2.bias, lin1.weight, lin1.bias]
     for f, p in zip(facs, expect):

@@ -16,10 +16,10 @@ def _setup(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from helpers import OracleBackend
+    from helpers import OracleBackend, set_kernel_backend
     from vivit_amd import kernels
 
-    kernels.set_backend_for_testing(OracleBackend())
+    set_kernel_backend(OracleBackend())
 
 
 def _worker_param_sharded(rank, world, port, ret):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import vivit_amd
-from helpers import FakeModule, OracleBackend, top_k_criterion
+from helpers import FakeModule, OracleBackend, set_kernel_backend, top_k_criterion
 from vivit_amd import kernels
 from vivit_amd.backend.extensions import _linear_weight_closures, _materialised_closures
 
@@ -17,11 +17,11 @@ FLAVOURS = [pytest.param("host", id="host"), pytest.param("hip", id="hip", marks
 @pytest.fixture(params=FLAVOURS)
 def device(request):
     if request.param == "host":
-        kernels.set_backend_for_testing(OracleBackend())
+        set_kernel_backend(OracleBackend())
         yield torch.device("cpu")
-        kernels.set_backend_for_testing(None)
+        set_kernel_backend(None)
     else:
-        kernels.set_backend_for_testing(None)
+        set_kernel_backend(None)
         yield torch.device("cuda:0")
 
 

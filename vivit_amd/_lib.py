@@ -61,6 +61,8 @@ SIGNATURES = {
     "vivit_symmetrize_lower_f32": (_int, [_ptr, _i64, _i64, _ptr]),
 }
 
+ABI_VERSION = 1003  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
+
 _lib = None
 
 
@@ -79,6 +81,13 @@ def load():
             " (hipcc --offload-arch=gfx950). vivit_amd has no CPU fallback."
         )
     lib = ctypes.CDLL(LIB_PATH)
+    lib.vivit_hip_abi_version.restype = _int
+    have = lib.vivit_hip_abi_version()
+    if have != ABI_VERSION:
+        raise ImportError(
+            f"{LIB_PATH} has ABI version {have}, this package needs {ABI_VERSION}: rebuild it "
+            "(`python -c 'import __graft_entry__ as g; g.build()'`)"
+        )
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype

@@ -58,6 +58,9 @@ struct GemmArgs {
   int a_vec, b_vec; // 16-byte loads legal for the operand
   const GemmDesc *desc;  // non-null: batched mode, problem blockIdx.z is desc[blockIdx.z]
   int sbw;          // super-block width in tiles (host and kernel must agree on the tile map)
+  // gemm256_kernel only: non-null = the launch stands in for a bf16-pipe launch and runs iff (*gate & gate_mask) != 0
+  const int *gate = nullptr;
+  int gate_mask = 0;
 };
 
 // Generic launcher (gemm_f32.hip).  alay/blay in {LAY_K, LAY_M}.

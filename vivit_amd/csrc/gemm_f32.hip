@@ -526,6 +526,8 @@ __device__ __forceinline__ void dma16(gcptr src, unsigned lds_byte_addr) {
 template <int ALAY, int BLAY>
 __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem2[];
+  // stand-in for a bf16-pipe launch whose operand chunk is out of the split's range: runs only when the chunk is flagged
+  if (p.gate && (*p.gate & p.gate_mask) == 0) return;
   int ti, tj;
   if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
 
@@ -789,10 +791,16 @@ __device__ __forceinline__ void bx_split2(float a, float b, unsigned &hi, unsign
 // every lane fetch 16 bytes from a different cache line: 4x the L2 traffic, the product ran at 105 TFLOP/s-equivalent).
 // One workgroup converts 32 rows x 64 k: coalesced 32-byte reads per lane, transposition through LDS, 1 KB bursts out.
 // Rows beyond `rows` are written as zeros.  kc % 16 == 0; grid.x = row blocks, grid.y = groups of 4 k tiles.
+//
+// Range gate: the three-way split is exact for finite values whose smallest piece is a NORMAL bf16 number.  A value that
+// is non-finite or rounds to +-inf as bf16 (|a| >= 0x7F7F8000 = 3.3962e38) sets bit 0 of *flag, a non-zero value below
+// 2^-100 (its `lo` piece could fall below 2^-126) sets bit 1; the bf16-pipe product of a flagged chunk returns at once
+// and the fp32 MFMA kernel, launched behind it on the same columns, computes the chunk instead (BX_GATE below).
+constexpr int BX_GATE_RANGE = 1, BX_GATE_TINY = 2;
 template <int LAY>
 __global__ __launch_bounds__(256) void bx_split_kernel(const float *__restrict__ A, int64_t rows, int64_t lda, int64_t k0,
                                                        int64_t kc, unsigned short *__restrict__ P, int64_t piece_stride,
-                                                       int64_t nrb) {
+                                                       int64_t nrb, int *__restrict__ flag) {
   __shared__ __attribute__((aligned(16))) unsigned char sp[3][4][1024];
   __shared__ float tr[LAY == LAY_M ? 64 * 33 : 1];
   const int tid = threadIdx.x;
@@ -832,6 +840,18 @@ __global__ __launch_bounds__(256) void bx_split_kernel(const float *__restrict__
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = tr[(seg * 8 + j) * 33 + rl];
+  }
+  {
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = fabsf(v[j]);
+      bad |= !(x < __uint_as_float(0x7F7F8000u)) ? BX_GATE_RANGE : 0;           // inf, NaN, rounds to inf as bf16
+      bad |= (x < __uint_as_float(0x0D800000u) && x != 0.f) ? BX_GATE_TINY : 0;  // 0 < |a| < 2^-100
+    }
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64((bad & BX_GATE_RANGE) != 0);
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64((bad & BX_GATE_TINY) != 0);
+    if ((m0 | m1) != 0 && (tid & 63) == 0) atomicOr(flag, (m0 ? BX_GATE_RANGE : 0) | (m1 ? BX_GATE_TINY : 0));  // rare
   }
   {
     unsigned h[4], m[4], l[4];
@@ -880,11 +900,14 @@ struct GemmBxArgs {
   // [z kt_split, (z + 1) kt_split) and writes its partial tile (alpha = 1, beta = 0) to slab[z][M][N]
   float *slab;
   int kt_split;
+  const int *gate;               // range flag of this chunk (bx_split_kernel); the kernel returns when *gate & gate_mask
+  int gate_mask;
 };
 
 template <int NPROD>
 __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
+  if (p.gate && (*p.gate & p.gate_mask) != 0) return;  // the fp32 MFMA kernel takes this chunk
   int ti, tj;
   if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
 
@@ -1626,11 +1649,26 @@ static int64_t bx_chunk_cols(int64_t K) {
   if (kc < 0) { const char *e = getenv("VIVIT_GEMM_SPLIT_KC"); kc = e ? atoll(e) : 65536; kc = kc / 16 * 16; if (kc < 16) kc = 16; }
   return K < kc ? K : kc;
 }
-static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same) {
+static size_t bx_piece_bytes(int64_t M, int64_t N, int64_t K, bool same) {
   const int64_t kc = bx_chunk_cols(K);
   const int64_t ra = cdiv(M, 32) * 32, rb = cdiv(N, 32) * 32;
-  return (size_t)6 * (size_t)kc * (size_t)(same ? ra : ra + rb) + 256;
+  return (size_t)6 * (size_t)kc * (size_t)(same ? ra : ra + rb);
 }
+// pieces of one chunk + one range flag per chunk (BX_GATE)
+static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same) {
+  return bx_piece_bytes(M, N, K, same) + 256 + 4 * (size_t)cdiv(K, bx_chunk_cols(K)) + 256;
+}
+
+// Which range flags send a chunk to the fp32 MFMA kernel.  The public products (vivit_gram_syrk_f32, vivit_gemm_*_f32)
+// honour both bits and so keep fp32-MFMA semantics for every input; the eigensolver's internal products on orthogonal
+// factors only reroute non-finite / out-of-range chunks (a localised eigenvector has entries below 2^-100 whose
+// 2^-126-level piece is immaterial, and the reroute would cost that chunk the bf16 pipe's 2.7x).
+static thread_local int tls_bx_gate_mask = BX_GATE_RANGE;
+struct BxStrictScope {
+  int saved;
+  BxStrictScope() : saved(tls_bx_gate_mask) { tls_bx_gate_mask = BX_GATE_RANGE | BX_GATE_TINY; }
+  ~BxStrictScope() { tls_bx_gate_mask = saved; }
+};
 
 static bool gemm256_attrs() {
   static unsigned long long attr_done = 0;
@@ -1697,36 +1735,62 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
     unsigned short *PA = static_cast<unsigned short *>(workspace);
     const int64_t strideA = nrbA * 32 * kc_max, strideB = nrbB * 32 * kc_max;
     unsigned short *PB = same ? PA : PA + 3 * strideA;
+    int *flags = reinterpret_cast<int *>(align_up(reinterpret_cast<uintptr_t>(workspace) + bx_piece_bytes(p.M, p.N, p.K, same), 256));
+    const int64_t nchunks = cdiv(p.K, kc_max);
+    if (hipMemsetAsync(flags, 0, 4 * (size_t)nchunks, stream) != hipSuccess) return VIVIT_E_LAUNCH;
     GemmBxArgs q;
     q.A = PA; q.B = PB; q.strideA = strideA; q.strideB = same ? strideA : strideB;
     q.nrbA = nrbA; q.nrbB = same ? nrbA : nrbB;
     q.C = p.C; q.M = p.M; q.N = p.N; q.ldc = p.ldc; q.alpha = p.alpha;
     q.tiles_m = p.tiles_m; q.tiles_n = p.tiles_n; q.syrk = p.syrk; q.sbw = p.sbw;
     q.slab = nullptr; q.kt_split = 0;
+    q.gate_mask = tls_bx_gate_mask;
     int st = VIVIT_OK;
-    for (int64_t k0 = 0; k0 < p.K && st == VIVIT_OK; k0 += kc_max) {
+    int64_t chunk = 0;
+    for (int64_t k0 = 0; k0 < p.K && st == VIVIT_OK; k0 += kc_max, ++chunk) {
       const int64_t kc = (p.K - k0) < kc_max ? (p.K - k0) : kc_max;
       const unsigned gy = (unsigned)cdiv(kc / 16, 4);
+      int *flag = flags + chunk;
       if (alay == LAY_K)
-        bx_split_kernel<LAY_K><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, k0, kc, PA, strideA, nrbA);
+        bx_split_kernel<LAY_K><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, k0, kc, PA, strideA, nrbA, flag);
       else
-        bx_split_kernel<LAY_M><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, k0, kc, PA, strideA, nrbA);
+        bx_split_kernel<LAY_M><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, k0, kc, PA, strideA, nrbA, flag);
       if (!same) {
         if (blay == LAY_K)
-          bx_split_kernel<LAY_K><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB);
+          bx_split_kernel<LAY_K><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB, flag);
         else
-          bx_split_kernel<LAY_M><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB);
+          bx_split_kernel<LAY_M><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB, flag);
       }
       q.K = kc;
       q.beta = k0 == 0 ? p.beta : 1.f;
       // SYRK: only the last chunk mirrors the finished lower tiles into the upper triangle (2 = lower tiles, no mirror)
       q.syrk = (p.syrk == 1 && k0 + kc < p.K) ? 2 : p.syrk;
+      q.gate = flag;
       if (bx == 6)
         gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
       else if (bx == 9)
         gemm256_bx_kernel<9><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
       else
         gemm256_bx_kernel<3><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+      st = launch_status();
+      if (st != VIVIT_OK) break;
+      // BX_GATE: the same chunk on the fp32 MFMA kernel; every workgroup returns at once unless the chunk is flagged
+      GemmArgs f = p;
+      f.A = p.A + (alay == LAY_K ? k0 : k0 * p.lda);
+      f.B = p.B + (blay == LAY_K ? k0 : k0 * p.ldb);
+      f.K = kc; f.kchunk = kc; f.ksplit = 1; f.slab = nullptr;
+      f.beta = q.beta; f.syrk = q.syrk;
+      f.a_vec = ((reinterpret_cast<uintptr_t>(f.A) & 15) == 0 && (f.lda & 3) == 0) ? 1 : 0;
+      f.b_vec = ((reinterpret_cast<uintptr_t>(f.B) & 15) == 0 && (f.ldb & 3) == 0) ? 1 : 0;
+      f.gate = flag; f.gate_mask = q.gate_mask;
+      if (alay == LAY_K && blay == LAY_K)
+        gemm256_kernel<LAY_K, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
+      else if (alay == LAY_K && blay == LAY_M)
+        gemm256_kernel<LAY_K, LAY_M><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
+      else if (alay == LAY_M && blay == LAY_K)
+        gemm256_kernel<LAY_M, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
+      else
+        gemm256_kernel<LAY_M, LAY_M><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
       st = launch_status();
     }
     if (st == VIVIT_OK && p.syrk == 1) {
@@ -1779,7 +1843,7 @@ static bool bx_splitk_shape(int64_t M, int64_t N, int64_t K, bool syrk, bool sam
   s = cdiv(nt, kts);
   if (nsplit_out) *nsplit_out = (int)s;
   if (kt_split_out) *kt_split_out = (int)kts;
-  if (bytes_out) *bytes_out = pieces + 256 + (size_t)s * (size_t)M * (size_t)N * sizeof(float) + 256;
+  if (bytes_out) *bytes_out = pieces + 256 + (size_t)s * (size_t)M * (size_t)N * sizeof(float) + 256 + 256;  // + range flag
   return true;
 }
 
@@ -1796,18 +1860,20 @@ static int bx_splitk_launch(int alay, int blay, const GemmArgs &p, bool syrk, vo
   unsigned short *PB = same ? PA : PA + 3 * strideA;
   const size_t pieces = (size_t)6 * (size_t)p.K * (size_t)(same ? nrbA * 32 : (nrbA + nrbB) * 32);
   float *slab = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(workspace) + pieces, 256));
+  int *flag = reinterpret_cast<int *>(align_up(reinterpret_cast<uintptr_t>(slab) + (size_t)nsplit * (size_t)p.M * (size_t)p.N * sizeof(float), 256));
+  if (hipMemsetAsync(flag, 0, 4, stream) != hipSuccess) return VIVIT_E_LAUNCH;
   const bool prof = syrk && same && prof_enabled();
   if (prof) prof_begin(0, (double)p.M * (double)(p.M + 1) * (double)p.K, stream);
   const unsigned gy = (unsigned)cdiv(p.K / 16, 4);
   if (alay == LAY_K)
-    bx_split_kernel<LAY_K><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, 0, p.K, PA, strideA, nrbA);
+    bx_split_kernel<LAY_K><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, 0, p.K, PA, strideA, nrbA, flag);
   else
-    bx_split_kernel<LAY_M><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, 0, p.K, PA, strideA, nrbA);
+    bx_split_kernel<LAY_M><<<dim3((unsigned)nrbA, gy), 256, 0, stream>>>(p.A, p.M, p.lda, 0, p.K, PA, strideA, nrbA, flag);
   if (!same) {
     if (blay == LAY_K)
-      bx_split_kernel<LAY_K><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, 0, p.K, PB, strideB, nrbB);
+      bx_split_kernel<LAY_K><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, 0, p.K, PB, strideB, nrbB, flag);
     else
-      bx_split_kernel<LAY_M><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, 0, p.K, PB, strideB, nrbB);
+      bx_split_kernel<LAY_M><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, 0, p.K, PB, strideB, nrbB, flag);
   }
   GemmBxArgs q;
   q.A = PA; q.B = PB; q.strideA = strideA; q.strideB = same ? strideA : strideB;
@@ -1818,11 +1884,30 @@ static int bx_splitk_launch(int alay, int blay, const GemmArgs &p, bool syrk, vo
   const int sbw = syrk ? 16 : sb_width(q.tiles_m, q.tiles_n), sbh = 256 / sbw;
   q.sbw = sbw;
   q.slab = slab; q.kt_split = kts;
+  q.gate = flag; q.gate_mask = tls_bx_gate_mask;
   const int64_t sbm = cdiv(q.tiles_m, sbh), sbn = cdiv(q.tiles_n, sbw);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
-  gemm256_bx_kernel<6><<<dim3((unsigned)(nsb * 256), (unsigned)nsplit), 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+  const dim3 grid((unsigned)(nsb * 256), (unsigned)nsplit);
+  gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
   int st = launch_status();
   if (st != VIVIT_OK) return st;
+  {  // BX_GATE: the fp32 MFMA kernel with the same K split and slab; returns at once unless the operand is flagged
+    GemmArgs f = p;
+    f.ksplit = nsplit; f.kchunk = (int64_t)kts * BK; f.slab = slab;
+    f.tiles_m = q.tiles_m; f.tiles_n = q.tiles_n; f.syrk = q.syrk; f.sbw = sbw; f.desc = nullptr;
+    f.a_vec = f.b_vec = 1;
+    f.gate = flag; f.gate_mask = q.gate_mask;
+    if (alay == LAY_K && blay == LAY_K)
+      gemm256_kernel<LAY_K, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
+    else if (alay == LAY_K && blay == LAY_M)
+      gemm256_kernel<LAY_K, LAY_M><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
+    else if (alay == LAY_M && blay == LAY_K)
+      gemm256_kernel<LAY_M, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
+    else
+      gemm256_kernel<LAY_M, LAY_M><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
+    st = launch_status();
+    if (st != VIVIT_OK) return st;
+  }
   gemm_reduce_kernel<<<(unsigned)cdiv(p.M * p.N, 256), 256, 0, stream>>>(slab, p.C, p.M, p.N, p.ldc, nsplit, p.alpha, p.beta,
                                                                        syrk ? 1 : 0, B2);
   st = launch_status();
@@ -2079,6 +2164,7 @@ size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p) { return gemm_w
 
 int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float *G, int64_t ldg, float alpha,
                         float beta, void *workspace, size_t workspace_bytes, void *stream) {
+  BxStrictScope strict;  // public product: both range bits reroute a chunk to the fp32 MFMA kernel
   return gemm_launch(LAY_K, LAY_K, A, A, G, n, n, p, lda, lda, ldg, alpha, beta, true, workspace, workspace_bytes,
                      static_cast<hipStream_t>(stream));
 }
@@ -2095,6 +2181,7 @@ size_t vivit_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) {
 int vivit_gemm_nt_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k, int64_t lda,
                       int64_t ldb, int64_t ldc, float alpha, float beta, void *workspace, size_t workspace_bytes,
                       void *stream) {
+  BxStrictScope strict;  // public product: both range bits reroute a chunk to the fp32 MFMA kernel
   return gemm_launch(LAY_K, LAY_K, A, B, C, m, n, k, lda, ldb, ldc, alpha, beta, false, workspace, workspace_bytes,
                      static_cast<hipStream_t>(stream));
 }
@@ -2102,6 +2189,7 @@ int vivit_gemm_nt_f32(const float *A, const float *B, float *C, int64_t m, int64
 int vivit_gemm_nn_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k, int64_t lda,
                       int64_t ldb, int64_t ldc, float alpha, float beta, void *workspace, size_t workspace_bytes,
                       void *stream) {
+  BxStrictScope strict;
   // few output rows: HBM-bound streaming kernel instead of a mostly idle MFMA tile (K7/K8)
   if (skinny_applicable(m, n, k) && A && B && C && lda >= k && ldb >= n && ldc >= n &&
       workspace_bytes >= skinny_workspace_bytes(m, k, n) && workspace)
@@ -2114,6 +2202,7 @@ int vivit_gemm_nn_f32(const float *A, const float *B, float *C, int64_t m, int64
 int vivit_gemm_tn_f32(const float *A, const float *B, float *C, int64_t m, int64_t n, int64_t k, int64_t lda,
                       int64_t ldb, int64_t ldc, float alpha, float beta, void *workspace, size_t workspace_bytes,
                       void *stream) {
+  BxStrictScope strict;  // public product: both range bits reroute a chunk to the fp32 MFMA kernel
   return gemm_launch(LAY_M, LAY_M, A, B, C, m, n, k, lda, ldb, ldc, alpha, beta, false, workspace, workspace_bytes,
                      static_cast<hipStream_t>(stream));
 }

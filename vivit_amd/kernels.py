@@ -3,7 +3,7 @@
 PyTorch is plumbing here (device memory, streams); all arithmetic happens in the hand-written
 gfx950 kernels behind the C ABI of ``include/vivit_hip.h``.  Every function raises
 ``RuntimeError`` for tensors that are not fp32 HIP-device tensors: there is deliberately no CPU
-path (tests inject the oracle through :func:`vivit_amd.kernels.set_backend_for_testing`).
+path and no backend switch (host-logic tests monkeypatch these functions from ``tests/helpers.py``).
 """
 import functools
 from typing import Optional, Tuple
@@ -13,17 +13,6 @@ import torch
 from vivit_amd import _lib
 
 _WORKSPACES = {}
-_TEST_BACKEND = None  # only ever set by tests/ (host-logic tests on CPU)
-
-
-def set_backend_for_testing(backend):
-    """Route the launchers below to ``backend`` (an object with the same function names).
-
-    Test infrastructure only: lets ``-m "not gpu"`` tests exercise the Python hook/scheduling
-    layer on CPU with the oracle standing in for the kernels.  Product code never calls this.
-    """
-    global _TEST_BACKEND
-    _TEST_BACKEND = backend
 
 
 def _require_device(*tensors):
@@ -61,7 +50,7 @@ def _launcher(fn):
 
     @functools.wraps(fn)
     def wrapped(*args, **kwargs):
-        dev = None if _TEST_BACKEND is not None else _first_device(args, kwargs)
+        dev = _first_device(args, kwargs)
         if dev is None or dev.index == torch.cuda.current_device():
             return fn(*args, **kwargs)
         with torch.cuda.device(dev):
@@ -76,7 +65,7 @@ def _launcher_method(fn):
     @functools.wraps(fn)
     def wrapped(self, *args, **kwargs):
         dev = self.evals.device
-        if _TEST_BACKEND is not None or not dev.type == "cuda" or dev.index == torch.cuda.current_device():
+        if not dev.type == "cuda" or dev.index == torch.cuda.current_device():
             return fn(self, *args, **kwargs)
         with torch.cuda.device(dev):
             return fn(self, *args, **kwargs)
@@ -135,8 +124,6 @@ def _ld(t):
 @_launcher
 def gram_syrk(A: torch.Tensor, out: Optional[torch.Tensor] = None, alpha: float = 1.0, beta: float = 0.0):
     """``out = alpha * A @ A.T + beta * out`` for ``A: [n, p]`` (K1, MFMA SYRK)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.gram_syrk(A, out, alpha, beta)
     _require_device(A, out)
     A = _as2d(A)
     n, p = A.shape
@@ -168,8 +155,6 @@ def _gemm(name, A, B, m, n, k, out, alpha, beta):
 @_launcher
 def gemm_nt(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out = alpha * A @ B.T + beta * out``; ``A: [m, k]``, ``B: [n, k]`` (K2/K9)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.gemm_nt(A, B, out, alpha, beta)
     _require_device(A, B, out)
     A, B = _as2d(A), _as2d(B)
     if A.shape[1] != B.shape[1]:
@@ -180,8 +165,6 @@ def gemm_nt(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
 @_launcher
 def gemm_nn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out = alpha * A @ B + beta * out``; ``A: [m, k]``, ``B: [k, n]`` (K6/K7/K8)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.gemm_nn(A, B, out, alpha, beta)
     _require_device(A, B, out)
     A, B = _as2d(A), _as2d(B)
     if A.shape[1] != B.shape[0]:
@@ -192,8 +175,6 @@ def gemm_nn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
 @_launcher
 def gemm_tn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out = alpha * A.T @ B + beta * out``; ``A: [k, m]``, ``B: [k, n]`` (K5)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.gemm_tn(A, B, out, alpha, beta)
     _require_device(A, B, out)
     A, B = _as2d(A), _as2d(B)
     if A.shape[0] != B.shape[0]:
@@ -204,8 +185,6 @@ def gemm_tn(A, B, out=None, alpha: float = 1.0, beta: float = 0.0):
 @_launcher
 def gram_hadamard(Gz, Gs, C: int, N: int, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out[c,n,d,m] = alpha * Gz[n,m] * Gs[c,n,d,m] + beta * out`` (K1')."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.gram_hadamard(Gz, Gs, C, N, out, alpha, beta)
     _require_device(Gz, Gs, out)
     Gz, Gs = Gz.contiguous(), Gs.contiguous()
     if out is None:
@@ -224,8 +203,6 @@ def gram_hadamard(Gz, Gs, C: int, N: int, out=None, alpha: float = 1.0, beta: fl
 def gram_hadamard_block(Gz, Gs, Cr: int, Nr: int, Cc: int, Nc: int, out=None, alpha: float = 1.0, beta: float = 0.0):
     """``out[(c,n),(d,m)] = alpha * Gz[n,m] * Gs[(c,n),(d,m)] + beta * out`` for a rectangular block (rows
     ``Cr x Nr``, columns ``Cc x Nc``): the block row of a batch shard, and ``V^T g`` of a factorised Linear weight."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.gram_hadamard_block(Gz, Gs, Cr, Nr, Cc, Nc, out, alpha, beta)
     _require_device(Gz, Gs, out)
     Gz, Gs = Gz.contiguous(), Gs.contiguous()
     rows, cols = Cr * Nr, Cc * Nc
@@ -244,8 +221,6 @@ def gram_hadamard_block(Gz, Gs, Cr: int, Nr: int, Cc: int, Nc: int, out=None, al
 @_launcher
 def class_contract(mat, s):
     """``T[f,o,n] = sum_c mat[f,c,n] s[c,n,o]``; ``mat: [F,C,N]``, ``s: [C,N,O]`` (first half of linear.py:53)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.class_contract(mat, s)
     _require_device(mat, s)
     mat, s = mat.contiguous(), s.contiguous()
     F, C, N = mat.shape
@@ -261,8 +236,6 @@ def class_contract(mat, s):
 @_launcher
 def class_expand(s, U):
     """``R[f,c,n] = sum_o s[c,n,o] U[f,o,n]``; ``s: [C,N,O]``, ``U: [F,O,N]`` (second half of linear.py:64)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.class_expand(s, U)
     _require_device(s, U)
     s, U = s.contiguous(), U.contiguous()
     C, N, O = s.shape
@@ -286,8 +259,6 @@ def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False,
     ``info_out``: the ``info`` tensor is appended to it instead and nothing is read back (check it with
     :func:`check_info` when convenient).
     """
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.symeig(G, eigenvectors)
     _require_device(G)
     if G.dim() != 2 or G.shape[0] != G.shape[1]:
         raise ValueError(f"Input must be a square matrix. Got shape {tuple(G.shape)}.")
@@ -314,8 +285,6 @@ def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False,
 @_launcher
 def linear_weight_mjp(s, z):
     """``V_t[c,n,o,i] = s[c,n,o] z[n,i]`` materialised (``param_mjp`` of a Linear weight, einsum "vno,ni->vnoi")."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.linear_weight_mjp(s, z)
     _require_device(s, z)
     s, z = s.contiguous(), z.contiguous()
     C, N, O = s.shape
@@ -332,8 +301,6 @@ def linear_weight_mjp(s, z):
 def conv2d_weight_mjp(M, x, kernel_size, stride, padding, dilation):
     """``param_mjp`` of a Conv2d weight (groups = 1, zero padding): ``M [V, N, Cout, OH, OW]``, ``x [N, Cin, H, W]`` ->
     ``[V, N, Cout, Cin, KH, KW]`` (unfold + einsum "vnol,nkl->vnok" without the im2col buffer)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.conv2d_weight_mjp(M, x, kernel_size, stride, padding, dilation)
     _require_device(M, x)
     M, x = M.contiguous(), x.contiguous()
     Vd, N, Cout, OH, OW = M.shape
@@ -368,7 +335,7 @@ class SymeigPlan:
         if any(k < 0 or k >= n for k in keep):
             raise IndexError(f"eigenvector index out of range for n = {n}")
         K = len(keep)
-        if self._full is not None:  # small problem / test backend: all vectors already there
+        if self._full is not None:  # small problem: all vectors already there
             return self._full[:, keep]
         if K == 0:
             return torch.empty((n, 0), dtype=torch.float32, device=dev)
@@ -395,9 +362,6 @@ def symeig_reduce(G: torch.Tensor, overwrite: bool = False) -> SymeigPlan:
     and a reduced state from which ``plan.select(keep)`` produces only the wanted eigenvectors
     (``vivit_symeig_reduce_f32`` / ``vivit_symeig_select_f32``).  Synchronises (the caller's criterion needs the
     eigenvalues anyway) and raises ``RuntimeError`` on non-convergence like :func:`symeig`."""
-    if _TEST_BACKEND is not None:
-        w, Z = _TEST_BACKEND.symeig(G, True)
-        return SymeigPlan(w, G.shape[0], full=Z)
     _require_device(G)
     if G.dim() != 2 or G.shape[0] != G.shape[1]:
         raise ValueError(f"Input must be a square matrix. Got shape {tuple(G.shape)}.")
@@ -434,9 +398,6 @@ def symeig_rows(G: torch.Tensor, row_begin: int, row_end: int, overwrite: bool =
     """All eigenvalues (ascending) of symmetric ``G`` and the eigenvectors ``row_begin .. row_end-1`` as ROWS
     ``[row_end - row_begin, n]`` (``vivit_symeig_rows_f32``): the unit of work of one rank in the multi-GPU
     eigensolver (``vivit_amd.distributed.symeig``)."""
-    if _TEST_BACKEND is not None:
-        w, Z = _TEST_BACKEND.symeig(G, True)
-        return w, Z.T[row_begin:row_end].contiguous()
     _require_device(G)
     if G.dim() != 2 or G.shape[0] != G.shape[1]:
         raise ValueError(f"Input must be a square matrix. Got shape {tuple(G.shape)}.")
@@ -544,8 +505,6 @@ def sb2st(AB: torch.Tensor):
 @_launcher
 def dir_curvature(GE, evals, C: int, N: int, scale: float):
     """``lambdas[n,k] = scale * sum_c GE[(c,n),k]^2 / evals[k]`` (K6 epilogue)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.dir_curvature(GE, evals, C, N, scale)
     _require_device(GE, evals)
     GE, evals = GE.contiguous(), evals.contiguous()
     K = evals.numel()
@@ -558,8 +517,6 @@ def dir_curvature(GE, evals, C: int, N: int, scale: float):
 @_launcher
 def scale_cols_rsqrt_(X, evals, pre: float = 1.0):
     """In place ``X[:, k] *= pre / sqrt(evals[k])`` (K5 epilogue)."""
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.scale_cols_rsqrt_(X, evals, pre)
     _require_device(X, evals)
     if X.stride(1) != 1:
         raise ValueError("X must have unit column stride")
@@ -576,8 +533,6 @@ def normalize_rows_(tensors):
     ``tensors``: list of ``[K, *param.shape]`` contiguous tensors; afterwards, for each ``k``,
     ``sum_t ||tensors[t][k]||^2 == 1``.  Replaces vivit/linalg/utils.py:67-76.
     """
-    if _TEST_BACKEND is not None:
-        return _TEST_BACKEND.normalize_rows_(tensors)
     if len(tensors) == 0:
         return tensors
     _require_device(*tensors)

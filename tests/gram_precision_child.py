@@ -38,6 +38,15 @@ def run_case(n, K, mixed, dev):
         A.mul_(scale.float().unsqueeze(1))
     G = kernels.gram_syrk(A)
     torch.cuda.synchronize()
+    ms = None
+    if os.environ.get("VIVIT_PREC_TIME"):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(3):
+            kernels.gram_syrk(A, out=G)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / 3
     ri = torch.tensor(rows_for(n, seed=1), device=dev)
     ci = torch.tensor(rows_for(n, seed=2), device=dev)
     ref = A[ri].double() @ A[ci].double().T                                  # [R, C] fp64
@@ -46,17 +55,22 @@ def run_case(n, K, mixed, dev):
     rms = A.double().pow(2).mean(1).sqrt()
     unit = rms[ri].unsqueeze(1) * rms[ci].unsqueeze(0) * (K ** 0.5)
     off = ri.unsqueeze(1) != ci.unsqueeze(0)
+    serr = ((got - ref) / unit)[off]
+    sref = (ref / unit)[off]
+    slope = float((serr * sref).sum() / (sref * sref).sum())   # err ~ slope * ref: a relative shrink/growth of every entry
     err = ((got - ref).abs() / unit)[off]
     err_t = ((got_t - ref).abs() / unit)[off]
     # diagonal: a sum of squares (all terms positive), error relative to the entry itself
     d = torch.arange(n, device=dev)
     dref = A.double().pow(2).sum(1)
     derr = ((G[d, d].double() - dref).abs() / dref)
+    dmean = float(((G[d, d].double() - dref) / dref).mean())
     return {
         "n": n, "K": K, "mixed": bool(mixed),
         "offdiag_rms": float(err.pow(2).mean().sqrt()), "offdiag_max": float(err.max()),
         "mirror_rms": float(err_t.pow(2).mean().sqrt()), "mirror_max": float(err_t.max()),
-        "diag_rms": float(derr.pow(2).mean().sqrt()), "diag_max": float(derr.max()),
+        "diag_rms": float(derr.pow(2).mean().sqrt()), "diag_max": float(derr.max()), "diag_mean": dmean,
+        "offdiag_slope": slope, "ms": ms,
         "symmetric": bool(torch.equal(G, G.T)),
         "finite": bool(torch.isfinite(G).all()),
         "entries": int(off.sum()),

@@ -110,7 +110,18 @@ def test_config1_eigh_keep_all(oracle_side):
     E = torch.cat([e.flatten(1) for e in evecs], 1)                       # [K, P] on the device
     assert E.shape[1] == sum(p.numel() for p in model.parameters())
     overlap = (E.double() @ E.double().T).cpu().numpy()
-    np.testing.assert_allclose(overlap, np.eye(K), atol=2e-4)            # test_eigh.py: rtol 1e-3 / atol 2e-4
+    # test_eigh.py:135-141 asks for atol 2e-4 on problems with a handful of O(1) eigenvalues.  Here the kept spectrum spans
+    # four decades.  A backward-stable fp32 eigensolver returns pairs with G e~ = l e~ + r, |r| = O(eps lambda_max), and
+    # e_i . e_j = e~_i^T (V V^T) e~_j / sqrt(l_i l_j), so the deviation from orthonormality carries the amplification
+    # lambda_max / sqrt(l_i l_j) (1e4 for two directions at the criterion's threshold): measured 4.7e-7 = 4 eps times it.
+    # LAPACK's ssyevd behind the reference's Tensor.symeig obeys the same bound.
+    ev = evals.cpu().double().numpy()
+    dev_ = np.abs(overlap - np.eye(K))
+    amp = lam / np.sqrt(np.outer(ev, ev))
+    print("orthonormality: max deviation", dev_.max(), "max deviation / amplification", (dev_ / amp).max())
+    assert (dev_ <= np.maximum(2e-4, 6e-7 * amp)).all(), (dev_.max(), (dev_ / amp).max())
+    strong = ev >= 3e-3 * lam                                             # amplification <= 333: the reference's atol holds
+    np.testing.assert_allclose(overlap[np.ix_(strong, strong)], np.eye(int(strong.sum())), atol=2e-4)
     # scaling property on a spread of directions, with the oracle's fp64 factors: (V^T V) e = lambda e
     Vflat = torch.cat([v.reshape(N * DIMS[2], -1) for v in oracle_side["V"]], 1)   # [n, P] fp64 (CPU)
     pick = sorted(set([K - 1, K - 2, K - 3, K - 10, K // 2, K // 4, 5, 0]))

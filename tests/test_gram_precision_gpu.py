@@ -60,16 +60,20 @@ def test_default_path_is_fp32_class(stats, case):
         assert bx[k] <= 2.0 * f32[k], (k, bx[k], f32[k])
     for k in ("offdiag_max", "mirror_max", "diag_max"):
         assert bx[k] <= 2.5 * f32[k], (k, bx[k], f32[k])
-    # and in absolute terms: fp32 accumulation of a (two-level) random-walk sum stays below 3e-6 per term
-    assert bx["offdiag_rms"] <= 3e-6
+    # and in absolute terms: fp32 accumulation of a (two-level) random-walk sum stays below 2.5e-6 per term, the mean
+    # relative error of the sums of squares on the diagonal (where truncation would show as a bias) below 2e-7
+    assert bx["offdiag_rms"] <= 2.5e-6
+    assert abs(bx["diag_mean"]) <= 2e-7 + 2.0 * abs(f32["diag_mean"])
 
 
 @pytest.mark.parametrize("case", TILE_CASES)
 def test_three_partial_products_would_be_caught(stats, case):
-    """The same criterion applied to VIVIT_GEMM_SPLIT=3 (hi hi + hi mid + mid hi only) fails by a wide margin."""
-    f32, b3 = stats[0][_key(case)], stats[3][_key(case)]
-    print(case, "fp32 MFMA:", f32["offdiag_rms"], "bf16 x 3:", b3["offdiag_rms"])
-    assert b3["offdiag_rms"] > 4.0 * f32["offdiag_rms"]
+    """The same criterion applied to VIVIT_GEMM_SPLIT=3 (hi hi + hi mid + mid hi only: every product off by 2^-16) FAILS:
+    the dropped partial products alone are ~4e-6 per term, 2.7 times the whole error of the fp32 MFMA kernel."""
+    f32, b3, b6 = stats[0][_key(case)], stats[3][_key(case)], stats[6][_key(case)]
+    print(case, "fp32 MFMA:", f32["offdiag_rms"], "bf16 x 3:", b3["offdiag_rms"], "bf16 x 6:", b6["offdiag_rms"])
+    assert b3["offdiag_rms"] > 2.0 * f32["offdiag_rms"]      # the criterion of test_default_path_is_fp32_class, violated
+    assert b3["offdiag_rms"] > 2.0 * b6["offdiag_rms"]
     assert b3["offdiag_rms"] > 3e-6
 
 
@@ -103,8 +107,9 @@ def test_input_range_contract(n, K):
     ri = torch.arange(0, n, 37, device=dev)
     ri = ri[clean[ri]]
     ref = A[ri].double() @ A[ri].double().T
-    err = (G[ri][:, ri].double() - ref).abs().max().item()
-    assert err <= 3e-6 * K ** 0.5, err   # unit-variance rows: 3e-6 per term of the random walk
+    d = ref.diagonal().sqrt()
+    err = ((G[ri][:, ri].double() - ref).abs() / (d[:, None] * d[None, :])).max().item()
+    assert err <= 5e-6, err   # relative to sqrt(G_ii G_jj), the scale of an entry's terms
     # inf row: +-inf with the sign of the partner's entry (inf * x + finite), NaN against the NaN row and against rows
     # that hold an exact zero in that column (inf * 0)
     row = G[7]

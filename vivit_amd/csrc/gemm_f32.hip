@@ -157,7 +157,10 @@ __device__ __forceinline__ bool map_tile(int syrk, int SBW, int tiles_m, int til
     I = (int)((sqrtf(8.f * (float)sb + 1.f) - 1.f) * 0.5f);
     while ((I + 1) * (I + 2) / 2 <= sb) ++I;
     while (I * (I + 1) / 2 > sb) --I;
-    J = sb - I * (I + 1) / 2;
+    // row I of the super-block triangle from its diagonal block leftwards: the LAST super-block of the grid is then an
+    // off-diagonal one (diagonal tiles flush their accumulators more often - bx_flush_tiles - and a slower tail block
+    // delayed every chunk launch of the Gram SYRK)
+    J = I - (sb - I * (I + 1) / 2);
   } else {
     const int sbn = (tiles_n + SBW - 1) / SBW;
     I = sb / sbn;
@@ -772,7 +775,7 @@ typedef const unsigned short __attribute__((address_space(1))) *gcptr16;
 constexpr int BX_PIECE = 8 * 1024;               // bytes of one piece of one operand tile (256 rows x 16 k bf16)
 constexpr int BX_OPER = 3 * BX_PIECE;            // 24 KB
 constexpr int BX_STAGE = 2 * BX_OPER;            // A and B: 48 KB
-constexpr int GEMM256BX_LDS_BYTES = 3 * BX_STAGE;  // three stages: 144 KB
+constexpr int GEMM256BX_LDS_BYTES = 3 * BX_STAGE + 4 * 4096;  // three stages (144 KB) + a 32 x 32 flush patch per wave = 160 KB
 
 __device__ __forceinline__ void bx_split2(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo) {
   const bf16x2 h = {(__bf16)a, (__bf16)b};
@@ -902,6 +905,9 @@ struct GemmBxArgs {
   int kt_split;
   const int *gate;               // range flag of this chunk (bx_split_kernel); the kernel returns when *gate & gate_mask
   int gate_mask;
+  // K tiles accumulated in one MFMA chain before the sum is added into C with a VALU add (see bx_flush_tiles);
+  // flush_diag: the same for the diagonal tiles of a SYRK (sums of squares: every product has the same sign)
+  int flush_tiles, flush_diag;
 };
 
 template <int NPROD>
@@ -935,7 +941,11 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   const int64_t ldc = p.kt_split > 0 ? p.N : p.ldc;
   const float alpha_ = p.kt_split > 0 ? 1.f : p.alpha, beta_ = p.kt_split > 0 ? 0.f : p.beta;
   const bool full_tile = row0 + B2 <= p.M && col0 + B2 <= p.N;
-  // C <- C' + alpha * acc with C' = beta * C on the first flush and C afterwards; acc <- final value
+  // C <- C' + alpha * acc with C' = beta * C on the first flush and C afterwards; acc <- final value.  The loads go to
+  // the L2 (sc1): earlier chains of this tile were added into C by L2 atomics (flush_atomic), which the L1 does not see.
+  auto ld_l2 = [](gptr q) __attribute__((always_inline)) -> float {
+    return __hip_atomic_load((const float *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   auto flush_to_c = [&](bool first) __attribute__((always_inline)) {
     const float beta = first ? beta_ : 1.f;
     int opaque = 0;
@@ -953,7 +963,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
           for (int j = 0; j < 4; ++j) {
             gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + r);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) old[j][e] = cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc];
+            for (int e = 0; e < 16; ++e) old[j][e] = ld_l2(cbase + (int64_t)((e & 3) + 8 * (e >> 2)) * ldc);
           }
         }
 #pragma unroll
@@ -977,7 +987,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
             float v = alpha_ * acc[i][j][e];
             if (row < p.M && col < p.N) {
               gptr c = Cout + row * ldc + col;
-              if (beta != 0.f) v += beta * *c;
+              if (beta != 0.f) v += beta * ld_l2(c);
               *c = v;
             }
             acc[i][j][e] = v;
@@ -993,6 +1003,90 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+
+  // The flush INSIDE the K loop (and the last one of a tile that is not mirrored): C <- C' + alpha * acc as above, but
+  // through a private 32 x 32 patch of LDS per wave that lies BEHIND the three operand stages, so it needs no barrier
+  // and the global -> LDS pipeline keeps running across it: restarting the pipeline per accumulation chain (barrier,
+  // first DMA round trip, fragment prologue) cost 34 us per chain, + 8.5 % at the headline shape for chains of 2048 k
+  // instead of 8192 even with the flush itself stubbed out.  An accumulator tile is written to the patch in MFMA layout
+  // and read back as float4 rows: C is read and written with 16-byte accesses (a wave may keep 63 memory instructions in
+  // flight: 4-byte accesses are 16 KB in flight, HBM latency-bound); the old values of the next three tiles are in
+  // flight while a tile is stored.
+  typedef f32x4 __attribute__((address_space(1))) *gptr4w;
+  const bool c_vec = (reinterpret_cast<uintptr_t>(Cout) & 15) == 0 && (ldc & 3) == 0;
+  auto flush_patch = [&](bool first) __attribute__((always_inline)) {
+    const float beta = first ? beta_ : 1.f;
+    float *ts = reinterpret_cast<float *>(smem_bx + 3 * BX_STAGE) + wave * 1024;
+    const int rr = lane >> 3, c4 = lane & 7;
+    int opaque = 0;
+    __asm__ volatile("" : "+v"(opaque));
+    const int64_t rbase = row0 + wm * 128 + rr + opaque, cbase = col0 + wn * 128 + 4 * c4;
+    gptr cwave = Cout + rbase * ldc + cbase;
+    const bool vec = full_tile && c_vec;
+    f32x4 oldv[4][4];   // ring over the tiles u = 4 i + j
+    auto ld_tile = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) oldv[u & 3][it] = *(gptr4w)(cwave + (int64_t)((u >> 2) * 32 + 8 * it) * ldc + (u & 3) * 32);
+    };
+#if defined(BX_VARIANT) && BX_VARIANT == 2   // timing only: no flush at all
+    return;
+#endif
+    const bool pre = vec && beta != 0.f;
+    if (pre) { ld_tile(0); ld_tile(1); ld_tile(2); }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (pre && u + 3 < 16) ld_tile(u + 3);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ts[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[u >> 2][u & 3][e];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(ts + (8 * it + rr) * 32 + 4 * c4);
+        v = alpha_ * v;
+        if (vec) {
+          if (beta != 0.f) v += beta * oldv[u & 3][it];
+          *(gptr4w)(cwave + (int64_t)((u >> 2) * 32 + 8 * it) * ldc + (u & 3) * 32) = v;
+        } else {   // edge tile or unaligned C: guarded elements
+          const int64_t row = rbase + (u >> 2) * 32 + 8 * it;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int64_t col = cbase + (u & 3) * 32 + k;
+            if (row < p.M && col < p.N) {
+              gptr c = Cout + row * ldc + col;
+              float x = v[k];
+              if (beta != 0.f) x += beta * *c;
+              *c = x;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // Every flush after the first of a full tile: C += alpha * acc with no-return fp32 atomics executed in the L2
+  // (global_atomic_add_f32: a correctly rounded fp32 add, exactly the VALU add of flush_patch).  This workgroup is the
+  // only writer of its tile and a wave's memory operations on one address stay in order, so the result is the same
+  // deterministic sum -- but nothing is loaded, nothing is waited for: the read-modify-write happens where the data
+  // lives while the next chain's MFMAs run.  (With the read-modify-write in the wave, the 63-instruction limit on
+  // memory operations in flight made a flush of the HBM-resident headline Gram matrix take 32 us per workgroup: + 10 %
+  // for chains of 2048 k.)
+  auto flush_atomic = [&]() __attribute__((always_inline)) {
+    int opaque = 0;
+    __asm__ volatile("" : "+v"(opaque));
+#if defined(BX_VARIANT) && BX_VARIANT == 2   // timing only: no flush at all
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gptr cb = Cout + (row0 + wm * 128 + i * 32 + 4 * h + opaque) * ldc + (col0 + wn * 128 + j * 32 + r);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          __builtin_amdgcn_global_atomic_fadd_f32(cb + (int64_t)((e & 3) + 8 * (e >> 2)) * ldc, alpha_ * acc[i][j][e]);
+      }
   };
 
   // ---- DMA sources: wave w fills blocks w and w + 4 of every piece of both operands (12 instructions per K tile),
@@ -1089,16 +1183,21 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   // waits for LDS.  In the middle of tile t every wave waits for its own share of tile t + 1 (requested one tile ago);
   // the barrier there publishes tile t + 1 and certifies that every wave is completely past tile t - 1, whose stage then
   // receives the requests for tile t + 2.
-  auto chunk = [&](int t0, int t1) __attribute__((always_inline)) {
-    __syncthreads();  // every wave is done with the LDS stages of the previous chunk
+  // One pipelined pass over all K tiles.  Every `flush_tiles` tiles (rounded to the two-tile trip) an MFMA chain ends:
+  // its sum goes into C (flush_patch) and the accumulators restart from zero -- see bx_flush_tiles for why chains are short.
+  bool first_flush = true;
+  const int flush_tiles = (((p.syrk != 0 && ti == tj) ? p.flush_diag : p.flush_tiles) + 1) & ~1;
+  const bool mirrored = p.syrk == 1 && ti != tj;   // the mirror store wants the final values in the accumulators
+  {
+    const int t1 = nt;
     issue(0);
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __asm__ volatile("s_barrier" ::: "memory");
-    if (t0 + 1 < t1) issue(1);
+    if (1 < t1) issue(1);
     // two named fragment sets in ping-pong (tile t uses one and fills the other for tile t + 1)
     FragB fbX = load_b(0), fbY;
     FragA faX = load_a(0, 0), faY;
-    int st = 0, t = t0;
+    int st = 0, t = 0, next_flush = flush_tiles;
     auto tile = [&](const FragB &fb, const FragA &fa, FragB &fbn, FragA &fan) __attribute__((always_inline)) {
       const int st1 = st == 2 ? 0 : st + 1, st2 = st == 0 ? 2 : st - 1;   // stages of tiles t + 1 and t + 2 (= t - 1)
       const int stn = t + 1 < t1 ? st1 : st;                              // (last tile: harmless re-read of its own stage)
@@ -1132,20 +1231,41 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       st = st1;
       ++t;
     };
-    while (t + 2 <= t1) {  // two tiles per trip, no exit in between (the sets swap roles and are back in place)
-      tile(fbX, faX, fbY, faY);
-      tile(fbY, faY, fbX, faX);
+    // (the flush sits BETWEEN two clean inner loops: as a conditional block inside the trip hipcc hoisted its 164
+    // accumulator reads and 25 spills above the branch, into every trip)
+    while (true) {
+      const int tc = next_flush < t1 ? next_flush : t1;
+      while (t + 2 <= tc) {  // two tiles per trip, no exit in between (the sets swap roles and are back in place)
+        tile(fbX, faX, fbY, faY);
+        tile(fbY, faY, fbX, faX);
+      }
+      if (t + 2 > t1) break;  // at most one tile left: it joins this chain
+      // end of a chain (its memory operations drain behind the next tile's MFMAs)
+#if defined(BX_NO_ATOMIC)   // experiment: read-modify-write in the wave for every flush
+      flush_patch(first_flush);
+#else
+      if (first_flush || !full_tile)
+        flush_patch(first_flush);
+      else
+        flush_atomic();
+#endif
+      first_flush = false;
+      clear_acc();
+      next_flush += flush_tiles;
     }
     if (t < t1) tile(fbX, faX, fbY, faY);
-  };
-  bool first_flush = true;
-  for (int t0 = 0; t0 < nt; t0 += FLUSH2_TILES) {
-    const int t1 = t0 + FLUSH2_TILES < nt ? t0 + FLUSH2_TILES : nt;
-    if (t0 > 0) clear_acc();
-    chunk(t0, t1);
-    flush_to_c(first_flush);
-    first_flush = false;
   }
+  if (mirrored || !full_tile)
+    flush_to_c(first_flush);
+#if defined(BX_NO_ATOMIC)
+  else
+    flush_patch(first_flush);
+#else
+  else if (first_flush)
+    flush_patch(true);
+  else
+    flush_atomic();
+#endif
 
   if (p.syrk == 1 && ti != tj) {
     __syncthreads();
@@ -1643,6 +1763,31 @@ static int gemm_split_mode() {
   return mode;
 }
 
+// Length of one MFMA accumulation chain of the bf16-pipe kernel, in K tiles.  v_mfma_f32_32x32x16_bf16 is NOT a chain
+// of correctly rounded fmas: it adds the accumulator and two 8-product group sums after aligning them to the largest
+// exponent with about one guard bit, and what is shifted out is TRUNCATED (scripts/probe/mfma_round.hip: c = 1 plus
+// sixteen products of 3/64 ulp returns 1; one product of 0.51 ulp rounds up correctly).  Once the accumulator is more
+// than ~2^6 times a group sum (chains beyond ~512 k) the low bits of every group sum are cut off towards zero: noise of
+// twice the fp32 chain's rounding for sums of random signs, and a BIAS for sums of equal signs -- the diagonal of a Gram
+// matrix, entries of correlated rows.  Measured on n = 5120, K = 401 408 (independent N(0,1) rows), chain length ->
+// off-diagonal error per term of the random walk / mean relative error of the diagonal:
+//     8192 -> 3.2e-6 / -2.5e-6     4096 -> 2.3e-6 / -2.0e-6     2048 -> 1.7e-6 / -1.3e-6     1024 -> 1.2e-6 / -5.5e-7
+//      512 -> 9.8e-7 / -6e-8       fp32 MFMA kernel (chains of 8192, correctly rounded): 1.6e-6 / -3.2e-7
+// and what a shorter chain costs at the headline shape (n = 40 960: C is 6.7 GB, every flush is HBM traffic that
+// competes with the operand panels for the L2 / Infinity Cache): 8192 -> 4096: + 2 %, -> 2048: + 6 %, -> 1024: + 10 %;
+// diagonal tiles at 512: + 1-2 % (1 % of the tiles).  Default: 4096 k (1.4 x the fp32 MFMA kernel's random-sign error),
+// 512 k on the diagonal tiles of a SYRK (no bias where every term has the same sign), 1024 k in the split-K form for
+// small outputs (whose yardstick is the 128-tile fp32 kernel with its chains of 2048).
+// VIVIT_BX_FLUSH / VIVIT_BX_FLUSH_DIAG / VIVIT_BX_FLUSH_SPLITK override (in k).
+static int bx_env_tiles(const char *name, int dflt_k) {
+  const char *e = getenv(name);
+  int ft = (e ? atoi(e) : dflt_k) / BK;
+  return ft < 1 ? 1 : ft;
+}
+static int bx_flush_tiles() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH", 4096); return ft; }
+static int bx_flush_diag() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_DIAG", 512); return ft; }
+static int bx_flush_splitk() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_SPLITK", 1024); return ft; }
+
 // columns of an operand split at a time (workspace: 6 bytes per element of the chunk and operand)
 static int64_t bx_chunk_cols(int64_t K) {
   static int64_t kc = -1;
@@ -1745,6 +1890,8 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
     q.tiles_m = p.tiles_m; q.tiles_n = p.tiles_n; q.syrk = p.syrk; q.sbw = p.sbw;
     q.slab = nullptr; q.kt_split = 0;
     q.gate_mask = tls_bx_gate_mask;
+    q.flush_tiles = bx_flush_tiles();
+    q.flush_diag = bx_flush_diag();
     int st = VIVIT_OK;
     int64_t chunk = 0;
     for (int64_t k0 = 0; k0 < p.K && st == VIVIT_OK; k0 += kc_max, ++chunk) {
@@ -1885,6 +2032,8 @@ static int bx_splitk_launch(int alay, int blay, const GemmArgs &p, bool syrk, vo
   q.sbw = sbw;
   q.slab = slab; q.kt_split = kts;
   q.gate = flag; q.gate_mask = tls_bx_gate_mask;
+  q.flush_tiles = bx_flush_splitk();
+  q.flush_diag = bx_flush_diag();
   const int64_t sbm = cdiv(q.tiles_m, sbh), sbn = cdiv(q.tiles_n, sbw);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
   const dim3 grid((unsigned)(nsb * 256), (unsigned)nsplit);

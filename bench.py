@@ -407,7 +407,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the parity check after the timed loop")
     ap.add_argument("--no-secondary", action="store_true", help="skip the values-only / top-10 secondary lines")
     ap.add_argument("--cpu-batches", default="128,256", help="batch sizes of the CPU baseline's einsum-Gram sample")
-    ap.add_argument("--cpu-eig-batches", default="256,512", help="batch sizes of the CPU baseline's eigh sample")
+    ap.add_argument("--cpu-eig-batches", default="512,1024", help="batch sizes of the CPU baseline's eigh sample (n = 10 x batch)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (configs block)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -754,6 +755,14 @@ def main():
             out["verified"] = verified
         if secondary_lines is not None:
             out["secondary"] = secondary_lines
+        if world == 1 and not args.no_configs:
+            # BASELINE configs 1, 3, 4, 5 (one GPU) through the public API on real factors (bench_configs.py)
+            import bench_configs
+
+            del facs[:]
+            G = w = Z = None
+            torch.cuda.empty_cache()
+            out["configs"] = bench_configs.run_configs(device, progress=_progress)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, C, n, P_total, batches=tuple(min(int(b), batch) for b in args.cpu_batches.split(",")),
                                                eig_batches=tuple(min(int(b), batch) for b in args.cpu_eig_batches.split(",")))

@@ -159,36 +159,7 @@ def set_kernel_backend(backend):
 
 
 def resnet32(num_classes=100):
-    """CIFAR ResNet-32 (3 stages x 5 basic blocks, 16/32/64 channels, option-A shortcuts: stride-2 sub-sampling and
-    zero-padded channels), written with the branching modules so that every operation is a leaf module.
-    470 004 parameters for 100 classes (BASELINE config 4)."""
-    from torch import nn
+    """CIFAR ResNet-32 of BASELINE config 4 (defined next to the benchmark that times it)."""
+    import bench_configs
 
-    from vivit_amd.backend import ActiveIdentity, Pad, Parallel, Slicing
-
-    def block(cin, cout, stride):
-        body = nn.Sequential(
-            nn.Conv2d(cin, cout, 3, stride=stride, padding=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(),
-            nn.Conv2d(cout, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout))
-        if stride == 1 and cin == cout:
-            shortcut = ActiveIdentity()
-        else:
-            pad = (cout - cin) // 2
-            shortcut = nn.Sequential(Slicing((slice(None), slice(None), slice(None, None, 2), slice(None, None, 2))),
-                                     Pad((0, 0, 0, 0, pad, pad)))
-        return nn.Sequential(Parallel(shortcut, body), nn.ReLU())
-
-    layers = [nn.Conv2d(3, 16, 3, padding=1, bias=False), nn.BatchNorm2d(16), nn.ReLU()]
-    cin = 16
-    for cout, stride in ((16, 1), (32, 2), (64, 2)):
-        for b in range(5):
-            layers.append(block(cin, cout, stride if b == 0 else 1))
-            cin = cout
-    layers += [nn.AvgPool2d(8), nn.Flatten(), nn.Linear(64, num_classes)]
-    model = nn.Sequential(*layers)
-    g = torch.Generator().manual_seed(0)
-    for m in model.modules():  # non-trivial running statistics (eval mode, as in the reference tests)
-        if isinstance(m, nn.BatchNorm2d):
-            m.running_mean.copy_(torch.rand(m.num_features, generator=g) - 0.5)
-            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
-    return model.eval()
+    return bench_configs.resnet32(num_classes)

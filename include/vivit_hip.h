@@ -37,7 +37,7 @@ extern "C" {
 #define VIVIT_E_UNSUPPORTED (-4)
 
 /* Library/ABI version (major*1000 + minor) and the gfx target it was compiled for. */
-int vivit_hip_abi_version(void);   /* 1003 in this release; _lib.py refuses an older library */
+int vivit_hip_abi_version(void);   /* 1004 in this release; _lib.py refuses an older library */
 const char *vivit_hip_target(void);
 const char *vivit_hip_status_string(int status);
 
@@ -146,6 +146,44 @@ int vivit_linear_weight_mjp_f32(const float *s, const float *z, float *V, int64_
 int vivit_conv2d_weight_mjp_f32(const float *M, const float *x, float *V, int64_t rows, int64_t N, int64_t Cin, int64_t H,
                                 int64_t W, int64_t Cout, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int64_t sh,
                                 int64_t sw, int64_t ph, int64_t pw, int64_t dh, int64_t dw, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f1  Back-propagation of the sqrt-GGN factor through the layers (jacobians.hip): the transposed input-Jacobian products
+ *   M [V, N, *out] -> [V, N, *in]  that BackPACK's derivative classes supply to the reference through `MatToJacMat`
+ *   (vivit/extensions/secondorder/vivit/__init__.py:84-118, base.py:19,41), the loss-Hessian square roots that seed it
+ *   (SqrtGGNCrossEntropyLoss, __init__.py:84-86) and the reductions of the bias / BatchNorm parameter rules
+ *   (base.py:84-92 -> param_mjp).  All tensors contiguous fp32, `V` slices outermost.
+ * ------------------------------------------------------------------------------------------- */
+/* out[v, e] = M[v, e] * f'(x[e]), e < per_v (= N * features).  kind: 0 ReLU, 1 Sigmoid, 2 Tanh, 3 LeakyReLU (param =
+ * negative slope), 4 LogSigmoid, 5 ELU (param = alpha), 6 SELU.  Replaces SqrtGGN{ReLU,Sigmoid,Tanh,LeakyReLU,LogSigmoid,
+ * ELU,SELU} (__init__.py:87-93). */
+int vivit_act_jac_t_f32(const float *M, const float *x, float *out, int64_t V, int64_t per_v, int kind, float param,
+                        void *stream);
+/* out[r, c, l] = M[r, c, l] * scale[c]: BatchNorm in eval mode, scale = weight / sqrt(running_var + eps)
+ * (vivit/extensions/secondorder/vivit/batchnormnd.py:8-13 -> BatchNormNdDerivatives). */
+int vivit_channel_scale_f32(const float *M, const float *scale, float *out, int64_t rows, int64_t C, int64_t L, void *stream);
+/* MaxPool2d / AvgPool2d (SqrtGGNMaxPool2d / SqrtGGNAvgPool2d, __init__.py:97-102): planes = N * C of the layer input
+ * x [planes, H, W]; M [V * planes, OH, OW] -> out [V * planes, H, W].  idx_ws: planes * OH * OW ints of scratch (the
+ * arg-max of every window: first maximum in scan order, as torch).  No ceil_mode, no dilation; average pooling counts
+ * the padding (count_include_pad). */
+int vivit_maxpool2d_jac_t_f32(const float *M, const float *x, float *out, int *idx_ws, int64_t V, int64_t planes, int64_t H,
+                              int64_t W, int64_t OH, int64_t OW, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph,
+                              int64_t pw, void *stream);
+int vivit_avgpool2d_jac_t_f32(const float *M, float *out, int64_t rows_planes, int64_t H, int64_t W, int64_t OH, int64_t OW,
+                              int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, void *stream);
+/* Conv2d (groups = 1, zero padding): out[r, ci, h, w] = sum_{co, a, b} M[r, co, oh, ow] weight[co, ci, a, b] with
+ * oh sh - ph + a dh = h, ow sw - pw + b dw = w  (the transposed convolution; base.py:19 with Conv2DDerivatives,
+ * convnd.py:17-22).  rows = V * N. */
+int vivit_conv2d_jac_t_f32(const float *M, const float *weight, float *out, int64_t rows, int64_t Cin, int64_t H, int64_t W,
+                           int64_t Cout, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int64_t sh, int64_t sw, int64_t ph,
+                           int64_t pw, int64_t dh, int64_t dw, void *stream);
+/* out[r] = sum_l M[r, l] * (X ? X[r % rows_x, l] : 1): bias rules (sum over the spatial positions) and the BatchNorm
+ * weight rule (X = normalised input of the rows_x = N * C planes, shared by the V slices). */
+int vivit_row_dot_f32(const float *M, const float *X, float *out, int64_t rows, int64_t rows_x, int64_t L, void *stream);
+/* Cross-entropy loss-Hessian square root from the logits [N, C]: p = softmax.  onehot == NULL (exact, V must equal C):
+ * S[v, n, c] = sqrt(p_nv) (delta_vc - p_nc) scale;  onehot [V, N, C] (sampled): S[v, n, c] = (p_nc - onehot[v, n, c]) scale. */
+int vivit_ce_sqrt_hessian_f32(const float *logits, const float *onehot, float *S, int64_t N, int64_t C, int64_t V, float scale,
+                              void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3/K4  Symmetric eigendecomposition (Householder tridiagonalisation + implicit-shift QL,

@@ -34,6 +34,13 @@ SIGNATURES = {
     "vivit_class_expand_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
     "vivit_linear_weight_mjp_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
     "vivit_conv2d_weight_mjp_f32": (_int, [_ptr, _ptr, _ptr] + [_i64] * 16 + [_ptr]),
+    "vivit_act_jac_t_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _int, _f32, _ptr]),
+    "vivit_channel_scale_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr]),
+    "vivit_maxpool2d_jac_t_f32": (_int, [_ptr, _ptr, _ptr, _ptr] + [_i64] * 12 + [_ptr]),
+    "vivit_avgpool2d_jac_t_f32": (_int, [_ptr, _ptr] + [_i64] * 11 + [_ptr]),
+    "vivit_conv2d_jac_t_f32": (_int, [_ptr, _ptr, _ptr] + [_i64] * 15 + [_ptr]),
+    "vivit_row_dot_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr]),
+    "vivit_ce_sqrt_hessian_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr]),
     "vivit_symeig_f32_workspace_bytes": (_sz, [_i64, _int]),
     "vivit_symeig_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
     "vivit_symeig_rows_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr, _sz, _ptr, _ptr]),
@@ -61,7 +68,7 @@ SIGNATURES = {
     "vivit_symmetrize_lower_f32": (_int, [_ptr, _i64, _i64, _ptr]),
 }
 
-ABI_VERSION = 1003  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
+ABI_VERSION = 1004  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
 
 _lib = None
 

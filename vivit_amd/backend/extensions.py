@@ -83,8 +83,13 @@ def _own_params(module):
 
 
 def _spatial_sum(t: Tensor, keep: int) -> Tensor:
-    """Sum all dims after the first ``keep`` ones."""
-    return t.flatten(start_dim=keep).sum(keep) if t.dim() > keep else t
+    """Sum all dims after the first ``keep`` ones (HIP: one wave per row, fixed order)."""
+    if t.dim() <= keep:
+        return t
+    if t.is_cuda:
+        lead = t.shape[:keep]
+        return kernels.row_dot(t.reshape(-1, t[(0,) * keep].numel())).view(lead)
+    return t.flatten(start_dim=keep).sum(keep)
 
 
 def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
@@ -97,7 +102,7 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
         return torch.einsum("vnao,nai->vnoi", M.flatten(2, -2), x.flatten(1, -2))
     if isinstance(module, _CONVS):
         if name == "bias":
-            return M.flatten(3).sum(3)
+            return _spatial_sum(M, 3)
         if (isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple)
                 and module.padding_mode == "zeros" and module.out_channels * 129 * 4 <= 64 * 1024):
             # unfold + "vnol,nkl->vnok" in one HIP kernel (patch values gathered on the fly, no im2col buffer)
@@ -108,8 +113,14 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
             raise NotImplementedError("BatchNorm must be in eval mode (as in the reference tests)")
         if name == "bias":
             return _spatial_sum(M, 3)
+        rstd = torch.rsqrt(module.running_var + module.eps)
+        if M.is_cuda:
+            # sum_l M xhat = (sum_l M x - mean_c sum_l M) rstd_c: two row reductions on HIP, the rest is [V, N, C]-sized
+            L = x[0, 0].numel()
+            Mx = kernels.row_dot(M.reshape(-1, L), x.reshape(-1, L), rows_x=x.shape[0] * x.shape[1]).view(M.shape[:3])
+            return (Mx - module.running_mean * _spatial_sum(M, 3)) * rstd
         shape = [1, -1] + [1] * (x.dim() - 2)
-        xhat = (x - module.running_mean.view(shape)) / torch.sqrt(module.running_var.view(shape) + module.eps)
+        xhat = (x - module.running_mean.view(shape)) * rstd.view(shape)
         return _spatial_sum(M * xhat.unsqueeze(0), 3)
     raise NotImplementedError(f"no parameter rule for {type(module).__name__}")
 
@@ -139,6 +150,44 @@ def _conv_weight_factor(module, M: Tensor, x: Tensor) -> Tensor:
     return vmap(vmap(single, in_dims=(0, 0)), in_dims=(None, 0))(x, M)
 
 
+_ACTIVATIONS = {nn.ReLU: ("relu", None), nn.Sigmoid: ("sigmoid", None), nn.Tanh: ("tanh", None),
+                nn.LeakyReLU: ("leaky_relu", "negative_slope"), nn.LogSigmoid: ("logsigmoid", None), nn.ELU: ("elu", "alpha"),
+                nn.SELU: ("selu", None)}
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
+    """The layer rules that have a HIP kernel (csrc/jacobians.hip): activations, Flatten / Identity / Dropout(eval),
+    Max/AvgPool2d, Conv2d (groups = 1, zero padding), BatchNorm (eval).  ``None``: no kernel for this module
+    (Conv1d/3d, transposed and grouped convolutions, custom index modules) -- the generic autograd rule takes over."""
+    kind = _ACTIVATIONS.get(type(module))
+    if kind is not None:
+        return kernels.act_jac_t(M, x, kind[0], getattr(module, kind[1]) if kind[1] else 0.0)
+    if isinstance(module, (nn.Flatten, nn.Identity, nn.Dropout)):
+        return M.reshape(M.shape[0], *x.shape)
+    if isinstance(module, nn.MaxPool2d) and x.dim() == 4:
+        if _pair(module.dilation) == (1, 1) and not module.ceil_mode and not module.return_indices:
+            ks = _pair(module.kernel_size)
+            return kernels.maxpool2d_jac_t(M, x, ks, _pair(module.stride if module.stride is not None else ks), _pair(module.padding))
+    if isinstance(module, nn.AvgPool2d) and x.dim() == 4:
+        if not module.ceil_mode and module.count_include_pad and module.divisor_override is None:
+            ks = _pair(module.kernel_size)
+            return kernels.avgpool2d_jac_t(M, x.shape[2:], ks, _pair(module.stride if module.stride is not None else ks),
+                                           _pair(module.padding))
+    if (isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple)
+            and module.padding_mode == "zeros" and module.out_channels * module.kernel_size[0] * module.kernel_size[1] <= 1024):
+        return kernels.conv2d_jac_t(M, module.weight.detach(), x.shape[2:], module.stride, module.padding, module.dilation)
+    if isinstance(module, _BATCHNORM) and x.dim() >= 2:
+        scale = torch.rsqrt(module.running_var + module.eps)
+        if module.weight is not None:
+            scale = scale * module.weight.detach()
+        return kernels.channel_scale(M if M.dim() > 3 else M.unsqueeze(-1), scale).view(M.shape)
+    return None
+
+
 def _jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Tensor:
     """Apply the transposed input-Jacobian of ``module`` to ``M`` [V, N, *out] -> [V, N, *in]."""
     if isinstance(module, nn.Linear) and M.dim() == 3:
@@ -150,6 +199,10 @@ def _jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Tensor:
         raise NotImplementedError("Dropout must be in eval mode")
     if isinstance(module, _BATCHNORM) and module.training:
         raise NotImplementedError("BatchNorm must be in eval mode")
+    if M.is_cuda and M.dtype == torch.float32:
+        g = _hip_jac_t_mat_prod(module, M, x)
+        if g is not None:
+            return g
     # generic rule: batched vector-Jacobian product through a recomputed forward (bypasses hooks)
     with torch.enable_grad():
         xi = x.detach().requires_grad_(True)
@@ -192,6 +245,15 @@ def _loss_hessian_sqrt(module, strategy: str, mc_samples: int, samples: Optional
     red = module.reduction
     if red not in ("mean", "sum"):
         raise NotImplementedError(f"reduction={red}")
+    if isinstance(module, nn.CrossEntropyLoss) and out.is_cuda and out.dtype == torch.float32 and C * 4 <= 60 * 1024:
+        norm = N if red == "mean" else 1
+        if strategy == "exact":
+            return kernels.ce_sqrt_hessian(out, 1.0 / math.sqrt(norm))     # softmax + sqrt(p_v)(delta_vc - p_c) in one kernel
+        if samples is None:
+            idx = torch.multinomial(out.softmax(dim=1), mc_samples, replacement=True)  # [N, M]
+            samples = F.one_hot(idx.t(), C).to(out.dtype)  # [M, N, C]
+        samples = samples.to(out.device, out.dtype)
+        return kernels.ce_sqrt_hessian(out, 1.0 / math.sqrt(samples.shape[0] * norm), onehot=samples)
     if isinstance(module, nn.CrossEntropyLoss):
         p = out.softmax(dim=1)
         norm = N if red == "mean" else 1

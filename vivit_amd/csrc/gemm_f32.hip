@@ -910,6 +910,14 @@ struct GemmBxArgs {
   int flush_tiles, flush_diag;
 };
 
+#if defined(BX_STAMP)
+// Diagnostic build only (scripts/probe/bx_clock.py; never in the product library): every workgroup stamps s_memtime (core
+// clock) and s_memrealtime (100 MHz) around its K loop into a buffer of its own -- the in-kernel clock the chip holds
+// under this kernel's load is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, "DVFS give-back" item 6).
+__device__ unsigned long long *g_bx_stamp = nullptr;
+__device__ unsigned int g_bx_stamp_cap = 0;
+#endif
+
 template <int NPROD>
 __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
@@ -1185,6 +1193,9 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   // receives the requests for tile t + 2.
   // One pipelined pass over all K tiles.  Every `flush_tiles` tiles (rounded to the two-tile trip) an MFMA chain ends:
   // its sum goes into C (flush_patch) and the accumulators restart from zero -- see bx_flush_tiles for why chains are short.
+#if defined(BX_STAMP)
+  const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   bool first_flush = true;
   const int flush_tiles = (((p.syrk != 0 && ti == tj) ? p.flush_diag : p.flush_tiles) + 1) & ~1;
   const bool mirrored = p.syrk == 1 && ti != tj;   // the mirror store wants the final values in the accumulators
@@ -1255,6 +1266,12 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     }
     if (t < t1) tile(fbX, faX, fbY, faY);
   }
+#if defined(BX_STAMP)
+  if (tid == 0 && g_bx_stamp && blockIdx.y == 0 && blockIdx.x < g_bx_stamp_cap) {
+    g_bx_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c0;
+    g_bx_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+  }
+#endif
   if (mirrored || !full_tile)
     flush_to_c(first_flush);
 #if defined(BX_NO_ATOMIC)
@@ -2306,6 +2323,15 @@ int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int
 using namespace vivit;
 
 extern "C" {
+
+#if defined(BX_STAMP)
+int vivit_debug_bx_stamp_buffer(void *buf, unsigned int capacity) {
+  unsigned long long *b = static_cast<unsigned long long *>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_bx_stamp), &b, sizeof(b)) != hipSuccess) return VIVIT_E_LAUNCH;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_bx_stamp_cap), &capacity, sizeof(capacity)) != hipSuccess) return VIVIT_E_LAUNCH;
+  return VIVIT_OK;
+}
+#endif
 
 int vivit_gemm_split_mode(void) { return gemm_split_mode(); }
 

@@ -1,0 +1,323 @@
+// Back-propagation of the sqrt-GGN factor through parameter-free layers and convolutions: the transposed
+// input-Jacobian products  M [V, N, *out] -> [V, N, *in]  that BackPACK's derivative classes provide to the reference
+// through `MatToJacMat` (vivit/extensions/secondorder/vivit/__init__.py:84-118: SqrtGGN{ReLU, Sigmoid, Tanh, ...},
+// SqrtGGN{Max,Avg}Pool2d, base.py:19,41 for Conv2d / BatchNorm), the loss-Hessian square roots that seed the
+// back-propagation (SqrtGGN{CrossEntropyLoss, MSELoss}, __init__.py:84-86) and the reductions of the parameter rules of
+// biases and BatchNorm.  Everything here is bandwidth-bound elementwise / gather work (coalesced along the innermost
+// spatial dimension, one pass over M), except the Conv2d rule which is a direct transposed convolution with the
+// filter slice in LDS and 16 input channels per thread in registers.
+#include "common.h"
+
+namespace vivit {
+
+// ---- elementwise activations: out[v, n, e] = M[v, n, e] * f'(x[n, e]) ----------------------------------------------
+enum { ACT_RELU = 0, ACT_SIGMOID = 1, ACT_TANH = 2, ACT_LEAKY_RELU = 3, ACT_LOGSIGMOID = 4, ACT_ELU = 5, ACT_SELU = 6 };
+
+__device__ __forceinline__ float act_derivative(int kind, float x, float a) {
+  switch (kind) {
+    case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-x)); return s * (1.f - s); }
+    case ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
+    case ACT_LEAKY_RELU: return x > 0.f ? 1.f : a;
+    case ACT_LOGSIGMOID: return 1.f / (1.f + expf(x));
+    case ACT_ELU: return x > 0.f ? 1.f : a * expf(x);
+    default: {  // SELU
+      const float scale = 1.0507009873554804934193349852946f, alpha = 1.6732632423543772848170429916717f;
+      return x > 0.f ? scale : scale * alpha * expf(x);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void act_jac_t_kernel(const float *__restrict__ M, const float *__restrict__ x,
+                                                        float *__restrict__ out, int64_t total, int64_t per_v, int kind, float a) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    out[i] = M[i] * act_derivative(kind, x[i % per_v], a);
+}
+
+// ---- per-channel scale (BatchNorm in eval mode): out[r, c, l] = M[r, c, l] * scale[c] -------------------------------
+__global__ __launch_bounds__(256) void channel_scale_kernel(const float *__restrict__ M, const float *__restrict__ scale,
+                                                            float *__restrict__ out, int64_t total, int64_t C, int64_t L) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    out[i] = M[i] * scale[(i / L) % C];
+}
+
+// ---- pooling ---------------------------------------------------------------------------------------------------------
+struct PoolGeom {
+  int H, W, OH, OW, kh, kw, sh, sw, ph, pw;
+};
+
+// argmax of every pooling window (first maximum in row-major scan order, as torch's max_pool2d): idx[(n,c), oh, ow]
+__global__ __launch_bounds__(256) void maxpool_argmax_kernel(const float *__restrict__ x, int *__restrict__ idx, int64_t planes,
+                                                             PoolGeom g) {
+  const int64_t total = planes * g.OH * g.OW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t pl = i / (g.OH * g.OW);
+    const int o = (int)(i - pl * (g.OH * g.OW)), oh = o / g.OW, ow = o - oh * g.OW;
+    const float *xp = x + pl * (int64_t)g.H * g.W;
+    float best = -INFINITY;
+    int bi = -1;
+    for (int a = 0; a < g.kh; ++a) {
+      const int h = oh * g.sh - g.ph + a;
+      if (h < 0 || h >= g.H) continue;
+      for (int b = 0; b < g.kw; ++b) {
+        const int w = ow * g.sw - g.pw + b;
+        if (w < 0 || w >= g.W) continue;
+        const float v = xp[h * g.W + w];
+        if (bi < 0 || v > best || (v != v && best == best)) {   // first maximum wins; a NaN wins and stays (torch)
+          best = v;
+          bi = h * g.W + w;
+        }
+      }
+    }
+    idx[i] = bi;
+  }
+}
+
+// out[r, c, h, w] = sum over the windows that contain (h, w) of  M[r, c, oh, ow] * weight,
+//   weight = [idx[n, c, oh, ow] == h W + w]  (max pooling)   or   1 / (kh kw)  (average pooling, count_include_pad)
+template <bool MAX>
+__global__ __launch_bounds__(256) void pool_jac_t_kernel(const float *__restrict__ M, const int *__restrict__ idx,
+                                                         float *__restrict__ out, int64_t rows_planes, int64_t planes_per_v,
+                                                         PoolGeom g, float inv_area) {
+  const int64_t total = rows_planes * g.H * g.W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t pl = i / (g.H * g.W);
+    const int hw = (int)(i - pl * (g.H * g.W)), h = hw / g.W, w = hw - h * g.W;
+    const float *Mp = M + pl * (int64_t)g.OH * g.OW;
+    const int *ip = MAX ? idx + (pl % planes_per_v) * (int64_t)g.OH * g.OW : nullptr;
+    // windows containing h: oh sh - ph <= h < oh sh - ph + kh
+    int oh_lo = (h + g.ph - g.kh + g.sh) / g.sh, oh_hi = (h + g.ph) / g.sh;
+    int ow_lo = (w + g.pw - g.kw + g.sw) / g.sw, ow_hi = (w + g.pw) / g.sw;
+    if (h + g.ph - g.kh + 1 <= 0) oh_lo = 0;
+    if (w + g.pw - g.kw + 1 <= 0) ow_lo = 0;
+    if (oh_hi > g.OH - 1) oh_hi = g.OH - 1;
+    if (ow_hi > g.OW - 1) ow_hi = g.OW - 1;
+    float acc = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const float m = Mp[oh * g.OW + ow];
+        if (MAX) acc += ip[oh * g.OW + ow] == hw ? m : 0.f;
+        else acc += m;
+      }
+    out[i] = MAX ? acc : acc * inv_area;
+  }
+}
+
+// ---- Conv2d input rule (groups = 1, zero padding): transposed convolution ------------------------------------------
+//   out[r, ci, h, w] = sum_{co, a, b} M[r, co, oh, ow] * Wt[co, ci, a, b],   oh sh - ph + a dh = h,  ow sw - pw + b dw = w
+// grid.x: tiles of 256 input positions (h, w) of one row r = (v, n); grid.y: groups of CIT input channels; the filter
+// slice [Cout][CIT][KH KW] sits in LDS (read as broadcasts), a thread keeps CIT accumulators and reads every M value it
+// needs once (neighbouring threads share them through L1).
+constexpr int CIT = 16;
+struct ConvGeom {
+  int Cin, H, W, Cout, KH, KW, OH, OW, sh, sw, ph, pw, dh, dw;
+};
+__global__ __launch_bounds__(256) void conv2d_jac_t_kernel(const float *__restrict__ M, const float *__restrict__ Wt,
+                                                           float *__restrict__ out, ConvGeom g) {
+  extern __shared__ float sW[];  // [Cout][KH*KW][CIT]
+  const int KK = g.KH * g.KW;
+  const int ci0 = blockIdx.y * CIT;
+  const int nci = (g.Cin - ci0) < CIT ? (g.Cin - ci0) : CIT;
+  for (int i = threadIdx.x; i < g.Cout * KK * CIT; i += 256) {
+    const int c = i % CIT, k = (i / CIT) % KK, co = i / (CIT * KK);
+    sW[i] = c < nci ? Wt[((int64_t)co * g.Cin + ci0 + c) * KK + k] : 0.f;
+  }
+  __syncthreads();
+  const int HW = g.H * g.W, L = g.OH * g.OW;
+  const int tiles = (HW + 255) / 256;
+  const int64_t r = blockIdx.x / tiles;
+  const int hw = (int)(blockIdx.x % tiles) * 256 + threadIdx.x;
+  if (hw >= HW) return;
+  const int h = hw / g.W, w = hw - h * g.W;
+  float acc[CIT];
+#pragma unroll
+  for (int c = 0; c < CIT; ++c) acc[c] = 0.f;
+  const float *Mr = M + r * (int64_t)g.Cout * L;
+  for (int a = 0; a < g.KH; ++a) {
+    const int th = h + g.ph - a * g.dh;
+    if (th < 0 || th % g.sh != 0) continue;
+    const int oh = th / g.sh;
+    if (oh >= g.OH) continue;
+    for (int b = 0; b < g.KW; ++b) {
+      const int tw = w + g.pw - b * g.dw;
+      if (tw < 0 || tw % g.sw != 0) continue;
+      const int ow = tw / g.sw;
+      if (ow >= g.OW) continue;
+      const float *mp = Mr + oh * g.OW + ow;
+      const float *wp = sW + (a * g.KW + b) * CIT;
+      for (int co = 0; co < g.Cout; ++co) {
+        const float m = mp[(int64_t)co * L];
+        const float4 *w4 = reinterpret_cast<const float4 *>(wp + co * KK * CIT);
+#pragma unroll
+        for (int q = 0; q < CIT / 4; ++q) {
+          const float4 ww = w4[q];
+          acc[4 * q] += m * ww.x; acc[4 * q + 1] += m * ww.y; acc[4 * q + 2] += m * ww.z; acc[4 * q + 3] += m * ww.w;
+        }
+      }
+    }
+  }
+  float *op = out + (r * g.Cin + ci0) * (int64_t)HW + hw;
+#pragma unroll
+  for (int c = 0; c < CIT; ++c)
+    if (c < nci) op[(int64_t)c * HW] = acc[c];
+}
+
+// ---- reductions of the parameter rules --------------------------------------------------------------------------------
+// out[r] = sum_l M[r, l] * (X ? X[(r % rows_x), l] : 1): bias of a convolution / BatchNorm (X = null), BatchNorm weight
+// (X = normalised input, shared by the V slices).  One wave per row, fixed summation order.
+__global__ __launch_bounds__(256) void row_dot_kernel(const float *__restrict__ M, const float *__restrict__ X,
+                                                      float *__restrict__ out, int64_t rows, int64_t rows_x, int64_t L) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float *m = M + r * L;
+  const float *xr = X ? X + (r % rows_x) * L : nullptr;
+  float acc = 0.f;
+  for (int64_t l = lane; l < L; l += 64) acc += xr ? m[l] * xr[l] : m[l];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) out[r] = acc;
+}
+
+// ---- loss-Hessian square roots ------------------------------------------------------------------------------------------
+// Cross entropy: p = softmax(logits[n, :]).  exact: S[v, n, c] = sqrt(p_v) (delta_vc - p_c) * scale  (V = C slices);
+// sampled:  S[m, n, c] = (p_c - onehot[m, n, c]) * scale.   One workgroup per sample.
+__global__ __launch_bounds__(256) void ce_sqrt_hessian_kernel(const float *__restrict__ logits, const float *__restrict__ onehot,
+                                                              float *__restrict__ S, int64_t N, int64_t C, int64_t Vd, float scale) {
+  extern __shared__ float p[];  // [C]
+  __shared__ float red[256];
+  const int64_t n = blockIdx.x;
+  const float *z = logits + n * C;
+  float mx = -INFINITY;
+  for (int64_t c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, z[c]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  float sum = 0.f;
+  for (int64_t c = threadIdx.x; c < C; c += 256) {
+    const float e = expf(z[c] - mx);
+    p[c] = e;
+    sum += e;
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float inv = 1.f / red[0];
+  for (int64_t c = threadIdx.x; c < C; c += 256) p[c] *= inv;
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < Vd * C; i += 256) {
+    const int64_t v = i / C, c = i - v * C;
+    float val;
+    if (onehot) val = (p[c] - onehot[(v * N + n) * C + c]) * scale;
+    else val = sqrtf(p[v]) * ((v == c ? 1.f : 0.f) - p[c]) * scale;
+    S[(v * N + n) * C + c] = val;
+  }
+}
+
+} // namespace vivit
+
+using namespace vivit;
+
+static inline unsigned grid_for(int64_t total) {
+  int64_t g = cdiv(total, 256);
+  return (unsigned)(g > 262144 ? 262144 : (g < 1 ? 1 : g));
+}
+
+extern "C" {
+
+int vivit_act_jac_t_f32(const float *M, const float *x, float *out, int64_t Vd, int64_t per_v, int kind, float param,
+                        void *stream) {
+  if (Vd < 0 || per_v < 0 || kind < 0 || kind > ACT_SELU) return VIVIT_E_BADARG;
+  if (Vd == 0 || per_v == 0) return VIVIT_OK;
+  if (!M || !x || !out) return VIVIT_E_BADARG;
+  act_jac_t_kernel<<<grid_for(Vd * per_v), 256, 0, static_cast<hipStream_t>(stream)>>>(M, x, out, Vd * per_v, per_v, kind, param);
+  return launch_status();
+}
+
+int vivit_channel_scale_f32(const float *M, const float *scale, float *out, int64_t rows, int64_t C, int64_t L, void *stream) {
+  if (rows < 0 || C <= 0 || L <= 0) return VIVIT_E_BADARG;
+  if (rows == 0) return VIVIT_OK;
+  if (!M || !scale || !out) return VIVIT_E_BADARG;
+  channel_scale_kernel<<<grid_for(rows * C * L), 256, 0, static_cast<hipStream_t>(stream)>>>(M, scale, out, rows * C * L, C, L);
+  return launch_status();
+}
+
+static int pool_geom(PoolGeom &g, int64_t H, int64_t W, int64_t OH, int64_t OW, int64_t kh, int64_t kw, int64_t sh, int64_t sw,
+                     int64_t ph, int64_t pw) {
+  if (H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0) return VIVIT_E_BADARG;
+  if (H * W > 0x7fffffffLL || OH * OW > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
+  g = PoolGeom{(int)H, (int)W, (int)OH, (int)OW, (int)kh, (int)kw, (int)sh, (int)sw, (int)ph, (int)pw};
+  return VIVIT_OK;
+}
+
+// idx_ws: [planes * OH * OW] ints (planes = N * C of the layer input)
+int vivit_maxpool2d_jac_t_f32(const float *M, const float *x, float *out, int *idx_ws, int64_t Vd, int64_t planes, int64_t H,
+                              int64_t W, int64_t OH, int64_t OW, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph,
+                              int64_t pw, void *stream) {
+  PoolGeom g;
+  const int st0 = pool_geom(g, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
+  if (st0 != VIVIT_OK || Vd < 0 || planes < 0) return st0 != VIVIT_OK ? st0 : VIVIT_E_BADARG;
+  if (Vd == 0 || planes == 0) return VIVIT_OK;
+  if (!M || !x || !out || !idx_ws) return VIVIT_E_BADARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  maxpool_argmax_kernel<<<grid_for(planes * OH * OW), 256, 0, s>>>(x, idx_ws, planes, g);
+  pool_jac_t_kernel<true><<<grid_for(Vd * planes * H * W), 256, 0, s>>>(M, idx_ws, out, Vd * planes, planes, g, 1.f);
+  return launch_status();
+}
+
+int vivit_avgpool2d_jac_t_f32(const float *M, float *out, int64_t rows_planes, int64_t H, int64_t W, int64_t OH, int64_t OW,
+                              int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, void *stream) {
+  PoolGeom g;
+  const int st0 = pool_geom(g, H, W, OH, OW, kh, kw, sh, sw, ph, pw);
+  if (st0 != VIVIT_OK || rows_planes < 0) return st0 != VIVIT_OK ? st0 : VIVIT_E_BADARG;
+  if (rows_planes == 0) return VIVIT_OK;
+  if (!M || !out) return VIVIT_E_BADARG;
+  pool_jac_t_kernel<false><<<grid_for(rows_planes * H * W), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      M, nullptr, out, rows_planes, 1, g, 1.f / (float)(kh * kw));
+  return launch_status();
+}
+
+int vivit_conv2d_jac_t_f32(const float *M, const float *weight, float *out, int64_t rows, int64_t Cin, int64_t H, int64_t W,
+                           int64_t Cout, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int64_t sh, int64_t sw, int64_t ph,
+                           int64_t pw, int64_t dh, int64_t dw, void *stream) {
+  if (rows < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || OH <= 0 || OW <= 0 || sh <= 0 || sw <= 0 ||
+      ph < 0 || pw < 0 || dh <= 0 || dw <= 0)
+    return VIVIT_E_BADARG;
+  if (rows == 0) return VIVIT_OK;
+  if (!M || !weight || !out) return VIVIT_E_BADARG;
+  const size_t lds = (size_t)Cout * KH * KW * CIT * sizeof(float);
+  const int64_t tiles = cdiv(H * W, 256);
+  if (lds > 64 * 1024 || rows * tiles > 0x7fffffffLL || cdiv(Cin, CIT) > 65535) return VIVIT_E_UNSUPPORTED;
+  ConvGeom g{(int)Cin, (int)H, (int)W, (int)Cout, (int)KH, (int)KW, (int)OH, (int)OW, (int)sh, (int)sw, (int)ph, (int)pw, (int)dh, (int)dw};
+  conv2d_jac_t_kernel<<<dim3((unsigned)(rows * tiles), (unsigned)cdiv(Cin, CIT)), 256, lds, static_cast<hipStream_t>(stream)>>>(M, weight,
+                                                                                                                                  out, g);
+  return launch_status();
+}
+
+int vivit_row_dot_f32(const float *M, const float *X, float *out, int64_t rows, int64_t rows_x, int64_t L, void *stream) {
+  if (rows < 0 || L < 0 || (X && rows_x <= 0)) return VIVIT_E_BADARG;
+  if (rows == 0) return VIVIT_OK;
+  if (!M || !out) return VIVIT_E_BADARG;
+  row_dot_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, static_cast<hipStream_t>(stream)>>>(M, X, out, rows, X ? rows_x : 1, L);
+  return launch_status();
+}
+
+int vivit_ce_sqrt_hessian_f32(const float *logits, const float *onehot, float *S, int64_t N, int64_t C, int64_t Vd, float scale,
+                              void *stream) {
+  if (N < 0 || C <= 0 || Vd <= 0) return VIVIT_E_BADARG;
+  if (N == 0) return VIVIT_OK;
+  if (!logits || !S || (!onehot && Vd != C)) return VIVIT_E_BADARG;
+  if ((size_t)C * sizeof(float) > 60 * 1024 || N > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
+  ce_sqrt_hessian_kernel<<<(unsigned)N, 256, (size_t)C * sizeof(float), static_cast<hipStream_t>(stream)>>>(logits, onehot, S, N, C, Vd,
+                                                                                                              scale);
+  return launch_status();
+}
+
+} // extern "C"

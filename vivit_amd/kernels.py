@@ -316,6 +316,123 @@ def conv2d_weight_mjp(M, x, kernel_size, stride, padding, dilation):
     return out
 
 
+ACTIVATION_KINDS = {"relu": 0, "sigmoid": 1, "tanh": 2, "leaky_relu": 3, "logsigmoid": 4, "elu": 5, "selu": 6}
+
+
+@_launcher
+def act_jac_t(M, x, kind: str, param: float = 0.0):
+    """``out[v, n, ...] = M[v, n, ...] * f'(x[n, ...])`` for an elementwise activation ``f`` (``kind`` in
+    :data:`ACTIVATION_KINDS`): the transposed input-Jacobian of SqrtGGN{ReLU,Sigmoid,Tanh,...}."""
+    _require_device(M, x)
+    M, x = M.contiguous(), x.contiguous()
+    if tuple(M.shape[1:]) != tuple(x.shape):
+        raise ValueError(f"M must be [V, *x.shape], got {tuple(M.shape)} for x {tuple(x.shape)}")
+    out = torch.empty_like(M)
+    st = _lib.load().vivit_act_jac_t_f32(M.data_ptr(), x.data_ptr(), out.data_ptr(), M.shape[0], x.numel(), ACTIVATION_KINDS[kind],
+                                        float(param), _stream(M))
+    _lib.check(st, "vivit_act_jac_t_f32")
+    return out
+
+
+@_launcher
+def channel_scale(M, scale):
+    """``out[v, n, c, ...] = M[v, n, c, ...] * scale[c]`` (BatchNorm in eval mode)."""
+    _require_device(M, scale)
+    M, scale = M.contiguous(), scale.contiguous()
+    C = scale.numel()
+    if M.dim() < 3 or M.shape[2] != C:
+        raise ValueError(f"M must be [V, N, {C}, ...], got {tuple(M.shape)}")
+    L = M[0, 0, 0].numel()
+    out = torch.empty_like(M)
+    st = _lib.load().vivit_channel_scale_f32(M.data_ptr(), scale.data_ptr(), out.data_ptr(), M.shape[0] * M.shape[1], C, L, _stream(M))
+    _lib.check(st, "vivit_channel_scale_f32")
+    return out
+
+
+@_launcher
+def maxpool2d_jac_t(M, x, kernel_size, stride, padding):
+    """Transposed input-Jacobian of ``MaxPool2d`` (no dilation, no ceil_mode): ``M [V, N, C, OH, OW]``, ``x [N, C, H, W]``."""
+    _require_device(M, x)
+    M, x = M.contiguous(), x.contiguous()
+    Vd, N, C, OH, OW = M.shape
+    if tuple(x.shape[:2]) != (N, C):
+        raise ValueError(f"x must be [{N}, {C}, H, W], got {tuple(x.shape)}")
+    H, W = x.shape[2:]
+    out = torch.empty((Vd, N, C, H, W), dtype=torch.float32, device=M.device)
+    idx = torch.empty(N * C * OH * OW, dtype=torch.int32, device=M.device)
+    st = _lib.load().vivit_maxpool2d_jac_t_f32(M.data_ptr(), x.data_ptr(), out.data_ptr(), idx.data_ptr(), Vd, N * C, H, W, OH, OW,
+                                              kernel_size[0], kernel_size[1], stride[0], stride[1], padding[0], padding[1], _stream(M))
+    _lib.check(st, "vivit_maxpool2d_jac_t_f32")
+    return out
+
+
+@_launcher
+def avgpool2d_jac_t(M, in_hw, kernel_size, stride, padding):
+    """Transposed input-Jacobian of ``AvgPool2d`` (count_include_pad, no ceil_mode): ``M [V, N, C, OH, OW]`` -> ``[V, N, C, H, W]``."""
+    _require_device(M)
+    M = M.contiguous()
+    Vd, N, C, OH, OW = M.shape
+    H, W = in_hw
+    out = torch.empty((Vd, N, C, H, W), dtype=torch.float32, device=M.device)
+    st = _lib.load().vivit_avgpool2d_jac_t_f32(M.data_ptr(), out.data_ptr(), Vd * N * C, H, W, OH, OW, kernel_size[0], kernel_size[1],
+                                              stride[0], stride[1], padding[0], padding[1], _stream(M))
+    _lib.check(st, "vivit_avgpool2d_jac_t_f32")
+    return out
+
+
+@_launcher
+def conv2d_jac_t(M, weight, in_hw, stride, padding, dilation):
+    """Transposed input-Jacobian of ``Conv2d`` (groups = 1, zero padding): ``M [V, N, Cout, OH, OW]``, ``weight
+    [Cout, Cin, KH, KW]`` -> ``[V, N, Cin, H, W]``."""
+    _require_device(M, weight)
+    M, weight = M.contiguous(), weight.contiguous()
+    Vd, N, Cout, OH, OW = M.shape
+    Co, Cin, KH, KW = weight.shape
+    if Co != Cout:
+        raise ValueError(f"weight must have {Cout} output channels, got {Co}")
+    H, W = in_hw
+    out = torch.empty((Vd, N, Cin, H, W), dtype=torch.float32, device=M.device)
+    st = _lib.load().vivit_conv2d_jac_t_f32(M.data_ptr(), weight.data_ptr(), out.data_ptr(), Vd * N, Cin, H, W, Cout, KH, KW, OH, OW,
+                                           stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], _stream(M))
+    _lib.check(st, "vivit_conv2d_jac_t_f32")
+    return out
+
+
+@_launcher
+def row_dot(M, X=None, rows_x: int = 1):
+    """``out[r] = sum_l M[r, l] * (X[r % rows_x, l] if X is given else 1)`` for ``M [rows, L]`` (fixed summation order)."""
+    _require_device(M, X)
+    M = _as2d(M.contiguous())
+    if X is not None:
+        X = _as2d(X.contiguous())
+        if X.shape != (rows_x, M.shape[1]):
+            raise ValueError(f"X must be [{rows_x}, {M.shape[1]}], got {tuple(X.shape)}")
+    out = torch.empty(M.shape[0], dtype=torch.float32, device=M.device)
+    st = _lib.load().vivit_row_dot_f32(M.data_ptr(), X.data_ptr() if X is not None else None, out.data_ptr(), M.shape[0], rows_x,
+                                      M.shape[1], _stream(M))
+    _lib.check(st, "vivit_row_dot_f32")
+    return out
+
+
+@_launcher
+def ce_sqrt_hessian(logits, scale: float, onehot=None):
+    """Cross-entropy loss-Hessian square root ``S [V, N, C]`` from ``logits [N, C]``: exact (``V = C``) or, with
+    ``onehot [M, N, C]``, the sampled factor ``(p - onehot) * scale``."""
+    _require_device(logits, onehot)
+    logits = logits.contiguous()
+    N, C = logits.shape
+    Vd = C if onehot is None else onehot.shape[0]
+    if onehot is not None:
+        onehot = onehot.contiguous()
+        if tuple(onehot.shape[1:]) != (N, C):
+            raise ValueError(f"onehot must be [M, {N}, {C}], got {tuple(onehot.shape)}")
+    S = torch.empty((Vd, N, C), dtype=torch.float32, device=logits.device)
+    st = _lib.load().vivit_ce_sqrt_hessian_f32(logits.data_ptr(), onehot.data_ptr() if onehot is not None else None, S.data_ptr(), N, C,
+                                              Vd, float(scale), _stream(logits))
+    _lib.check(st, "vivit_ce_sqrt_hessian_f32")
+    return S
+
+
 class SymeigPlan:
     """A symmetric matrix reduced to tridiagonal form with ALL eigenvalues known (``evals``, ascending), waiting for
     the caller to say which eigenvectors it wants: the two launches around the reference's ``criterion`` callback

@@ -461,17 +461,16 @@ def main():
             if e is not None:
                 e[1].record(), e[2].record()
             return G
-        shards = [vdist.to_parameter_shard(A.view(C, Ng, -1), 2, None, k) for k, A in enumerate(facs)]  # all-to-all
+        # batch shards -> parameter shards (all-to-all in column chunks, chunk j + 1 in flight while the SYRK of chunk j
+        # runs) -> full-size partial SYRKs -> all-reduce of the packed lower triangle (vivit_amd/distributed.py)
+        acc = vdist.BatchShardedGram(C, Ng)
         if e is not None:
             e[1].record()
-        part = torch.zeros((n, n), dtype=torch.float32, device=device)
-        for A in shards:
-            if A.shape[1] > 0:
-                kernels.gram_syrk(A, out=part, alpha=1.0, beta=1.0)
-        del shards
+        for A in facs:
+            acc.add_factor(A.view(C, Ng, -1))
         if e is not None:
             e[2].record()
-        return vdist.all_reduce_sum_(part)
+        return acc.finalize().view(n, n)
 
     def step(idx):
         e = ev[idx]
@@ -521,6 +520,7 @@ def main():
     if world == 1:
         exch_s, gram_s, ar_s = 0.0, phase(0, 1), 0.0
     else:
+        # the exchange is pipelined behind the SYRKs: phase (1, 2) is exchange + Gram, (0, 1) the shard-size handshake
         exch_s, gram_s, ar_s = phase(0, 1), phase(1, 2), phase(2, 3)
     eig_s = phase(3, 4)
 

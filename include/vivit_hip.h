@@ -312,6 +312,12 @@ int vivit_profile_stages(double *out_ms, int num);
 /* Mirror the lower triangle of G into the upper triangle (G[i][j] = G[j][i], i < j). */
 int vivit_symmetrize_lower_f32(float *G, int64_t n, int64_t ldg, void *stream);
 
+/* Lower triangle of a symmetric matrix <-> packed vector, packed[i (i + 1) / 2 + j] = G[i][j] (j <= i; n (n + 1) / 2 floats):
+ * the partial Gram matrices of the ranks are all-reduced in this form (half the bytes of `gram += gram_p` summed over
+ * ranks, vivit/utils/gram.py:104-116).  unpack writes the lower triangle and mirrors it (both triangles valid). */
+int vivit_pack_lower_f32(const float *G, int64_t n, int64_t ldg, float *packed, void *stream);
+int vivit_unpack_lower_f32(const float *packed, int64_t n, float *G, int64_t ldg, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

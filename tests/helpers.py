@@ -122,6 +122,16 @@ class OracleBackend:
         w, Z = self.symeig(G, True)
         return w, Z.T[row_begin:row_end].contiguous()
 
+    def pack_lower(self, G):
+        i, j = torch.tril_indices(G.shape[0], G.shape[0])
+        return G[i, j].contiguous()
+
+    def unpack_lower_(self, packed, G):
+        i, j = torch.tril_indices(G.shape[0], G.shape[0])
+        G[i, j] = packed
+        G[j, i] = packed
+        return G
+
     def dir_curvature(self, GE, evals, C, N, scale):
         K = evals.numel()
         return scale * (GE.view(C, N, K) ** 2).sum(0) / evals

@@ -119,13 +119,40 @@ def _worker_batch_sharded(rank, world, port, ret):
     dist.all_gather(gathered, flat)
     ok["replicated"] = all(torch.equal(gathered[0], t) for t in gathered)
 
-    # (6) unequal shards are rejected
+    # (6) unequal shards are rejected -- by the check itself and by the accumulator's constructor (a ragged last batch
+    # would otherwise give mismatched collective sizes: a hang or corruption under RCCL)
     try:
         vd.check_equal_shards(Ng + rank)
         ok["unequal_raises"] = False
     except ValueError:
         ok["unequal_raises"] = True
+    try:
+        vd.BatchShardedGram(C, Ng + rank)
+        ok["unequal_ctor_raises"] = False
+    except ValueError:
+        ok["unequal_ctor_raises"] = True
     ok["equal_ok"] = vd.check_equal_shards(Ng) == N
+
+    # (7) the headline's aspect (C = 10, a wide parameter and three small ones), exchanged in several column chunks with
+    # a ragged last one: chunk j + 1 is in flight while chunk j is multiplied; packed lower-triangle all-reduce
+    vd.EXCHANGE_CHUNK_COLUMNS = 37
+    Cw, Pw = 10, 40 * world + 3
+    Vw1 = torch.randn(Cw, N, Pw, generator=g)
+    Vw2 = torch.randn(Cw, N, 4, generator=g)
+    gw1 = torch.randn(N, Pw, generator=g)
+    acc = vd.BatchShardedGram(Cw, Ng, N_grad_local=Ng)
+    acc.add_factor(Vw1[:, lo:hi], gw1[lo:hi])
+    acc.add_factor(Vw2[:, lo:hi], torch.zeros(Ng, 4))
+    Gw = acc.finalize()
+    VtGw = acc.finalize_vtg()
+    ok["chunked_gram"] = torch.allclose(Gw, oracle.compute_gram_mat([Vw1, Vw2], start_dim=2, flatten=False), rtol=1e-5, atol=1e-4)
+    ok["chunked_vtg"] = torch.allclose(VtGw, oracle.partial_contract(Vw1, gw1, (2, 1)), rtol=1e-5, atol=1e-4)
+    Gf = Gw.reshape(Cw * N, Cw * N)
+    ok["chunked_symmetric"] = torch.equal(Gf, Gf.T)
+    flat = Gf.reshape(-1)
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok["chunked_replicated"] = all(torch.equal(gathered[0], t) for t in gathered)
     ret[rank] = {k: bool(v) for k, v in ok.items()}
     dist.destroy_process_group()
 

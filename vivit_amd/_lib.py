@@ -66,6 +66,8 @@ SIGNATURES = {
     "vivit_profile_end": (_int, [ctypes.POINTER(ctypes.c_double)]),
     "vivit_profile_stages": (_int, [ctypes.POINTER(ctypes.c_double), _int]),
     "vivit_symmetrize_lower_f32": (_int, [_ptr, _i64, _i64, _ptr]),
+    "vivit_pack_lower_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr]),
+    "vivit_unpack_lower_f32": (_int, [_ptr, _i64, _ptr, _i64, _ptr]),
 }
 
 ABI_VERSION = 1004  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)

@@ -194,6 +194,20 @@ int symmetrize_launch(float *G, int64_t n, int64_t ldg, hipStream_t stream) {
   return launch_status();
 }
 
+// Lower triangle (diagonal included) of a symmetric matrix <-> packed row-major vector, packed[i (i + 1) / 2 + j] = G[i][j]
+// for j <= i: what the ranks all-reduce instead of the full partial Gram matrices (half the bytes over xGMI).
+// grid.y = row, grid.x = 256-column blocks; both sides coalesced.
+__global__ __launch_bounds__(256) void pack_lower_kernel(const float *__restrict__ G, int64_t r0, int64_t ldg,
+                                                         float *__restrict__ packed) {
+  const int64_t i = r0 + blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j <= i) packed[i * (i + 1) / 2 + j] = G[i * ldg + j];
+}
+__global__ __launch_bounds__(256) void unpack_lower_kernel(const float *__restrict__ packed, int64_t r0, float *__restrict__ G,
+                                                           int64_t ldg) {
+  const int64_t i = r0 + blockIdx.y, j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j <= i) G[i * ldg + j] = packed[i * (i + 1) / 2 + j];
+}
+
 } // namespace vivit
 
 using namespace vivit;
@@ -308,6 +322,32 @@ int vivit_symmetrize_lower_f32(float *G, int64_t n, int64_t ldg, void *stream) {
   if (n == 0) return VIVIT_OK;
   if (!G) return VIVIT_E_BADARG;
   return symmetrize_launch(G, n, ldg, static_cast<hipStream_t>(stream));
+}
+
+int vivit_pack_lower_f32(const float *G, int64_t n, int64_t ldg, float *packed, void *stream) {
+  if (n < 0 || ldg < n) return VIVIT_E_BADARG;
+  if (n == 0) return VIVIT_OK;
+  if (!G || !packed) return VIVIT_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int64_t r0 = 0; r0 < n; r0 += 65535) {  // grid.y limit
+    const int64_t rc = (n - r0) < 65535 ? n - r0 : 65535;
+    pack_lower_kernel<<<dim3((unsigned)cdiv(r0 + rc, 256), (unsigned)rc), 256, 0, st>>>(G, r0, ldg, packed);
+  }
+  return launch_status();
+}
+
+int vivit_unpack_lower_f32(const float *packed, int64_t n, float *G, int64_t ldg, void *stream) {
+  if (n < 0 || ldg < n) return VIVIT_E_BADARG;
+  if (n == 0) return VIVIT_OK;
+  if (!G || !packed) return VIVIT_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int64_t r0 = 0; r0 < n; r0 += 65535) {
+    const int64_t rc = (n - r0) < 65535 ? n - r0 : 65535;
+    unpack_lower_kernel<<<dim3((unsigned)cdiv(r0 + rc, 256), (unsigned)rc), 256, 0, st>>>(packed, r0, G, ldg);
+  }
+  int s2 = launch_status();
+  if (s2 != VIVIT_OK) return s2;
+  return symmetrize_launch(G, n, ldg, st);
 }
 
 } // extern "C"

@@ -35,6 +35,9 @@ import torch.distributed as dist
 from vivit_amd import kernels
 
 SMALL_PARAM_COLUMNS = 64  # parameters with fewer columns per rank than this are owned whole by one rank
+EXCHANGE_CHUNK_COLUMNS = 8192  # columns of a rank's parameter shard exchanged (and multiplied) at a time: the all-to-all
+                               # of chunk j + 1 runs on RCCL's stream while the SYRK of chunk j runs (at n = 40 960, R = 8:
+                               # 168 MB per peer and chunk, ~3 ms over one xGMI link, against a ~60 ms SYRK)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -70,6 +73,17 @@ def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def all_reduce_sym_(G: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over the ranks of a SYMMETRIC matrix (every rank's summand symmetric): only the packed lower
+    triangle travels (n (n + 1) / 2 floats instead of n^2 -- the all-reduce is bound by the bytes per xGMI link), the
+    upper triangle is mirrored locally afterwards (``vivit_pack_lower_f32`` / ``vivit_unpack_lower_f32``)."""
+    if not _active(group):
+        return G
+    packed = kernels.pack_lower(G)
+    all_reduce_sum_(packed, group)
+    return kernels.unpack_lower_(packed, G)
+
+
 def all_gather_cat(t: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``[R * t.shape[0], *t.shape[1:]]``: the ranks' equally shaped ``t`` stacked along dim 0 in rank order."""
     R = world_size(group)
@@ -88,18 +102,27 @@ def all_gather_cat(t: torch.Tensor, group=None, out: Optional[torch.Tensor] = No
     return out
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
 def all_to_all_flat(send: torch.Tensor, in_splits: Sequence[int], out_splits: Sequence[int], group=None,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, async_op: bool = False):
     """1-D all-to-all with per-peer element counts; returns the received flat buffer (peer order), ``out`` if given
-    (contiguous, ``sum(out_splits)`` elements)."""
+    (contiguous, ``sum(out_splits)`` elements).  ``async_op``: returns ``(recv, work)`` instead; ``work.wait()`` makes
+    the current stream wait for the exchange (RCCL runs it on its own stream behind the work already queued here)."""
     recv = torch.empty(int(sum(out_splits)), dtype=send.dtype, device=send.device) if out is None else out
+    work = _Done()
     if _staged(send, group):
         h = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(h, send.cpu(), list(out_splits), list(in_splits), group=group)
         recv.copy_(h)
     else:
-        dist.all_to_all_single(recv, send, list(out_splits), list(in_splits), group=group)
-    return recv
+        w = dist.all_to_all_single(recv, send, list(out_splits), list(in_splits), group=group, async_op=async_op)
+        if async_op:
+            work = w
+    return (recv, work) if async_op else recv
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -167,17 +190,44 @@ def to_parameter_shard(local: torch.Tensor, lead_dims: int, group=None, index: i
     if R == 1:
         return F.reshape(C * Ng, P)
     slices = parameter_slices(P, R, index)
-    w = slices[me][1] - slices[me][0]
-    # one exchange per class, received straight into the class-major result [C, R, N_g, w]: the peak is the local factor
-    # plus the result plus one class worth of send buffer (a single exchange of the whole factor needed the factor four
-    # times over: send copy, receive buffer [R, C, N_g, w] and its permuted copy)
-    out = torch.empty((C, R, Ng, w), dtype=F.dtype, device=F.device)
-    in_splits = [Ng * (hi - lo) for lo, hi in slices]
-    for c in range(C):
-        send = torch.cat([F[c, :, lo:hi].reshape(-1) for lo, hi in slices])
-        all_to_all_flat(send, in_splits, [Ng * w] * R, group, out=out[c].reshape(-1))
-        del send
-    return out.reshape(C * R * Ng, w)
+    return _exchange_columns(F, [(lo, hi) for lo, hi in slices], slices[me][1] - slices[me][0], group)
+
+
+def _pack_columns(F: torch.Tensor, cols: Sequence[Tuple[int, int]]) -> Tuple[torch.Tensor, List[int]]:
+    """Send buffer of one exchange: for every peer ``r`` the columns ``cols[r]`` of ``F [C, N_g, P]`` (all classes, all
+    local samples), peer-major.  Equal-width slices at a constant pitch are ONE strided copy; otherwise one copy per peer."""
+    C, Ng, P = F.shape
+    R = len(cols)
+    widths = [hi - lo for lo, hi in cols]
+    splits = [C * Ng * w for w in widths]
+    w0 = widths[0]
+    pitch = cols[1][0] - cols[0][0] if R > 1 else 0
+    if R > 1 and w0 > 0 and all(w == w0 for w in widths) and all(cols[r][0] == cols[0][0] + r * pitch for r in range(R)) and pitch > 0:
+        view = F.as_strided((R, C, Ng, w0), (pitch * F.stride(2), F.stride(0), F.stride(1), F.stride(2)),
+                            F.storage_offset() + cols[0][0] * F.stride(2))
+        return view.contiguous().reshape(-1), splits
+    send = torch.empty(sum(splits), dtype=F.dtype, device=F.device)
+    off = 0
+    for (lo, hi), cnt in zip(cols, splits):
+        if cnt > 0:
+            send[off:off + cnt].view(C, Ng, hi - lo).copy_(F[:, :, lo:hi])
+        off += cnt
+    return send, splits
+
+
+def _class_major(recv: torch.Tensor, R: int, C: int, Ng: int, w: int) -> torch.Tensor:
+    """Received ``[R, C, N_g, w]`` (peer-major) -> ``[C R N_g, w]``: the reference's class-major rows ``c N + n``."""
+    if C == 1 or R == 1:
+        return recv.view(C * R * Ng, w)
+    return recv.view(R, C, Ng, w).permute(1, 0, 2, 3).reshape(C * R * Ng, w)
+
+
+def _exchange_columns(F: torch.Tensor, cols, w_mine: int, group) -> torch.Tensor:
+    C, Ng, _ = F.shape
+    R = len(cols)
+    send, in_splits = _pack_columns(F, cols)
+    recv = all_to_all_flat(send, in_splits, [C * Ng * w_mine] * R, group)
+    return _class_major(recv, R, C, Ng, w_mine)
 
 
 def check_equal_shards(n_local: int, group=None) -> int:
@@ -204,6 +254,9 @@ class BatchShardedGram:
         self.group = group
         self.R, self.me = world_size(group), rank_of(group)
         self.C, self.Ng = int(C), int(N_local)
+        check_equal_shards(self.Ng, group)  # unequal shards would give mismatched collective sizes (hang / corruption)
+        if N_grad_local is not None:
+            check_equal_shards(int(N_grad_local), group)
         self.N = self.Ng * self.R
         self.n = self.C * self.N
         self.Mg = None if N_grad_local is None else int(N_grad_local)
@@ -216,20 +269,53 @@ class BatchShardedGram:
 
     # -- materialised factors: all-to-all to parameter shards, full-size SYRK on 1/R of the contraction ------------
     def add_factor(self, V_local: torch.Tensor, g_local: Optional[torch.Tensor] = None):
-        """``V_local: [C, N_g, *param]``; ``g_local: [M_g, *param]`` adds ``V^T g`` (K2) of the same parameter."""
+        """``V_local: [C, N_g, *param]``; ``g_local: [M_g, *param]`` adds ``V^T g`` (K2) of the same parameter.
+
+        The rank's column range of the parameter is exchanged and multiplied in chunks of ``EXCHANGE_CHUNK_COLUMNS``:
+        the all-to-all of chunk ``j + 1`` is issued (asynchronously, on RCCL's stream) before the SYRK of chunk ``j``
+        is launched, so the exchange hides behind the matrix work; only the first chunk's exchange is exposed."""
         idx = self._count
         self._count += 1
-        A = to_parameter_shard(V_local, 2, self.group, idx)
+        C, Ng, R, me = self.C, self.Ng, self.R, self.me
+        F = V_local.detach().reshape(C, Ng, -1)
+        P = F.shape[2]
+        Fg = None if g_local is None else g_local.detach().reshape(1, self.Mg, -1)
+        slices = parameter_slices(P, R, idx)
+        widths = [hi - lo for lo, hi in slices]
         if self.partial is None:
             self.partial = torch.zeros((self.n, self.n), dtype=torch.float32, device=V_local.device)
-        if A.shape[1] > 0:
-            kernels.gram_syrk(A, out=self.partial, alpha=1.0, beta=1.0)
-        if g_local is not None:
-            B = to_parameter_shard(g_local, 1, self.group, idx)
-            if self.partial_g is None:
-                self.partial_g = torch.zeros((self.n, self.M), dtype=torch.float32, device=V_local.device)
-            if A.shape[1] > 0:
-                kernels.gemm_nt(A, B, out=self.partial_g, alpha=1.0, beta=1.0)
+        if g_local is not None and self.partial_g is None:
+            self.partial_g = torch.zeros((self.n, self.M), dtype=torch.float32, device=V_local.device)
+        nch = -(-max(widths) // EXCHANGE_CHUNK_COLUMNS)
+
+        def issue(j):
+            cols = [(lo + min(j * EXCHANGE_CHUNK_COLUMNS, w), lo + min((j + 1) * EXCHANGE_CHUNK_COLUMNS, w))
+                    for (lo, _), w in zip(slices, widths)]
+            wc = cols[me][1] - cols[me][0]
+            send, in_splits = _pack_columns(F, cols)
+            recv, work = all_to_all_flat(send, in_splits, [C * Ng * wc] * R, self.group, async_op=True)
+            out = [(send, recv, work, wc)]
+            if Fg is not None:
+                sg, isg = _pack_columns(Fg, cols)
+                rg, wg = all_to_all_flat(sg, isg, [self.Mg * wc] * R, self.group, async_op=True)
+                out.append((sg, rg, wg, wc))
+            return out
+
+        pending = issue(0) if nch > 0 else None
+        for j in range(nch):
+            nxt = issue(j + 1) if j + 1 < nch else None
+            (_, recv, work, wc) = pending[0]
+            work.wait()
+            if wc > 0:
+                A = _class_major(recv, R, C, Ng, wc)
+                kernels.gram_syrk(A, out=self.partial, alpha=1.0, beta=1.0)
+                if Fg is not None:
+                    (_, rg, wg, _) = pending[1]
+                    wg.wait()
+                    kernels.gemm_nt(A, rg.view(self.M, wc), out=self.partial_g, alpha=1.0, beta=1.0)
+            elif Fg is not None:
+                pending[1][2].wait()
+            pending = nxt
 
     # -- small materialised factors (biases, ...): all-gather the factor, block row by one NT GEMM -----------------
     def add_factor_rows(self, V_local: torch.Tensor, g_local: Optional[torch.Tensor] = None):
@@ -275,27 +361,26 @@ class BatchShardedGram:
             return g.reshape(C, self.N, -1)
         return g.permute(1, 0, 2, 3).reshape(C, self.N, -1)
 
-    def _assemble(self, rows, partial, width):
-        """Block rows ``[C N_g, width]`` of all ranks -> class-major ``[n, width]``; plus the all-reduced partial."""
+    def _assemble(self, rows, partial, width, symmetric=False):
+        """Block rows ``[C N_g, width]`` of all ranks -> class-major ``[n, width]``, plus the summed partials
+        (``symmetric``: every rank's partial is a sum of SYRKs, so only its packed lower triangle is all-reduced)."""
         C, Ng, R, n = self.C, self.Ng, self.R, self.n
         out = None
         if partial is not None:
-            if rows is not None:  # disjoint supports: fold the block row into the partial sum before the all-reduce
-                partial.view(C, R, Ng, width)[:, self.me].add_(rows.view(C, Ng, width))
-                rows = None
-            out = all_reduce_sum_(partial, self.group)
+            out = all_reduce_sym_(partial, self.group) if symmetric else all_reduce_sum_(partial, self.group)
         if rows is not None:
             g = all_gather_cat(rows.view(1, C * Ng, width), self.group)            # [R, C N_g, width]
             if C > 1 and R > 1:  # class-major store: row (c, g N_g + n_local)
-                g = g.view(R, C, Ng, width).permute(1, 0, 2, 3).contiguous()
-            out = g.reshape(n, width)
+                g = g.view(R, C, Ng, width).permute(1, 0, 2, 3)
+            g = g.reshape(n, width)
+            out = g if out is None else out.add_(g)
         return out
 
     def finalize(self) -> torch.Tensor:
         """The group's Gram matrix ``[C, N, C, N]``, identical on every rank."""
         if self.rows is None and self.partial is None:
             raise ValueError("no factor was added")
-        G = self._assemble(self.rows, self.partial, self.n)
+        G = self._assemble(self.rows, self.partial, self.n, symmetric=True)
         self.rows = self.partial = None
         return G.view(self.C, self.N, self.C, self.N)
 

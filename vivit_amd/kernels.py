@@ -433,6 +433,30 @@ def ce_sqrt_hessian(logits, scale: float, onehot=None):
     return S
 
 
+@_launcher
+def pack_lower(G: torch.Tensor) -> torch.Tensor:
+    """Lower triangle (diagonal included) of the square matrix ``G`` as a packed ``n (n + 1) / 2`` vector (row-major)."""
+    _require_device(G)
+    G = _as2d(G)
+    n = G.shape[0]
+    packed = torch.empty(n * (n + 1) // 2, dtype=torch.float32, device=G.device)
+    st = _lib.load().vivit_pack_lower_f32(G.data_ptr(), n, _ld(G), packed.data_ptr(), _stream(G))
+    _lib.check(st, "vivit_pack_lower_f32")
+    return packed
+
+
+@_launcher
+def unpack_lower_(packed: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
+    """Inverse of :func:`pack_lower` into the (row-major) ``G``, both triangles written (symmetric result)."""
+    _require_device(packed, G)
+    n = G.shape[0]
+    if G.dim() != 2 or G.shape[1] != n or G.stride(1) != 1 or packed.numel() != n * (n + 1) // 2 or not packed.is_contiguous():
+        raise ValueError("unpack_lower_ needs a square row-major G and a contiguous packed vector of n (n + 1) / 2 floats")
+    st = _lib.load().vivit_unpack_lower_f32(packed.data_ptr(), n, G.data_ptr(), _ld(G), _stream(G))
+    _lib.check(st, "vivit_unpack_lower_f32")
+    return G
+
+
 class SymeigPlan:
     """A symmetric matrix reduced to tridiagonal form with ALL eigenvalues known (``evals``, ascending), waiting for
     the caller to say which eigenvectors it wants: the two launches around the reference's ``criterion`` callback

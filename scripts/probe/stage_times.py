@@ -2,7 +2,14 @@
 import os, sys, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
-from vivit_amd import kernels, _lib
+from vivit_amd import _lib
+if os.environ.get("VIVIT_LIB"):   # A/B against another build of the library (e.g. last round's: scripts/probe/libr02.so)
+    _lib.LIB_PATH = os.path.abspath(os.environ["VIVIT_LIB"])
+    _probe = ctypes.CDLL(_lib.LIB_PATH)
+    _probe.vivit_hip_abi_version.restype = ctypes.c_int
+    _lib.ABI_VERSION = _probe.vivit_hip_abi_version()
+    _lib.SIGNATURES = {k: v for k, v in _lib.SIGNATURES.items() if hasattr(_probe, k)}
+from vivit_amd import kernels
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40960
 V = torch.randn(n, n // 2, device="cuda")
 pad = int(os.environ.get("PAD", "0"))

@@ -3,8 +3,14 @@
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
+import ctypes
 import vivit_amd._lib as L
-if os.environ.get("VIVIT_LIB"): L.LIB_PATH = os.path.abspath(os.environ["VIVIT_LIB"])
+if os.environ.get("VIVIT_LIB"):
+    L.LIB_PATH = os.path.abspath(os.environ["VIVIT_LIB"])
+    _probe = ctypes.CDLL(L.LIB_PATH)
+    _probe.vivit_hip_abi_version.restype = ctypes.c_int
+    L.ABI_VERSION = _probe.vivit_hip_abi_version()
+    L.SIGNATURES = {k: v for k, v in L.SIGNATURES.items() if hasattr(_probe, k)}
 from vivit_amd import kernels
 dev = torch.device("cuda:0")
 n, p = 40960, int(os.environ.get("P", 401408))

@@ -775,7 +775,14 @@ typedef const unsigned short __attribute__((address_space(1))) *gcptr16;
 constexpr int BX_PIECE = 8 * 1024;               // bytes of one piece of one operand tile (256 rows x 16 k bf16)
 constexpr int BX_OPER = 3 * BX_PIECE;            // 24 KB
 constexpr int BX_STAGE = 2 * BX_OPER;            // A and B: 48 KB
-constexpr int GEMM256BX_LDS_BYTES = 3 * BX_STAGE + 4 * 4096;  // three stages (144 KB) + a 32 x 32 flush patch per wave = 160 KB
+#if defined(BX_EXP) && BX_EXP == 3   // timing only: 144 KB of LDS as in round 2 (the flush patch then aliases the stages: wrong results)
+constexpr int GEMM256BX_LDS_BYTES = 3 * BX_STAGE;
+#define BX_PATCH_OFFSET (2 * BX_STAGE)
+#else
+#define BX_PATCH_OFFSET (3 * BX_STAGE)
+constexpr int GEMM256BX_LDS_BYTES = 3 * BX_STAGE + 4 * 4096;
+#endif
+constexpr int GEMM256BX_LDS_BYTES_UNUSED = 0;  // three stages (144 KB) + a 32 x 32 flush patch per wave = 160 KB
 
 __device__ __forceinline__ void bx_split2(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo) {
   const bf16x2 h = {(__bf16)a, (__bf16)b};
@@ -921,7 +928,9 @@ __device__ unsigned int g_bx_stamp_cap = 0;
 template <int NPROD>
 __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
+#if !(defined(BX_EXP) && BX_EXP == 2)   // (experiment 2: timing without the gate check)
   if (p.gate && (*p.gate & p.gate_mask) != 0) return;  // the fp32 MFMA kernel takes this chunk
+#endif
   int ti, tj;
   if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
 
@@ -950,7 +959,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   const float alpha_ = p.kt_split > 0 ? 1.f : p.alpha, beta_ = p.kt_split > 0 ? 0.f : p.beta;
   const bool full_tile = row0 + B2 <= p.M && col0 + B2 <= p.N;
   // C <- C' + alpha * acc with C' = beta * C on the first flush and C afterwards; acc <- final value.  The loads go to
-  // the L2 (sc1): earlier chains of this tile were added into C by L2 atomics (flush_atomic), which the L1 does not see.
+  // the L2 (sc1): earlier chains of this tile were added into C by L2 atomics (flush_mid), which the L1 does not see.
   auto ld_l2 = [](gptr q) __attribute__((always_inline)) -> float {
     return __hip_atomic_load((const float *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
@@ -1013,74 +1022,17 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   };
 
-  // The flush INSIDE the K loop (and the last one of a tile that is not mirrored): C <- C' + alpha * acc as above, but
-  // through a private 32 x 32 patch of LDS per wave that lies BEHIND the three operand stages, so it needs no barrier
-  // and the global -> LDS pipeline keeps running across it: restarting the pipeline per accumulation chain (barrier,
-  // first DMA round trip, fragment prologue) cost 34 us per chain, + 8.5 % at the headline shape for chains of 2048 k
-  // instead of 8192 even with the flush itself stubbed out.  An accumulator tile is written to the patch in MFMA layout
-  // and read back as float4 rows: C is read and written with 16-byte accesses (a wave may keep 63 memory instructions in
-  // flight: 4-byte accesses are 16 KB in flight, HBM latency-bound); the old values of the next three tiles are in
-  // flight while a tile is stored.
   typedef f32x4 __attribute__((address_space(1))) *gptr4w;
   const bool c_vec = (reinterpret_cast<uintptr_t>(Cout) & 15) == 0 && (ldc & 3) == 0;
-  auto flush_patch = [&](bool first) __attribute__((always_inline)) {
-    const float beta = first ? beta_ : 1.f;
-    float *ts = reinterpret_cast<float *>(smem_bx + 3 * BX_STAGE) + wave * 1024;
-    const int rr = lane >> 3, c4 = lane & 7;
-    int opaque = 0;
-    __asm__ volatile("" : "+v"(opaque));
-    const int64_t rbase = row0 + wm * 128 + rr + opaque, cbase = col0 + wn * 128 + 4 * c4;
-    gptr cwave = Cout + rbase * ldc + cbase;
-    const bool vec = full_tile && c_vec;
-    f32x4 oldv[4][4];   // ring over the tiles u = 4 i + j
-    auto ld_tile = [&](int u) __attribute__((always_inline)) {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) oldv[u & 3][it] = *(gptr4w)(cwave + (int64_t)((u >> 2) * 32 + 8 * it) * ldc + (u & 3) * 32);
-    };
-#if defined(BX_VARIANT) && BX_VARIANT == 2   // timing only: no flush at all
-    return;
-#endif
-    const bool pre = vec && beta != 0.f;
-    if (pre) { ld_tile(0); ld_tile(1); ld_tile(2); }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      if (pre && u + 3 < 16) ld_tile(u + 3);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ts[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[u >> 2][u & 3][e];
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        f32x4 v = *reinterpret_cast<const f32x4 *>(ts + (8 * it + rr) * 32 + 4 * c4);
-        v = alpha_ * v;
-        if (vec) {
-          if (beta != 0.f) v += beta * oldv[u & 3][it];
-          *(gptr4w)(cwave + (int64_t)((u >> 2) * 32 + 8 * it) * ldc + (u & 3) * 32) = v;
-        } else {   // edge tile or unaligned C: guarded elements
-          const int64_t row = rbase + (u >> 2) * 32 + 8 * it;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int64_t col = cbase + (u & 3) * 32 + k;
-            if (row < p.M && col < p.N) {
-              gptr c = Cout + row * ldc + col;
-              float x = v[k];
-              if (beta != 0.f) x += beta * *c;
-              *c = x;
-            }
-          }
-        }
-      }
-    }
-  };
-
-  // Every flush after the first of a full tile: C += alpha * acc with no-return fp32 atomics executed in the L2
-  // (global_atomic_add_f32: a correctly rounded fp32 add, exactly the VALU add of flush_patch).  This workgroup is the
-  // only writer of its tile and a wave's memory operations on one address stay in order, so the result is the same
-  // deterministic sum -- but nothing is loaded, nothing is waited for: the read-modify-write happens where the data
-  // lives while the next chain's MFMAs run.  (With the read-modify-write in the wave, the 63-instruction limit on
-  // memory operations in flight made a flush of the HBM-resident headline Gram matrix take 32 us per workgroup: + 10 %
-  // for chains of 2048 k.)
-  auto flush_atomic = [&]() __attribute__((always_inline)) {
+  // The flush INSIDE the K loop (end of an accumulation chain): C += alpha * acc with no-return fp32 atomics executed in
+  // the L2 (global_atomic_add_f32: a correctly rounded fp32 add, exactly the VALU add of the other flushes), or a plain
+  // store when this is the tile's first flush and beta = 0 (the host passes only beta = 0 or 1 and scales C beforehand
+  // otherwise).  This workgroup is the only writer of its tile and a wave's memory operations on one address stay in
+  // order, so the result is the same deterministic sum -- but nothing is loaded and nothing is waited for: the
+  // read-modify-write happens where the data lives while the next chain's MFMAs run, and the global -> LDS pipeline is
+  // not restarted (that alone cost 34 us per chain).  (Out of line -- accumulators copied to a private array, a noinline
+  // function issuing the atomics -- the flush cost 140 us: 512 KB of scratch traffic per workgroup.)
+  auto flush_mid = [&](bool store) __attribute__((always_inline)) {
     int opaque = 0;
     __asm__ volatile("" : "+v"(opaque));
 #if defined(BX_VARIANT) && BX_VARIANT == 2   // timing only: no flush at all
@@ -1090,10 +1042,16 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        gptr cb = Cout + (row0 + wm * 128 + i * 32 + 4 * h + opaque) * ldc + (col0 + wn * 128 + j * 32 + r);
+        const int64_t rb = row0 + wm * 128 + i * 32 + 4 * h + opaque, col = col0 + wn * 128 + j * 32 + r;
+        gptr cb = Cout + rb * ldc + col;
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          __builtin_amdgcn_global_atomic_fadd_f32(cb + (int64_t)((e & 3) + 8 * (e >> 2)) * ldc, alpha_ * acc[i][j][e]);
+        for (int e = 0; e < 16; ++e) {
+          const int dr = (e & 3) + 8 * (e >> 2);
+          if (full_tile || (rb + dr < p.M && col < p.N)) {
+            if (store) cb[(int64_t)dr * ldc] = alpha_ * acc[i][j][e];
+            else __builtin_amdgcn_global_atomic_fadd_f32(cb + (int64_t)dr * ldc, alpha_ * acc[i][j][e]);
+          }
+        }
       }
   };
 
@@ -1192,7 +1150,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   // the barrier there publishes tile t + 1 and certifies that every wave is completely past tile t - 1, whose stage then
   // receives the requests for tile t + 2.
   // One pipelined pass over all K tiles.  Every `flush_tiles` tiles (rounded to the two-tile trip) an MFMA chain ends:
-  // its sum goes into C (flush_patch) and the accumulators restart from zero -- see bx_flush_tiles for why chains are short.
+  // its sum goes into C (flush_mid) and the accumulators restart from zero -- see bx_flush_tiles for why chains are short.
 #if defined(BX_STAMP)
   const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1218,7 +1176,13 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       FragA fa2 = load_a(st, 2);
       mfma_row(J1{}, fa1, fb, nothing);
       __builtin_amdgcn_sched_barrier(0);
-      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile t + 1 has landed
+      // own share of tile t + 1 has landed.  The wait is the compiler-VISIBLE builtin on purpose: hipcc cannot see the asm DMA
+      // requests, but it does track its own memory operations (accumulator rows it keeps in scratch around a flush, spill
+      // reloads in front of the loop); with those pending in its model it put s_waitcnt vmcnt(12/8/4/0) in front of the first
+      // MFMAs of every second tile -- where the hardware counter also holds the DMA requests just issued (+ 40 us per 128 K
+      // tiles).  Seeing this vmcnt(0) it knows nothing of its own is pending afterwards.
+      __asm__ volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
       __asm__ volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       FragA fa3 = load_a(st, 3);
@@ -1242,8 +1206,6 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       st = st1;
       ++t;
     };
-    // (the flush sits BETWEEN two clean inner loops: as a conditional block inside the trip hipcc hoisted its 164
-    // accumulator reads and 25 spills above the branch, into every trip)
     while (true) {
       const int tc = next_flush < t1 ? next_flush : t1;
       while (t + 2 <= tc) {  // two tiles per trip, no exit in between (the sets swap roles and are back in place)
@@ -1251,18 +1213,14 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
         tile(fbY, faY, fbX, faX);
       }
       if (t + 2 > t1) break;  // at most one tile left: it joins this chain
-      // end of a chain (its memory operations drain behind the next tile's MFMAs)
-#if defined(BX_NO_ATOMIC)   // experiment: read-modify-write in the wave for every flush
-      flush_patch(first_flush);
-#else
-      if (first_flush || !full_tile)
-        flush_patch(first_flush);
-      else
-        flush_atomic();
-#endif
+      flush_mid(first_flush && beta_ == 0.f);  // end of a chain; its memory operations drain behind the next tile's MFMAs
       first_flush = false;
       clear_acc();
       next_flush += flush_tiles;
+      // the fragments of tile t are read again (nothing but the accumulators is carried across the flush)
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      fbX = load_b(st);
+      faX = load_a(st, 0);
     }
     if (t < t1) tile(fbX, faX, fbY, faY);
   }
@@ -1272,19 +1230,107 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     g_bx_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
   }
 #endif
-  if (mirrored || !full_tile)
-    flush_to_c(first_flush);
-#if defined(BX_NO_ATOMIC)
-  else
-    flush_patch(first_flush);
+  // The LAST flush of a full, 16-byte-aligned tile that must read C (beta != 0 on a single-chain product, or a SYRK tile
+  // whose final values also go to the transposed tile).  The operand stages are dead now, so the old values of C are
+  // fetched by the same global -> LDS DMA as the operands, two 32 x 32 tiles (8 KB) per wave and request, three requests
+  // (24 KB per wave, no registers) in flight while a pair of tiles is combined and stored (a plain read-modify-write in
+  // registers holds 64 four-byte loads = 16 KB in flight).  `mirror`: the final values are written back to the patch and read
+  // column-wise: lane r stores element (row r, col c) to C[col0 + c][row0 + r], 128 contiguous bytes per mirror row.
+  auto flush_final = [&](bool first, bool mirror) __attribute__((always_inline)) {
+    const float beta = first ? beta_ : 1.f;
+    float *ts = reinterpret_cast<float *>(smem_bx + BX_PATCH_OFFSET) + wave * 1024;
+    const int rr = lane >> 3, c4 = lane & 7;
+    int opaque = 0;
+    __asm__ volatile("" : "+v"(opaque));
+    gptr cwave = Cout + (row0 + wm * 128 + rr + opaque) * ldc + (col0 + wn * 128 + 4 * c4);
+    const bool pre = beta != 0.f;
+    const unsigned oldb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * (32768 - 1024)));   // this wave's 4 x 8 KB of the stages
+    const unsigned char *oldp = smem_bx + wave * 32768 + lane * 16;
+    auto issue_pair = [&](int k) __attribute__((always_inline)) {   // old values of tiles 2 k, 2 k + 1 into buffer k & 3
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int u = 2 * k + t;
+          dma16b((gcptr16)(const void __attribute__((address_space(1))) *)(cwave + (int64_t)((u >> 2) * 32 + 8 * it) * ldc + (u & 3) * 32),
+                 oldb + (unsigned)((k & 3) * 8192 + t * 4096 + it * 1024));
+        }
+    };
+    auto wait_vm = [](int n) __attribute__((always_inline)) {
+      switch (n) {
+        case 16: __asm__ volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 24: __asm__ volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 32: __asm__ volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 56: __asm__ volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+        default: __asm__ volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+      }
+    };
+    __syncthreads();   // every wave is past its last fragment reads: the stages may be overwritten
+    if (pre) {
+      // earlier chains of this tile may have been added into C by L2 atomics: the DMA must not be served from a stale L1 line
+      if (!first) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      issue_pair(0); issue_pair(1); issue_pair(2);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (pre) {
+        // operations issued after the requests of pair k: the later requests (8 each) and the stores of the pairs in
+        // between (8 per pair, + 32 mirror stores); vmcnt counts in issue order
+        const int S = mirror ? 40 : 8;
+        const int after = k == 0 ? 16 : k == 1 ? 16 + S : k < 6 ? 16 + 2 * S : k == 6 ? 8 + 2 * S : 2 * S;
+        wait_vm(after < 24 ? 16 : after < 32 ? 24 : after < 56 ? 32 : after < 63 ? 56 : 63);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int u = 2 * k + t;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+          ts[row * 32 + (r ^ ((row & 7) << 2))] = acc[u >> 2][u & 3][e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          float *tp = ts + (8 * it + rr) * 32 + 4 * (c4 ^ (rr & 7));
+          f32x4 v = *reinterpret_cast<const f32x4 *>(tp);
+          v = alpha_ * v;
+          if (pre) v += beta * *reinterpret_cast<const f32x4 *>(oldp + (k & 3) * 8192 + t * 4096 + it * 1024);
+          *(gptr4w)(cwave + (int64_t)((u >> 2) * 32 + 8 * it) * ldc + (u & 3) * 32) = v;
+          if (mirror) *reinterpret_cast<f32x4 *>(tp) = v;
+        }
+        if (mirror) {   // transposed copy of tile u = (i, j)
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          gptr mbase = (gptr)p.C + (col0 + wn * 128 + (u & 3) * 32 + h) * p.ldc + (row0 + wm * 128 + (u >> 2) * 32 + r);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int col = 2 * q + h;
+            mbase[(int64_t)(2 * q) * p.ldc] = ts[r * 32 + (col ^ ((r & 7) << 2))];
+          }
+        }
+      }
+      if (pre && k + 3 < 8) {
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads of buffer (k + 3) & 3 == (k - 1) & 3 are done
+        issue_pair(k + 3);
+      }
+    }
+  };
+#if defined(BX_OLD_FINAL)   // experiment: the register read-modify-write for every last flush
+  const bool fast_tile = false;
 #else
-  else if (first_flush)
-    flush_patch(true);
-  else
-    flush_atomic();
+  const bool fast_tile = full_tile && c_vec;
 #endif
+#if defined(BX_EXP) && BX_EXP == 1   // timing only: no final flush
+  if (p.alpha == 12345.678f)
+#endif
+  if (!fast_tile)
+    flush_to_c(first_flush);          // edge tiles / unaligned C; the mirror store below takes the values from the registers
+  else if (mirrored || first_flush)
+    flush_final(first_flush, mirrored);   // final values to the tile (and, for a SYRK, to its transposed image)
+  else
+    flush_mid(false);
 
-  if (p.syrk == 1 && ti != tj) {
+  if (mirrored && !fast_tile) {
     __syncthreads();
     float *ts = reinterpret_cast<float *>(smem_bx) + wave * (32 * 33);
 #pragma unroll
@@ -1909,6 +1955,11 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
     q.gate_mask = tls_bx_gate_mask;
     q.flush_tiles = bx_flush_tiles();
     q.flush_diag = bx_flush_diag();
+    float beta0 = p.beta;
+    if (beta0 != 0.f && beta0 != 1.f) {   // the in-loop flushes add into C: C <- beta C once, then beta = 1
+      scale_c_kernel<<<(unsigned)cdiv(p.M * p.N, 256), 256, 0, stream>>>(p.C, p.M, p.N, p.ldc, beta0);
+      beta0 = 1.f;
+    }
     int st = VIVIT_OK;
     int64_t chunk = 0;
     for (int64_t k0 = 0; k0 < p.K && st == VIVIT_OK; k0 += kc_max, ++chunk) {
@@ -1926,7 +1977,7 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
           bx_split_kernel<LAY_M><<<dim3((unsigned)nrbB, gy), 256, 0, stream>>>(p.B, p.N, p.ldb, k0, kc, PB, strideB, nrbB, flag);
       }
       q.K = kc;
-      q.beta = k0 == 0 ? p.beta : 1.f;
+      q.beta = k0 == 0 ? beta0 : 1.f;
       // SYRK: only the last chunk mirrors the finished lower tiles into the upper triangle (2 = lower tiles, no mirror)
       q.syrk = (p.syrk == 1 && k0 + kc < p.K) ? 2 : p.syrk;
       q.gate = flag;
@@ -1947,6 +1998,7 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
       f.a_vec = ((reinterpret_cast<uintptr_t>(f.A) & 15) == 0 && (f.lda & 3) == 0) ? 1 : 0;
       f.b_vec = ((reinterpret_cast<uintptr_t>(f.B) & 15) == 0 && (f.ldb & 3) == 0) ? 1 : 0;
       f.gate = flag; f.gate_mask = q.gate_mask;
+#if !defined(BX_NO_STANDIN)
       if (alay == LAY_K && blay == LAY_K)
         gemm256_kernel<LAY_K, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
       else if (alay == LAY_K && blay == LAY_M)
@@ -1955,6 +2007,7 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
         gemm256_kernel<LAY_M, LAY_K><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
       else
         gemm256_kernel<LAY_M, LAY_M><<<grid, 256, GEMM256_LDS_BYTES, stream>>>(f);
+#endif
       st = launch_status();
     }
     if (st == VIVIT_OK && p.syrk == 1) {

@@ -1840,8 +1840,9 @@ static int gemm_split_mode() {
 // competes with the operand panels for the L2 / Infinity Cache): 8192 -> 4096: + 2 %, -> 2048: + 6 %, -> 1024: + 10 %;
 // diagonal tiles at 512: + 1-2 % (1 % of the tiles).  Default: 4096 k (1.4 x the fp32 MFMA kernel's random-sign error),
 // 512 k on the diagonal tiles of a SYRK (no bias where every term has the same sign), 1024 k in the split-K form for
-// small outputs (whose yardstick is the 128-tile fp32 kernel with its chains of 2048).
-// VIVIT_BX_FLUSH / VIVIT_BX_FLUSH_DIAG / VIVIT_BX_FLUSH_SPLITK override (in k).
+// small outputs (whose yardstick is the 128-tile fp32 kernel with its chains of 2048); the eigensolver's internal
+// products on orthogonal factors (random signs, the measured off-diagonal case) keep 8192.
+// VIVIT_BX_FLUSH / VIVIT_BX_FLUSH_DIAG / VIVIT_BX_FLUSH_SPLITK / VIVIT_BX_FLUSH_INTERNAL override (in k).
 static int bx_env_tiles(const char *name, int dflt_k) {
   const char *e = getenv(name);
   int ft = (e ? atoi(e) : dflt_k) / BK;
@@ -1849,6 +1850,7 @@ static int bx_env_tiles(const char *name, int dflt_k) {
 }
 static int bx_flush_tiles() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH", 4096); return ft; }
 static int bx_flush_diag() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_DIAG", 512); return ft; }
+static int bx_flush_internal() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_INTERNAL", 8192); return ft; }
 static int bx_flush_splitk() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_SPLITK", 1024); return ft; }
 
 // columns of an operand split at a time (workspace: 6 bytes per element of the chunk and operand)
@@ -1953,8 +1955,10 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
     q.tiles_m = p.tiles_m; q.tiles_n = p.tiles_n; q.syrk = p.syrk; q.sbw = p.sbw;
     q.slab = nullptr; q.kt_split = 0;
     q.gate_mask = tls_bx_gate_mask;
-    q.flush_tiles = bx_flush_tiles();
-    q.flush_diag = bx_flush_diag();
+    // the eigensolver's own products (orthogonal factors: sums of random signs, nothing correlated) keep chains of 8192
+    const bool internal = tls_bx_gate_mask == BX_GATE_RANGE;
+    q.flush_tiles = internal ? bx_flush_internal() : bx_flush_tiles();
+    q.flush_diag = internal ? bx_flush_internal() : bx_flush_diag();
     float beta0 = p.beta;
     if (beta0 != 0.f && beta0 != 1.f) {   // the in-loop flushes add into C: C <- beta C once, then beta = 1
       scale_c_kernel<<<(unsigned)cdiv(p.M * p.N, 256), 256, 0, stream>>>(p.C, p.M, p.N, p.ldc, beta0);

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from vivit_amd import kernels
+from vivit_amd import _lib, kernels
 from vivit_amd.backend.custom_module import SumModule
 from vivit_amd.utils.ggn import Vmp
 from vivit_amd.utils.gram import mVp, pairwise_dot
@@ -106,7 +106,11 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
         if (isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple)
                 and module.padding_mode == "zeros" and module.out_channels * 129 * 4 <= 64 * 1024):
             # unfold + "vnol,nkl->vnok" in one HIP kernel (patch values gathered on the fly, no im2col buffer)
-            return kernels.conv2d_weight_mjp(M, x, module.kernel_size, module.stride, module.padding, module.dilation)
+            try:
+                return kernels.conv2d_weight_mjp(M, x, module.kernel_size, module.stride, module.padding, module.dilation)
+            except _lib.VivitHipError as exc:  # shapes outside the kernel's launch limits: the torch rule below
+                if "status -4" not in str(exc):
+                    raise
         return _conv_weight_factor(module, M, x)
     if isinstance(module, _BATCHNORM):
         if module.training:

@@ -33,7 +33,7 @@ int stebz_launch(const float *d, const float *e, int64_t n, float *w, const floa
 // stein.hip: selected eigenvectors of the tridiagonal (d, e) by inverse iteration, rows of Zt
 size_t stein_workspace_bytes(int64_t n, int64_t K);
 int stein_launch(const float *d, const float *e, int64_t n, const double *lam64, const int *sel, int64_t K, float *Zt,
-                 int64_t ldz, void *wsbase, hipStream_t stream);
+                 int64_t ldz, void *wsbase, int32_t *info, hipStream_t stream);
 // sytrd.hip: pointers into a workspace laid out by sytrd_launch (same base, same n) without launching anything
 void sytrd_layout(float *wsbase, int64_t n, SytrdWs *out);
 // two-phase eigensolver for criterion-selected eigenvectors (symeig_large.hip)

@@ -1123,6 +1123,30 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       between(j);
+#if defined(BX_EXP) && BX_EXP == 5   // timing only (wrong numbers): the same flops on v_mfma_f32_16x16x32_bf16 -- the 32 x 32 block as
+      // four 16 x 16 tiles, three instructions (two partial products fused along k) per tile and K tile
+      if (NPROD == 6) {
+        f32x16 c0 = acc[i][j];
+        f32x4 q[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) q[t] = __builtin_shufflevector(c0, c0, 4 * 0, 4 * 0 + 1, 4 * 0 + 2, 4 * 0 + 3);
+        q[0] = __builtin_shufflevector(c0, c0, 0, 1, 2, 3);
+        q[1] = __builtin_shufflevector(c0, c0, 4, 5, 6, 7);
+        q[2] = __builtin_shufflevector(c0, c0, 8, 9, 10, 11);
+        q[3] = __builtin_shufflevector(c0, c0, 12, 13, 14, 15);
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            q[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v[pr], fb.v[(pr + t) % 3][j], q[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c0[4 * t + e] = q[t][e];
+        acc[i][j] = c0;
+        continue;
+      }
+#endif
       f32x16 c = acc[i][j];
       if (NPROD >= 9) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2], fb.v[2][j], c, 0, 0, 0);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void stein_span_kernel(const float *__restrict
 // `sel[k]` is the position of the wanted eigenvalue in the ascending list lam64 (strictly ascending in k).
 __global__ __launch_bounds__(64) void stein_iterate_kernel(const float *__restrict__ d, const float *__restrict__ e, int n,
                                                            const double *__restrict__ lam64, const int *__restrict__ sel,
-                                                           int K, int Kp, SteinWs ws) {
+                                                           int K, int Kp, SteinWs ws, int32_t *__restrict__ info) {
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k >= K) return;
   const double tnorm = ws.span[1];
@@ -119,11 +119,12 @@ __global__ __launch_bounds__(64) void stein_iterate_kernel(const float *__restri
     a[o] = ak; b[o] = 0.0; c[o] = 0.0; d2[o] = 0.0; piv[o] = 0;
   }
   // ---- start vector: xorshift per (k, i), in [-1, 1)
-  unsigned int s = 0x9E3779B9u * (unsigned int)(sel[k] + 1) + 0x85EBCA6Bu;
+  unsigned int s = (0x9E3779B9u * (unsigned int)(sel[k] + 1) + 0x85EBCA6Bu) | 1u;   // never 0: xorshift would stay 0
   for (int i = 0; i < n; ++i) {
     s ^= s << 13; s ^= s >> 17; s ^= s << 5;
     y[(int64_t)i * Kp] = (double)(int)s * (1.0 / 2147483648.0);
   }
+  double growth = 0.0;   // |x| / |y| of the last solve
   for (int it = 0; it < ST_ITERS; ++it) {
     // forward: y <- L^-1 P y
     double yi = y[0];
@@ -158,7 +159,12 @@ __global__ __launch_bounds__(64) void stein_iterate_kernel(const float *__restri
     }
     const double inv = 1.0 / sqrt(fmax(ss, 1e-300));
     for (int i = 0; i < n; ++i) y[(int64_t)i * Kp] *= inv;
+    growth = sqrt(ss) / scale;
   }
+  // A converged inverse iteration amplifies a unit vector by ~ 1 / |lam - lam_true| >= 1 / (n eps64 |T|); a shift that is
+  // not an eigenvalue (or a broken solve: zero / non-finite vector) shows as a small or non-finite growth factor.  The
+  // caller's `info` word counts such vectors (kernels.check_info raises, like a non-converged Tensor.symeig).
+  if (tnorm > 1e-290 && (!(growth * tnorm >= 1e6) || !(growth < INFINITY))) atomicAdd(info, 1);
 }
 
 // One workgroup: modified Gram-Schmidt inside runs of numerically multiple selected eigenvalues (ascending order),
@@ -210,12 +216,12 @@ __global__ __launch_bounds__(256) void stein_finish_kernel(int n, const double *
 // Zt[k][:] (k < K, ld ldz) = unit eigenvector of the tridiagonal (d, e) for the eigenvalue lam64[sel[k]].
 // sel: device int32 [K], strictly ascending positions in the ascending eigenvalue list lam64 [n] (fp64).
 int stein_launch(const float *d, const float *e, int64_t n, const double *lam64, const int *sel, int64_t K, float *Zt,
-                 int64_t ldz, void *wsbase, hipStream_t stream) {
+                 int64_t ldz, void *wsbase, int32_t *info, hipStream_t stream) {
   if (K <= 0) return VIVIT_OK;
   SteinWs ws = stein_carve(wsbase, n, K);
   const int Kp = (int)stein_kp(K);
   stein_span_kernel<<<1, 256, 0, stream>>>(d, e, (int)n, ws.span);
-  stein_iterate_kernel<<<(unsigned)cdiv(K, 64), 64, 0, stream>>>(d, e, (int)n, lam64, sel, (int)K, Kp, ws);
+  stein_iterate_kernel<<<(unsigned)cdiv(K, 64), 64, 0, stream>>>(d, e, (int)n, lam64, sel, (int)K, Kp, ws, info);
   stein_finish_kernel<<<1, 256, 0, stream>>>((int)n, lam64, sel, (int)K, Kp, ws, Zt, ldz);
   return launch_status();
 }

@@ -499,7 +499,7 @@ int symeig_select_launch(const float *A, int64_t n, int64_t lda, const int *sel,
   int st;
   if (K <= SELECT_STEIN_MAX) {
     void *stws = take(stein_workspace_bytes(n, K));
-    st = stein_launch(L.d, L.e, n, L.lam64, sel, K, Zt, ldz, stws, stream);
+    st = stein_launch(L.d, L.e, n, L.lam64, sel, K, Zt, ldz, stws, info, stream);
     if (st != VIVIT_OK) return st;
   } else {  // many eigenvectors: divide & conquer for all of them, keep the selected rows
     float *wscratch = (float *)take(sizeof(float) * n);
@@ -524,7 +524,6 @@ int symeig_select_launch(const float *A, int64_t n, int64_t lda, const int *sel,
   }
   if (st != VIVIT_OK) return st;
   prof_mark(PROF_STAGE_Q1, stream);
-  (void)info;
   return VIVIT_OK;
 }
 

@@ -21,11 +21,18 @@ def get_vivit_extension(subsampling: Union[None, List[int]], mc_samples: int):
     """Extension that provides the Gram / ``V`` closures for a backward pass.
 
     Without BackPACK: ``ViViTGGN{Exact,MC}`` of the stand-in backend (factorised Linear weights,
-    vivit/linalg/utils.py:11-28).  With BackPACK installed: its built-in ``SqrtGGN{Exact,MC}``;
-    the hooks then wrap the materialised ``V_t`` into the same closures (see ``get_closures``).
+    vivit/linalg/utils.py:11-28).  With BackPACK installed: its ``SqrtGGN{Exact,MC}`` with the Linear module
+    extension replaced by one that keeps the weight factorised (``extensions/backpack_adapter.py``; untestable here,
+    falls back to the plain extension on any mismatch); the hooks wrap materialised ``V_t`` tensors into the same
+    closures (see ``get_closures``).
     """
     ext = real_backpack_extensions()
     if ext is not None:
+        from vivit_amd.extensions.backpack_adapter import factorised_sqrt_ggn
+
+        fact = factorised_sqrt_ggn(mc_samples, subsampling)   # Linear weights as closures (linear.py:41-81); None: not possible
+        if fact is not None:
+            return fact
         if mc_samples == 0:
             return ext.SqrtGGNExact(subsampling=subsampling)
         return ext.SqrtGGNMC(mc_samples=mc_samples, subsampling=subsampling)

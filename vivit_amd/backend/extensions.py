@@ -104,7 +104,7 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
         if name == "bias":
             return _spatial_sum(M, 3)
         if (isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple)
-                and module.padding_mode == "zeros" and module.out_channels * 129 * 4 <= 64 * 1024):
+                and module.padding_mode == "zeros"):
             # unfold + "vnol,nkl->vnok" in one HIP kernel (patch values gathered on the fly, no im2col buffer)
             try:
                 return kernels.conv2d_weight_mjp(M, x, module.kernel_size, module.stride, module.padding, module.dilation)

@@ -34,43 +34,60 @@ struct Conv2dGeom {
 };
 
 // V[(v,n)][o][c][kh][kw] = sum_{oh,ow} M[(v,n)][o][oh][ow] * x[n][c][oh*sh - ph + kh*dh][ow*sw - pw + kw*dw]
-// grid.x = (v,n) row, grid.y = chunk of 256 outputs (o, c, kh, kw); M staged through LDS in chunks of positions.
-constexpr int CV_LC = 128;  // output positions per staged chunk
+// grid.x = (v,n) row, grid.y = chunk of 256 patch positions k = (c, kh, kw), grid.z = group of CV_OT output channels.
+// A thread owns ONE patch position and CV_OT output channels in registers: the input value of an output position is
+// loaded once (L1 / L2: the sample's planes are small) and used for CV_OT products; M is staged through LDS as
+// [position][channel] so that the CV_OT channel values of a position are two broadcast ds_read_b128.  (The first version
+// -- one output per thread, one LDS read and one global read per multiply-add -- ran at 2 TFLOP/s and was 70 of the
+// 118 ms of config 4's factor back-propagation.)
+constexpr int CV_LC = 64;   // output positions per staged chunk
+constexpr int CV_OT = 8;    // output channels per thread
 __global__ __launch_bounds__(256) void conv2d_weight_mjp_kernel(const float *__restrict__ M, const float *__restrict__ x,
                                                                 float *__restrict__ V, int64_t N, Conv2dGeom g) {
-  extern __shared__ float sM[];  // [Cout][CV_LC + 1]
+  __shared__ __attribute__((aligned(16))) float sM[CV_LC * CV_OT];   // [position][channel of this group]
   const int64_t row = blockIdx.x;
   const int64_t n = row % N;
   const int K = g.Cin * g.KH * g.KW;
   const int L = g.OH * g.OW;
-  const int out_idx = blockIdx.y * 256 + threadIdx.x;
-  const bool active = out_idx < g.Cout * K;
-  const int o = active ? out_idx / K : 0;
-  const int kk = active ? out_idx - o * K : 0;
-  const int c = kk / (g.KH * g.KW);
-  const int kh = (kk / g.KW) % g.KH, kw = kk % g.KW;
+  const int kk = blockIdx.y * 256 + threadIdx.x;
+  const int o0 = blockIdx.z * CV_OT;
+  const bool active = kk < K;
+  const int c = active ? kk / (g.KH * g.KW) : 0;
+  const int kh = active ? (kk / g.KW) % g.KH : 0, kw = active ? kk % g.KW : 0;
   const float *Mrow = M + row * (int64_t)g.Cout * L;
   const float *xc = x + (n * g.Cin + c) * (int64_t)g.H * g.W;
   const int ih0 = kh * g.dh - g.ph, iw0 = kw * g.dw - g.pw;
-  float acc = 0.f;
+  float acc[CV_OT];
+#pragma unroll
+  for (int t = 0; t < CV_OT; ++t) acc[t] = 0.f;
   for (int l0 = 0; l0 < L; l0 += CV_LC) {
     const int lc = (L - l0) < CV_LC ? (L - l0) : CV_LC;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < g.Cout * lc; idx += 256) {
-      const int oo = idx / lc, ll = idx - oo * lc;
-      sM[oo * (CV_LC + 1) + ll] = Mrow[(int64_t)oo * L + l0 + ll];
+    for (int idx = threadIdx.x; idx < CV_OT * CV_LC; idx += 256) {   // coalesced along the positions of a channel
+      const int t = idx / CV_LC, ll = idx - t * CV_LC;
+      sM[ll * CV_OT + t] = (ll < lc && o0 + t < g.Cout) ? Mrow[(int64_t)(o0 + t) * L + l0 + ll] : 0.f;
     }
     __syncthreads();
     if (active) {
       int oh = l0 / g.OW, ow = l0 - oh * g.OW;
       for (int ll = 0; ll < lc; ++ll) {
         const int ih = oh * g.sh + ih0, iw = ow * g.sw + iw0;
-        if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) acc += sM[o * (CV_LC + 1) + ll] * xc[ih * g.W + iw];
+        if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) {
+          const float xv = xc[ih * g.W + iw];
+          const float4 m0 = *reinterpret_cast<const float4 *>(sM + ll * CV_OT);
+          const float4 m1 = *reinterpret_cast<const float4 *>(sM + ll * CV_OT + 4);
+          acc[0] += m0.x * xv; acc[1] += m0.y * xv; acc[2] += m0.z * xv; acc[3] += m0.w * xv;
+          acc[4] += m1.x * xv; acc[5] += m1.y * xv; acc[6] += m1.z * xv; acc[7] += m1.w * xv;
+        }
         if (++ow == g.OW) { ow = 0; ++oh; }
       }
     }
   }
-  if (active) V[row * (int64_t)g.Cout * K + out_idx] = acc;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < CV_OT; ++t)
+      if (o0 + t < g.Cout) V[row * (int64_t)g.Cout * K + (int64_t)(o0 + t) * K + kk] = acc[t];
+  }
 }
 
 } // namespace vivit
@@ -107,21 +124,20 @@ int vivit_conv2d_weight_mjp_f32(const float *M, const float *x, float *V, int64_
   if (!M || !x || !V) return VIVIT_E_BADARG;
   // the geometry must be that of a convolution: every output position reads inside the padded input
   if ((OH - 1) * sh + (KH - 1) * dh - ph >= H + ph || (OW - 1) * sw + (KW - 1) * dw - pw >= W + pw) return VIVIT_E_BADARG;
-  if (Cout * (CV_LC + 1) * sizeof(float) > 64 * 1024 || rows > 0x7fffffffLL || Cout * Cin * KH * KW > 0x7fffffffLL / 4)
+  if (rows > 0x7fffffffLL || Cout * Cin * KH * KW > 0x7fffffffLL / 4 || cdiv(Cout, CV_OT) > 65535 || cdiv(Cin * KH * KW, 256) > 65535)
     return VIVIT_E_UNSUPPORTED;
   Conv2dGeom g{(int)Cin, (int)H, (int)W, (int)Cout, (int)KH, (int)KW, (int)OH, (int)OW,
                (int)sh,  (int)sw, (int)ph, (int)pw,  (int)dh, (int)dw};
   const int64_t outs = Cout * Cin * KH * KW;
-  const size_t lds = (size_t)Cout * (CV_LC + 1) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  for (int64_t r0 = 0; r0 < rows; r0 += 1 << 20) {  // grid.x chunks (far below the 2^31 limit)
-    const int64_t rc = (rows - r0) < (1 << 20) ? rows - r0 : (1 << 20);
-    const dim3 grid((unsigned)rc, (unsigned)cdiv(outs, 256));
-    if (grid.y > 65535) return VIVIT_E_UNSUPPORTED;
-    // row r0 of a chunk must keep its sample index: r0 is a multiple of N only if chunks align; pass offset pointers
-    // and the per-row sample index through (row % N) with rows counted from r0 -> require alignment
-    if (r0 % N != 0) return VIVIT_E_UNSUPPORTED;
-    conv2d_weight_mjp_kernel<<<grid, 256, lds, st>>>(M + r0 * Cout * OH * OW, x, V + r0 * outs, N, g);
+  // grid.x chunks of whole batches (a chunk starts at a multiple of N rows, so row % N inside the kernel is the sample index)
+  const int64_t per = (1 << 20) / N > 0 ? (1 << 20) / N : 1;
+  const int64_t step = N * per;
+  if (step > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
+  for (int64_t r0 = 0; r0 < rows; r0 += step) {
+    const int64_t rc = (rows - r0) < step ? rows - r0 : step;
+    const dim3 grid((unsigned)rc, (unsigned)cdiv(Cin * KH * KW, 256), (unsigned)cdiv(Cout, CV_OT));
+    conv2d_weight_mjp_kernel<<<grid, 256, 0, st>>>(M + r0 * Cout * OH * OW, x, V + r0 * outs, N, g);
   }
   return launch_status();
 }

@@ -1,6 +1,5 @@
 #!/bin/bash
 for i in 1 2; do
-  TAG=sgrp4 python scripts/probe/stage_times.py 40960 2>&1 | grep total
-  TAG=sgrp8 VIVIT_LIB=scripts/probe/lib_sgrp8.so python scripts/probe/stage_times.py 40960 2>&1 | grep total
-  TAG=sgrp2 VIVIT_LIB=scripts/probe/lib_sgrp2.so python scripts/probe/stage_times.py 40960 2>&1 | grep total
+  python scripts/probe/syrk_flush_headline.py 2>&1 | grep flush=
+  VIVIT_BX_SYNC=1 python scripts/probe/syrk_flush_headline.py 2>&1 | grep flush=
 done

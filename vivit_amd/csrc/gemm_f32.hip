@@ -207,6 +207,40 @@ __device__ __forceinline__ bool map_tile(int syrk, int SBW, int tiles_m, int til
   return true;
 }
 
+// Number of valid tiles map_tile hands XCD `blockIdx.x & 7` in this workgroup's super-block (the members of its XCD
+// group: they share their operand panels through that XCD's L2), and the group's index.  Same geometry as map_tile.
+__device__ __forceinline__ int xcd_group(int syrk, int SBW, int tiles_m, int tiles_n, int &group) {
+  const int sb = blockIdx.x >> 8;
+  const int xcd = (blockIdx.x - blockIdx.y) & 7;
+  const int SBH = 256 / SBW;
+  int I, J;
+  if (syrk) {
+    I = (int)((sqrtf(8.f * (float)sb + 1.f) - 1.f) * 0.5f);
+    while ((I + 1) * (I + 2) / 2 <= sb) ++I;
+    while (I * (I + 1) / 2 > sb) --I;
+    J = I - (sb - I * (I + 1) / 2);
+  } else {
+    const int sbn = (tiles_n + SBW - 1) / SBW;
+    I = sb / sbn;
+    J = sb - I * sbn;
+  }
+  group = sb * 8 + xcd;
+  const int vr = tiles_m - I * SBH < SBH ? tiles_m - I * SBH : SBH;
+  const int vc = tiles_n - J * SBW < SBW ? tiles_n - J * SBW : SBW;
+  int v;
+  if (syrk && I == J) {
+    const int d = vr < vc ? vr : vc;
+    v = d * (d + 1) / 2;
+  } else if (vr < SBH || vc < SBW) {
+    v = vr > 0 && vc > 0 ? vr * vc : 0;
+  } else {
+    return 32;
+  }
+  const int c = (v + 7) >> 3;
+  const int left = v - c * xcd;
+  return left < 0 ? 0 : (left < c ? left : c);
+}
+
 // WM = waves along M: 2 -> 128 x 128 tile (2 x 2 waves), 1 -> 64 x 256 tile (1 x 4 waves) for outputs
 // with at most 64 rows (the panel products of the band reduction), where the square tile would
 // spend half of its MFMAs on padding.
@@ -915,6 +949,8 @@ struct GemmBxArgs {
   // K tiles accumulated in one MFMA chain before the sum is added into C with a VALU add (see bx_flush_tiles);
   // flush_diag: the same for the diagonal tiles of a SYRK (sums of squares: every product has the same sign)
   int flush_tiles, flush_diag;
+  // optional start barrier of an XCD group (VIVIT_BX_SYNC, see bx_sync_enabled): one zeroed counter per group
+  int *sync;
 };
 
 #if defined(BX_STAMP)
@@ -935,6 +971,23 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
 
   const int tid = threadIdx.x;
+  if (p.sync) {
+    // The 32 workgroups of an XCD group stream the same 12 operand panels; they hit in that XCD's L2 only while they are
+    // within ~14 K tiles of each other.  Workgroups start when a CU frees up, so the start times of a group random-walk
+    // apart over the rounds of a launch.  Start barrier: wait (at most 50 us: no deadlock if fewer CUs are available)
+    // until the whole group has arrived.  Older groups never wait for newer ones.
+    if (tid == 0) {
+      int group;
+      const int expect = xcd_group(p.syrk, p.sbw, p.tiles_m, p.tiles_n, group);
+      int *cnt = p.sync + (int64_t)blockIdx.y * (gridDim.x >> 5) + group;
+      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect &&
+             __builtin_amdgcn_s_memrealtime() - t0 < 5000ull)
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+  }
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
@@ -1889,8 +1942,19 @@ static size_t bx_piece_bytes(int64_t M, int64_t N, int64_t K, bool same) {
   return (size_t)6 * (size_t)kc * (size_t)(same ? ra : ra + rb);
 }
 // pieces of one chunk + one range flag per chunk (BX_GATE)
+// XCD-group start barrier of the bf16-pipe kernel (experiment, VIVIT_BX_SYNC=1): counters per launch
+static bool bx_sync_enabled() {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("VIVIT_BX_SYNC"); on = e ? atoi(e) : 0; }
+  return on != 0;
+}
+static size_t bx_sync_ints(int64_t M, int64_t N) {   // upper bound of 8 x (number of super-blocks)
+  const int64_t tm = cdiv(M, B2), tn = cdiv(N, B2);
+  return (size_t)8 * (size_t)(tm * tn / 256 + tm + tn + 2);
+}
 static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same) {
-  return bx_piece_bytes(M, N, K, same) + 256 + 4 * (size_t)cdiv(K, bx_chunk_cols(K)) + 256;
+  const size_t nch = (size_t)cdiv(K, bx_chunk_cols(K));
+  return bx_piece_bytes(M, N, K, same) + 256 + 4 * nch + 256 + (bx_sync_enabled() ? 4 * nch * bx_sync_ints(M, N) + 256 : 0);
 }
 
 // Which range flags send a chunk to the fp32 MFMA kernel.  The public products (vivit_gram_syrk_f32, vivit_gemm_*_f32)
@@ -1971,7 +2035,11 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
     unsigned short *PB = same ? PA : PA + 3 * strideA;
     int *flags = reinterpret_cast<int *>(align_up(reinterpret_cast<uintptr_t>(workspace) + bx_piece_bytes(p.M, p.N, p.K, same), 256));
     const int64_t nchunks = cdiv(p.K, kc_max);
-    if (hipMemsetAsync(flags, 0, 4 * (size_t)nchunks, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+    int *sync = nullptr;
+    const size_t sync_ints = bx_sync_ints(p.M, p.N);
+    if (bx_sync_enabled()) sync = reinterpret_cast<int *>(align_up(reinterpret_cast<uintptr_t>(flags + nchunks), 256));
+    if (hipMemsetAsync(flags, 0, 4 * (size_t)nchunks + (sync ? 256 + 4 * (size_t)nchunks * sync_ints : 0), stream) != hipSuccess)
+      return VIVIT_E_LAUNCH;
     GemmBxArgs q;
     q.A = PA; q.B = PB; q.strideA = strideA; q.strideB = same ? strideA : strideB;
     q.nrbA = nrbA; q.nrbB = same ? nrbA : nrbB;
@@ -2009,6 +2077,7 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
       // SYRK: only the last chunk mirrors the finished lower tiles into the upper triangle (2 = lower tiles, no mirror)
       q.syrk = (p.syrk == 1 && k0 + kc < p.K) ? 2 : p.syrk;
       q.gate = flag;
+      q.sync = sync ? sync + chunk * (int64_t)sync_ints : nullptr;
       if (bx == 6)
         gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
       else if (bx == 9)
@@ -2132,6 +2201,7 @@ static int bx_splitk_launch(int alay, int blay, const GemmArgs &p, bool syrk, vo
   q.gate = flag; q.gate_mask = tls_bx_gate_mask;
   q.flush_tiles = bx_flush_splitk();
   q.flush_diag = bx_flush_diag();
+  q.sync = nullptr;
   const int64_t sbm = cdiv(q.tiles_m, sbh), sbn = cdiv(q.tiles_n, sbw);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
   const dim3 grid((unsigned)(nsb * 256), (unsigned)nsplit);

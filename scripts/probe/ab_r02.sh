@@ -1,5 +1,5 @@
 #!/bin/bash
-for i in 1 2; do
-  python scripts/probe/syrk_flush_headline.py 2>&1 | grep flush=
-  VIVIT_BX_SYNC=1 python scripts/probe/syrk_flush_headline.py 2>&1 | grep flush=
+for pad in 0 64 32 0 64; do
+  PAD=$pad python scripts/probe/syrk_flush_headline.py 2>&1 | grep flush=
 done
+PAD=64 VIVIT_BX_FLUSH=2048 python scripts/probe/syrk_flush_headline.py 2>&1 | grep flush=

@@ -14,7 +14,8 @@ if os.environ.get("VIVIT_LIB"):
 from vivit_amd import kernels
 dev = torch.device("cuda:0")
 n, p = 40960, int(os.environ.get("P", 401408))
-G = torch.empty(n, n, device=dev)
+pad = int(os.environ.get('PAD', '0'))
+G = torch.empty(n, n + pad, device=dev)[:, :n]
 A = torch.randn(n, p, device=dev)
 kernels.gram_syrk(A, out=G); torch.cuda.synchronize()
 ts = []
@@ -28,6 +29,6 @@ ref = A[ri].double() @ A[ri].double().T
 got = G[ri][:, ri].double()
 off = ~torch.eye(len(ri), dtype=torch.bool, device=dev)
 unit = p ** 0.5
-print(f"flush={os.environ.get('VIVIT_BX_FLUSH')} diag={os.environ.get('VIVIT_BX_FLUSH_DIAG')}: {dt*1e3:.1f} ms (all {[round(t*1e3,1) for t in ts]})"
+print(f"pad={pad} flush={os.environ.get('VIVIT_BX_FLUSH')} diag={os.environ.get('VIVIT_BX_FLUSH_DIAG')}: {dt*1e3:.1f} ms (all {[round(t*1e3,1) for t in ts]})"
       f" {n*(n+1)*p/dt/1e12:.1f} TFLOP/s  off_rms {((got-ref)[off]/unit).pow(2).mean().sqrt().item():.2e}"
       f" diag_mean {((got-ref).diagonal()/ref.diagonal()).mean().item():+.2e}", flush=True)

@@ -22,6 +22,10 @@ struct SytrdWs {
 size_t sytrd_workspace_floats(int64_t n);
 int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, hipStream_t stream);
 
+// sytrd_persist.hip: the same reduction as one persistent launch on the 32 CUs of one XCD (n <= 1280; after prescale_launch)
+bool sytrd_persist_ok(int64_t n);
+int sytrd_persist_launch(float *A, int64_t n, int64_t lda, const SytrdWs &ws, hipStream_t stream);
+
 // stedc.hip
 size_t stedc_workspace_bytes(int64_t n, bool vectors);
 int stedc_dc_launch(const float *d, const float *e, int64_t n, void *wsbase, float **Qt_out, float **d_out,

@@ -570,6 +570,7 @@ int sytrd_launch(float *A, int64_t n, int64_t lda, float *wsbase, SytrdWs *out, 
   const bool vec = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0) && (n % 4 == 0);
 
   prescale_launch(A, n, lda, ws.scal, scanpart, stream);
+  if (sytrd_persist_ok(n)) return sytrd_persist_launch(A, n, lda, ws, stream);   // one persistent launch on one XCD
 
   // Debug knob for counter collection (rocprofv3 --pmc dies on >10^4 dispatches): stop after this
   // many columns.  The factorisation is then incomplete and its outputs meaningless.

@@ -1,0 +1,58 @@
+"""The persistent kernels against the launch chains they replace.
+
+* ``sb2st_persist_kernel`` (csrc/sb2st.hip) runs the same tasks with the same arithmetic as one launch per wavefront step:
+  d, e, every reflector and every tau must be BIT-identical -- any stale band row (a missed dependency, a cache line
+  served from the wrong L2) changes them.
+* ``trd_persist_kernel`` (csrc/sytrd_persist.hip) is an unblocked right-looking reduction, ``sytrd.hip`` a blocked one:
+  different rounding, same tridiagonal matrix up to signs -- the spectra of (d, e) must agree to fp32 accuracy and with
+  the fp64 spectrum of the input.
+
+The knobs are read once per process, hence the child processes (as tests/test_gram_precision_gpu.py).
+Reference semantics: the eigenvalues ``Tensor.symeig`` returns at vivit/linalg/eigh.py:248-250."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.linalg
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _child(tmp, tag, **env):
+    out = tmp / f"persist_{tag}.json"
+    subprocess.run([sys.executable, os.path.join(HERE, "persist_child.py"), str(out)], env=dict(os.environ, **env), check=True,
+                   timeout=600)
+    return json.loads(out.read_text())
+
+
+@pytest.fixture(scope="module")
+def runs(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("persist")
+    return {"on": _child(tmp, "on", VIVIT_SB2ST_PERSIST="1", VIVIT_SYTRD_PERSIST="1"),
+            "off": _child(tmp, "off", VIVIT_SB2ST_PERSIST="0", VIVIT_SYTRD_PERSIST="0")}
+
+
+def test_sb2st_persistent_is_bit_identical_to_the_launch_chain(runs):
+    assert runs["on"]["sb2st"] == runs["off"]["sb2st"]
+
+
+@pytest.mark.parametrize("n", [193, 256, 300, 777, 1024, 1280])
+def test_sytrd_persistent_spectrum(runs, n):
+    g = torch.Generator().manual_seed(n)
+    M = torch.randn(n, n, generator=g)
+    S = (M + M.T).double().numpy()
+    ref = np.linalg.eigvalsh(S)
+    scale = np.abs(ref).max()
+    w = {}
+    for tag in ("on", "off"):
+        r = runs[tag]["sytrd"][str(n)]
+        d, e = np.array(r["d"], dtype=np.float64), np.array(r["e"], dtype=np.float64)[: n - 1]
+        w[tag] = scipy.linalg.eigvalsh_tridiagonal(d, e)
+        assert np.abs(w[tag] - ref).max() <= 5e-6 * scale, tag
+    assert np.abs(w["on"] - w["off"]).max() <= 5e-6 * scale
+    assert runs["on"]["sytrd"][str(n)] != runs["off"]["sytrd"][str(n)]   # (the knob did select another kernel)

@@ -14,6 +14,8 @@
 // and cannot deadlock).  Each task is one 256-thread workgroup (four waves, each a quarter of the columns).
 //
 // The reflectors are kept for the back-transformation: v(s,k) at R2[s][R_k], tau at tau2[s][k].
+#include <cstdlib>
+
 #include "common.h"
 #include "device_utils.h"
 #include "eig_internal.h"
@@ -48,50 +50,55 @@ __device__ __forceinline__ float rlu(float v, int l) {
 // phases on LDS-resident blocks: 12 us per wavefront step; one wave with the blocks in registers and
 // v_readlane broadcasts, no barrier: 11.5 us of which 6.7 us were that single wave's 512 FMAs + 450
 // readlanes and 4.7 us the serialised loads - scripts/probe/run_variant_sb2st.py.)
-__global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB, int n, int t, int s_lo,
-                                                         float *__restrict__ R2, int64_t ldr, float *__restrict__ tau2,
-                                                         int nk, int rmod) {
-  __shared__ __attribute__((aligned(16))) float sE[NB * LDT];
-  __shared__ __attribute__((aligned(16))) float sD[NB * LDT];
-  __shared__ float red[3][4][NB];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = s_lo + blockIdx.x;
-  const int k = t - 2 * s;
-  const int c0 = s + 1 + k * NB;
-  const int L = (n - c0) < NB ? (n - c0) : NB;
-  if (k < 0 || L <= 0 || s > n - 3) return;
-  const int q0 = 16 * wave;
+struct Sb2stLds {
+  float sE[NB * LDT];
+  float sD[NB * LDT];
+  float red[3][4][NB];
+};
 
-  // ---- load: wave w takes band rows r = w, w + 4, ...; every address is inside the band array whatever
-  // r, lane and k are, so the loads are unconditional (all in flight at once) and masked afterwards
-  float pv = 0.f, ptau = 0.f, x = 0.f;
-  if (k > 0) {
-    pv = R2[(int64_t)(s % rmod) * ldr + (c0 - NB + lane)];
-    ptau = tau2[(int64_t)s * nk + (k - 1)];
-  } else {
-    x = lane < L ? AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] : 0.f;  // column s of the band
-  }
-#if SB2ST_VARIANT != 2
+// COH (the persistent kernel): agent-scope (sc1) accesses -- loads that miss the L1 and see what other workgroups
+// stored, stores that are written through.
+template <bool COH>
+__device__ __forceinline__ float band_ld(const float *p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void band_st(float *p, float v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+struct Sb2stRows {
   float ev[NB / 4], dv[NB / 4];
+};
+
+// band rows r = wave, wave + 4, ...: every address is inside the band array whatever r, lane and k are, so the loads
+// are unconditional (all in flight at once) and masked afterwards
+template <bool COH>
+__device__ __forceinline__ void sb2st_load(const float *__restrict__ AB, int c0, int L, int wave, int lane, Sb2stRows &t) {
 #pragma unroll
   for (int rr = 0; rr < NB / 4; ++rr) {
     const int r = 4 * rr + wave;
     const float *row = AB + (int64_t)(c0 + (r < L ? r : 0)) * LDAB;
-    ev[rr] = row[NB - r + lane];                                   // E[r][lane]
-    dv[rr] = row[lane <= r ? 2 * NB - r + lane : 2 * NB];          // D[r][lane], lane <= r
+    t.ev[rr] = band_ld<COH>(row + (NB - r + lane));                                   // E[r][lane]
+    t.dv[rr] = band_ld<COH>(row + (lane <= r ? 2 * NB - r + lane : 2 * NB));          // D[r][lane], lane <= r
   }
   __builtin_amdgcn_sched_barrier(0);   // keep the consumers behind ALL loads (hipcc hoists the first one otherwise)
-#endif
+}
+
+// Blocks in registers -> LDS, the task's arithmetic, results back in LDS (rows of E and D as they go back to the band).
+// x: column s of the band for k = 0.  (pv, ptau): reflector of task k - 1 in, of task k out.  Returns beta.
+__device__ __forceinline__ float sb2st_core(int k, int L, int wave, int lane, const Sb2stRows &t, float x, float &pv, float &ptau,
+                                            Sb2stLds &lds) {
+  float *sE = lds.sE, *sD = lds.sD;
+  auto &red = lds.red;
+  const int q0 = 16 * wave;
 #pragma unroll
   for (int rr = 0; rr < NB / 4; ++rr) {
     const int r = 4 * rr + wave;
     const bool in = r < L;
-#if SB2ST_VARIANT == 2   // timing attribution only (results invalid): no block loads
-    const float e1 = in ? 0.001f * (r + lane) : 0.f, d1 = in ? 0.002f * (r - lane) : 0.f;
-#else
-    const float e1 = (in && k > 0) ? ev[rr] : 0.f, d1 = in ? dv[rr] : 0.f;
-#endif
+    const float e1 = (in && k > 0) ? t.ev[rr] : 0.f, d1 = in ? t.dv[rr] : 0.f;
     sE[r * LDT + lane] = e1;
     if (lane <= r) {
       sD[r * LDT + lane] = d1;
@@ -100,7 +107,6 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
   }
   __syncthreads();
 
-#if SB2ST_VARIANT != 1     // (variant 1: timing attribution only, results invalid: no compute)
   float er[16], d[16];
 #pragma unroll
   for (int c4 = 0; c4 < 4; ++c4) {
@@ -161,8 +167,6 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
 #pragma unroll
     for (int j = 0; j < 16; ++j) er[j] -= v * rlu(z, q0 + j);
     if (wave == 0 && lane < L) er[0] = (lane == 0) ? beta : 0.f;  // exact zeros below the new sub-band entry
-  } else if (wave == 0 && lane < L) {
-    AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] = (lane == 0) ? beta : 0.f;
   }
   // w = p - tau/2 (p.v) v;  D -= v w^T + w v^T
   const float p = tau * ((red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]));
@@ -170,34 +174,195 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
   const float w = p - 0.5f * tau * pdotv * v;
 #pragma unroll
   for (int j = 0; j < 16; ++j) d[j] -= v * rlu(w, q0 + j) + w * vq[j];
-  // results back to LDS (rows), reflector to global memory
+  // results back to LDS (rows)
 #pragma unroll
   for (int c4 = 0; c4 < 4; ++c4) {
     if (k > 0)
       *reinterpret_cast<float4 *>(sE + lane * LDT + q0 + 4 * c4) = make_float4(er[4 * c4], er[4 * c4 + 1], er[4 * c4 + 2], er[4 * c4 + 3]);
     *reinterpret_cast<float4 *>(sD + lane * LDT + q0 + 4 * c4) = make_float4(d[4 * c4], d[4 * c4 + 1], d[4 * c4 + 2], d[4 * c4 + 3]);
   }
-  if (wave == 0) {
-    if (lane < L) R2[(int64_t)(s % rmod) * ldr + c0 + lane] = v;
-    if (lane == 0) tau2[(int64_t)s * nk + k] = tau;
-  }
-#endif
+  pv = v;
+  ptau = tau;
   __syncthreads();
+  return beta;
+}
 
-  // ---- store: lower part of D and E, same segments as loaded
+// band rows rr0 <= rr < rr1 of this wave (r = 4 rr + wave) from LDS back to the band: lower part of D, and E
+template <bool COH>
+__device__ __forceinline__ void sb2st_store(float *__restrict__ AB, int c0, int L, int k, int wave, int lane, int rr0, int rr1,
+                                            const Sb2stLds &lds) {
 #pragma unroll
   for (int rr = 0; rr < NB / 4; ++rr) {
     const int r = 4 * rr + wave;
-#if SB2ST_VARIANT == 2
-    if (r < L && sE[r * LDT + lane] == 12345.678f) {
-#else
-    if (r < L) {
-#endif
+    if (rr >= rr0 && rr < rr1 && r < L) {
       float *row = AB + (int64_t)(c0 + r) * LDAB;
-      if (k > 0) row[NB - r + lane] = sE[r * LDT + lane];
-      if (lane <= r) row[2 * NB - r + lane] = sD[r * LDT + lane];
+      if (k > 0) band_st<COH>(row + (NB - r + lane), lds.sE[r * LDT + lane]);
+      if (lane <= r) band_st<COH>(row + (2 * NB - r + lane), lds.sD[r * LDT + lane]);
     }
   }
+}
+
+// one launch per wavefront step t = 2 s + k (the fallback: VIVIT_SB2ST_PERSIST=0, or n < 960)
+__global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB, int n, int t, int s_lo,
+                                                         float *__restrict__ R2, int64_t ldr, float *__restrict__ tau2,
+                                                         int nk, int rmod) {
+  __shared__ __attribute__((aligned(16))) Sb2stLds lds;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s = s_lo + blockIdx.x;
+  const int k = t - 2 * s;
+  const int c0 = s + 1 + k * NB;
+  const int L = (n - c0) < NB ? (n - c0) : NB;
+  if (k < 0 || L <= 0 || s > n - 3) return;
+  float pv = 0.f, ptau = 0.f, x = 0.f;
+  if (k > 0) {
+    pv = R2[(int64_t)(s % rmod) * ldr + (c0 - NB + lane)];
+    ptau = tau2[(int64_t)s * nk + (k - 1)];
+  } else {
+    x = lane < L ? AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] : 0.f;  // column s of the band
+  }
+  Sb2stRows rows;
+  sb2st_load<false>(AB, c0, L, wave, lane, rows);
+  const float beta = sb2st_core(k, L, wave, lane, rows, x, pv, ptau, lds);
+  if (wave == 0) {
+    if (k == 0 && lane < L) AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] = (lane == 0) ? beta : 0.f;
+    if (lane < L) R2[(int64_t)(s % rmod) * ldr + c0 + lane] = pv;
+    if (lane == 0) tau2[(int64_t)s * nk + k] = ptau;
+  }
+  sb2st_store<false>(AB, c0, L, k, wave, lane, 0, NB / 4, lds);
+}
+
+// ---- the whole chase as ONE persistent launch.  A workgroup takes a sweep and runs its tasks k = 0, 1, .. in order,
+// the reflector staying in registers.  What a task waits for is split by band row: rows 0..62 of task (s, k) are rows
+// 1..63 of (s - 1, k), only its last row is the first row of (s - 1, k + 1).  Sweep s - 1 therefore publishes two
+// counters (one 32-bit word in the spare last column of tau2's row: A << 16 | B):
+//   A = k + 1: the FIRST row of its task k is in memory (stored first, right behind the arithmetic);
+//   B = k + 1: all rows of its task k are.
+// Task (s, k) requests its 64 rows as soon as B >= k + 1 (true long ago: it is one level behind), polls A >= k + 2 while
+// they fly, then fetches the last row again.  The dependent chain of a wavefront step is then: first row stored ->
+// counter -> poll -> one row loaded -> arithmetic -> first row stored, with everything else off the path.
+// Band traffic is agent-scope (sc1) both ways.  (Plain stores inside an XCD with a write-through only at the hand-over
+// to the next XCD are NOT safe: bytes that no later sweep rewrites -- the zeros a sweep leaves in the first column of E
+// -- keep their line dirty in that XCD's L2, and an sc1 load that hits a dirty line returns its stale remainder after
+// other XCDs have rewritten it; and they were slower than write-through stores throughout: 607 against 493 ms.)
+// Sweeps are dealt to the XCDs in blocks of 32 consecutive sweeps (a ticket counter per XCD, taken in order: a waiting
+// sweep's predecessor is always running or done, whatever is resident), so most hand-overs stay inside one L2.
+// Spins are bounded (2 s): the grid always drains; a timeout poisons d with NaN so that the solve fails loudly.
+struct Sb2stCtl {
+  int ticket[8];
+  int arrive, mask, dead, pad;
+};
+
+__global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ AB, int n, float *__restrict__ R2, int64_t ldr,
+                                                            float *__restrict__ tau2, int nk, int rmod, Sb2stCtl *ctl) {
+  __shared__ __attribute__((aligned(16))) Sb2stLds lds;
+  __shared__ int s_info[4];   // 0: sweep, 1: dead, 2: index of the XCD among those present, 3: number of XCDs
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto prog = [&](int s) { return reinterpret_cast<int *>(tau2 + (int64_t)s * nk + (nk - 1)); };
+  // ---- who is where: every workgroup registers its XCD, all wait for all (once)
+  if (tid == 0) {
+    int xcc;
+    __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15;
+    __hip_atomic_fetch_or(&ctl->mask, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&ctl->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int dead = 0;
+    while (__hip_atomic_load(&ctl->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x)
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { dead = 1; break; }
+    const int mask = __hip_atomic_load(&ctl->mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_info[1] = dead;
+    s_info[2] = __builtin_popcount(mask & ((1 << xcc) - 1));
+    s_info[3] = __builtin_popcount(mask);
+    if (dead) __hip_atomic_store(&ctl->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int xi = s_info[2], nx = s_info[3];
+  // thread 0: wait until counter `A` (hi = true) or `B` of sweep sp has reached `need`
+  int seenA = 0, seenB = 0;
+  auto wait_for = [&](int sp, bool hi, int need) {
+    int &seen = hi ? seenA : seenB;
+    if (seen >= need) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int spins = 0;
+    while (true) {
+      const int raw = __hip_atomic_load(prog(sp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      seenA = raw >> 16;
+      seenB = raw & 0xffff;
+      if (seen >= need) break;
+      if ((++spins & 1023) == 0 && (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull ||
+                                    __hip_atomic_load(&ctl->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        s_info[1] = 1;
+        __hip_atomic_store(&ctl->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  };
+  while (!s_info[1]) {
+    // ---- next sweep of this XCD: ticket i -> block (i / 32) * nx + xi, sweep 32 * block + i % 32
+    if (tid == 0) {
+      const int i = __hip_atomic_fetch_add(&ctl->ticket[xi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_info[0] = 32 * ((i >> 5) * nx + xi) + (i & 31);
+    }
+    __syncthreads();
+    const int s = s_info[0];
+    if (s > n - 3) break;
+    const int ks = (n - s - 2) / NB + 1;                   // tasks of this sweep:  s + 1 + k NB < n
+    const int kprev = s > 0 ? (n - s - 1) / NB + 1 : 0;    // tasks of sweep s - 1 (>= ks)
+    seenA = seenB = 0;
+    float pv = 0.f, ptau = 0.f;
+    for (int k = 0; k < ks; ++k) {
+      const int c0 = s + 1 + k * NB;
+      const int L = (n - c0) < NB ? (n - c0) : NB;
+      if (tid == 0 && s > 0) wait_for(s - 1, false, k + 1);
+      __syncthreads();   // (also: the previous task's LDS reads are done)
+      if (s_info[1]) break;
+      Sb2stRows rows;
+      sb2st_load<true>(AB, c0, L, wave, lane, rows);
+      if (tid == 0 && s > 0) wait_for(s - 1, true, k + 2 < kprev ? k + 2 : kprev);
+      __syncthreads();
+      if (s_info[1]) break;
+      if (wave == 3 && L == NB) {   // the last row again, now that its owner has stored it
+        const float *row = AB + (int64_t)(c0 + NB - 1) * LDAB;
+        rows.ev[NB / 4 - 1] = band_ld<true>(row + (1 + lane));
+        rows.dv[NB / 4 - 1] = band_ld<true>(row + (NB + 1 + lane));
+      }
+      float x = 0.f;
+      if (k == 0) x = lane < L ? band_ld<true>(AB + (int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)) : 0.f;  // column s of the band
+      const float beta = sb2st_core(k, L, wave, lane, rows, x, pv, ptau, lds);
+      // ---- first row out, counter A
+      if (wave == 0) {
+        if (k == 0 && lane == 0) band_st<true>(AB + (int64_t)c0 * LDAB + (2 * NB - 1), beta);
+        sb2st_store<true>(AB, c0, L, k, wave, lane, 0, 1, lds);
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(prog(s), ((k + 1) << 16) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the rest of column s (zeros), the reflector for the back-transformation
+        if (k == 0 && lane >= 1 && lane < L) band_st<true>(AB + (int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane), 0.f);
+        if (lane < L) R2[(int64_t)(s % rmod) * ldr + c0 + lane] = pv;
+        if (lane == 0) tau2[(int64_t)s * nk + k] = ptau;
+        sb2st_store<true>(AB, c0, L, k, wave, lane, 1, NB / 4, lds);
+      } else {
+        sb2st_store<true>(AB, c0, L, k, wave, lane, 0, NB / 4, lds);
+      }
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's band rows are in memory
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(prog(s), ((k + 1) << 16) | (k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sb2st_zero_kernel(float *__restrict__ tau2, int n, int nk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n - 1) tau2[(int64_t)i * nk + (nk - 1)] = 0.f;                  // progress counters
+  if (i < nk) tau2[(int64_t)(n - 1) * nk + i] = 0.f;                       // control block
+}
+
+__global__ void sb2st_poison_kernel(const Sb2stCtl *ctl, int n, float *__restrict__ d) {
+  if (ctl->dead) d[0] = __builtin_nanf("");
+  if (n < 0) printf("sb2st persist: mask 0x%x dead %d tickets %d %d %d %d %d %d %d %d\n", ctl->mask, ctl->dead, ctl->ticket[0], ctl->ticket[1],
+                    ctl->ticket[2], ctl->ticket[3], ctl->ticket[4], ctl->ticket[5], ctl->ticket[6], ctl->ticket[7]);
 }
 
 __global__ __launch_bounds__(256) void sb2st_extract_kernel(const float *__restrict__ AB, int n, float *__restrict__ d,
@@ -216,10 +381,30 @@ int64_t sb2st_ring_rows(int64_t n) { const int64_t need = n / NB + 64; return ne
 // uses row s % r2rows (r2rows = n keeps every reflector for the back-transformation; a ring of
 // SB2ST_RING rows is enough for the chase itself when only eigenvalues are wanted);
 // tau2: [n][sb2st_num_levels(n)].
+static bool sb2st_persist_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("VIVIT_SB2ST_PERSIST");
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
+
 int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ldr, int64_t r2rows, float *tau2,
                  hipStream_t stream) {
   const int ni = (int)n;
   const int nk = sb2st_num_levels(n);
+  // persistent form: the progress counters sit in tau2's last column (never a task: k < nk - 1), the control block in
+  // its unused last row (sweeps end at n - 3)
+  const bool persist = sb2st_persist_enabled() && n >= 960 && (size_t)nk * sizeof(float) >= sizeof(Sb2stCtl);
+  if (n >= 3 && persist) {
+    Sb2stCtl *ctl = reinterpret_cast<Sb2stCtl *>(tau2 + (n - 1) * nk);
+    sb2st_zero_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(tau2, ni, nk);
+    sb2st_persist_kernel<<<256, 256, 0, stream>>>(AB, ni, R2, ldr, tau2, nk, (int)r2rows, ctl);
+    sb2st_extract_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(AB, ni, d, e);
+    sb2st_poison_kernel<<<1, 1, 0, stream>>>(ctl, getenv("VIVIT_SB2ST_DEBUG") ? -ni : ni, d);
+    return launch_status();
+  }
   if (n >= 3) {
     const int64_t tmax = 2 * (n - 3) + nk;
     for (int64_t t = 0; t <= tmax; ++t) {

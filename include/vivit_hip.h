@@ -254,6 +254,31 @@ size_t vivit_sy2sb_f32_workspace_bytes(int64_t n);
 int vivit_sy2sb_f32(float *A, int64_t n, int64_t lda, float *AB, float *tau1, void *workspace,
                     size_t workspace_bytes, void *stream);
 
+/* The pieces of the two-stage solver around a band reduction that is done by the CALLER -- the multi-GPU path
+ * (vivit_amd/distributed.py:sy2sb_sharded): the trailing matrix is sharded by block columns over the
+ * ranks, the sub-band panel is broadcast and factored by every rank, the rest of the solve runs as in
+ * vivit_symeig_rows_f32.
+ *   vivit_symeig_prepare_f32: LAPACK-style scaling of A + mirror of the lower triangle (A then has BOTH triangles);
+ *     scal: DEVICE float[16] (scal[1] = the factor applied, scal[2] = non-finite-input flag), to be handed to
+ *     vivit_symeig_banded_rows_f32.  workspace: 8 n + 256 bytes.
+ *   vivit_sy2sb_panel_qr_f32: Householder QR of one panel, pan: [mp][NB] row-major (NB = vivit_sb2st_half_bandwidth()),
+ *     factored in place: R's strict upper triangle in rows 0..NB-1, its diagonal in betas[NB].  Vt: [NB][ldv] receives
+ *     the reflectors as ROWS (Vt[c][r] = v_c[r], v_c[c] = 1, zeros in front), tau: [NB], T: [NB][NB] upper triangular
+ *     with Q = I - V T V^T (LAPACK larft, forward / columnwise).
+ *   vivit_symeig_banded_rows_f32: A as vivit_sy2sb_f32 leaves it (band in A[i][j], 0 <= i-j <= NB; reflector c of
+ *     panel p in A[p*NB + c][(p+1)*NB + c ..]), tau1: DEVICE [n]; continues with bulge chasing, divide & conquer and the
+ *     two back-transformations restricted to the eigenvectors row_begin .. row_end-1 (ROWS of Zt, as
+ *     vivit_symeig_rows_f32).  Workspace of vivit_symeig_f32(want_vectors = 1).  n > 2 NB.
+ * Replace the same Tensor.symeig(eigenvectors=True) call sites as vivit_symeig_f32. */
+int vivit_symeig_prepare_f32(float *A, int64_t n, int64_t lda, float *scal, void *workspace, size_t workspace_bytes,
+                             void *stream);
+size_t vivit_sy2sb_panel_qr_f32_workspace_bytes(int64_t mp);
+int vivit_sy2sb_panel_qr_f32(float *pan, int64_t mp, float *Vt, int64_t ldv, float *tau, float *betas, float *T,
+                             void *workspace, size_t workspace_bytes, void *stream);
+int vivit_symeig_banded_rows_f32(float *A, int64_t n, int64_t lda, const float *tau1, const float *scal, float *w,
+                                 float *Zt, int64_t ldz, int64_t row_begin, int64_t row_end, void *workspace,
+                                 size_t workspace_bytes, int32_t *info, void *stream);
+
 /* Stage 1b of the two-stage path, exported for testing: symmetric BAND -> tridiagonal by bulge
  * chasing.  Half bandwidth NB = vivit_sb2st_half_bandwidth() (64).  AB: [n][2*NB+1] row-band
  * layout, AB[i][j - i + 2*NB] = A[i][j] for i - 2*NB <= j <= i (entries with i - j > NB must be

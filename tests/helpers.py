@@ -122,6 +122,66 @@ class OracleBackend:
         w, Z = self.symeig(G, True)
         return w, Z.T[row_begin:row_end].contiguous()
 
+    # ---- the pieces of the sharded band reduction (vivit_amd/distributed.py:sy2sb_sharded_), LAPACK conventions in fp64
+    def symeig_prepare_(self, A):
+        A.copy_(torch.tril(A) + torch.tril(A, -1).T)
+        scal = torch.zeros(16)
+        scal[1] = 1.0
+        return scal
+
+    def panel_qr_(self, pan):
+        NB = 64
+        mp = pan.shape[0]
+        x = pan.double()
+        Vt = torch.zeros(NB, mp, dtype=torch.float64)
+        tau = torch.zeros(NB, dtype=torch.float64)
+        betas = torch.zeros(NB, dtype=torch.float64)
+        for c in range(min(mp, NB)):
+            alpha = x[c, c].item()
+            ssq = float((x[c + 1:, c] ** 2).sum())
+            beta, t, sc = alpha, 0.0, 0.0
+            if ssq > 0.0:
+                beta = -float(np.copysign(np.sqrt(alpha * alpha + ssq), alpha))
+                t = (beta - alpha) / beta
+                sc = 1.0 / (alpha - beta)
+            v = torch.zeros(mp, dtype=torch.float64)
+            v[c] = 1.0
+            v[c + 1:] = x[c + 1:, c] * sc
+            z = t * (v @ x)
+            z[: c + 1] = 0.0
+            x -= torch.outer(v, z)
+            Vt[c], tau[c], betas[c] = v, t, beta
+        T = torch.zeros(NB, NB, dtype=torch.float64)
+        for j in range(NB):   # larft, forward / columnwise: Q = H_0 H_1 ... = I - V T V^T
+            T[j, j] = tau[j]
+            if j:
+                T[:j, j] = -tau[j] * (T[:j, :j] @ (Vt[:j] @ Vt[j]))
+        pan.copy_(x.float())
+        return Vt.float(), tau.float(), betas.float(), T.float()
+
+    def symeig_banded_rows(self, A, tau1, scal, row_begin, row_end):
+        NB = 64
+        n = A.shape[0]
+        Ad = A.double()
+        B = torch.zeros(n, n, dtype=torch.float64)
+        for i in range(n):
+            lo = max(0, i - NB)
+            B[i, lo: i + 1] = Ad[i, lo: i + 1]
+        B = B + torch.tril(B, -1).T
+        w, Z = torch.linalg.eigh(B)
+        # Q1 = product of the panel reflectors in generation order; eigenvectors of the full matrix = Q1 Z
+        refl = []
+        for j0 in range(0, n - NB, NB):
+            gi = j0 + NB
+            for c in range(min(NB, n - gi)):
+                v = torch.zeros(n, dtype=torch.float64)
+                v[gi + c] = 1.0
+                v[gi + c + 1:] = Ad[j0 + c, gi + c + 1:]
+                refl.append((v, float(tau1[j0 + c])))
+        for v, t in reversed(refl):
+            Z -= t * torch.outer(v, v @ Z)
+        return (w / float(scal[1])).float(), Z.T[row_begin:row_end].float().contiguous()
+
     def pack_lower(self, G):
         i, j = torch.tril_indices(G.shape[0], G.shape[0])
         return G[i, j].contiguous()

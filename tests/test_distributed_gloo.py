@@ -255,6 +255,41 @@ def _worker_dp_linalg(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _worker_sharded_band(rank, world, port, ret):
+    """The eigensolver with the full -> band reduction sharded by block rows: same spectrum and valid
+    eigenvectors as the plain solve, bit-identical on every rank, band equal to the single-process reduction."""
+    _setup(rank, world, port)
+    from vivit_amd import distributed as vd, kernels
+
+    ok = {}
+    solo = [dist.new_group([r]) for r in range(world)][rank]   # (collective: every rank creates every group, same order)
+    for n in (130, 200, 333):   # 3, 4 and 6 row blocks of 64 (the last one partial)
+        g = torch.Generator().manual_seed(n)
+        M = torch.randn(n, n, generator=g)
+        S = (M + M.T) / 2
+        w_ref = torch.linalg.eigvalsh(S.double())
+        scale = float(w_ref.abs().max())
+        w, Z = vd.symeig(S, sharded_reduction=True)
+        ok[f"vals{n}"] = bool((w.double() - w_ref).abs().max() <= 2e-5 * scale)
+        Zd = Z.double()
+        ok[f"resid{n}"] = bool((S.double() @ Zd - Zd * w.double()).abs().max() <= 5e-5 * scale)
+        ok[f"orth{n}"] = bool((Zd.T @ Zd - torch.eye(n, dtype=torch.float64)).abs().max() <= 5e-5)
+        both = [torch.empty_like(Z) for _ in range(world)]
+        dist.all_gather(both, Z.contiguous())
+        ok[f"same{n}"] = all(torch.equal(both[0], b) for b in both)
+        # the band itself against a single-process reduction with the same panel kernel (world of one)
+        A = S.clone()
+        kernels.symeig_prepare_(A)
+        tau1 = vd.sy2sb_sharded_(A, None if world == 1 else dist.group.WORLD)
+        A1 = S.clone()
+        kernels.symeig_prepare_(A1)
+        tau1_solo = vd.sy2sb_sharded_(A1, solo)
+        band = lambda X: torch.tril(X) - torch.tril(X, -65)   # noqa: E731
+        ok[f"band{n}"] = bool((band(A) - band(A1)).abs().max() <= 2e-5 * scale) and bool((tau1 - tau1_solo).abs().max() <= 1e-5)
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
 def _run(worker, world):
     port = 29000 + (os.getpid() % 2000) + world
     mgr = mp.Manager()
@@ -284,4 +319,11 @@ def test_data_parallel_newton_step_world2():
 def test_data_parallel_linalg_world2():
     ret = _run(_worker_dp_linalg, 2)
     for r in range(2):
+        assert r in ret and all(ret[r].values()), ret
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_band_reduction(world):
+    ret = _run(_worker_sharded_band, world)
+    for r in range(world):
         assert r in ret and all(ret[r].values()), ret

@@ -52,6 +52,10 @@ SIGNATURES = {
     "vivit_sytrd_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
     "vivit_sy2sb_f32_workspace_bytes": (_sz, [_i64]),
     "vivit_sy2sb_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _sz, _ptr]),
+    "vivit_symeig_prepare_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _sz, _ptr]),
+    "vivit_sy2sb_panel_qr_f32_workspace_bytes": (_sz, [_i64]),
+    "vivit_sy2sb_panel_qr_f32": (_int, [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
+    "vivit_symeig_banded_rows_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _sz, _ptr, _ptr]),
     "vivit_sb2st_half_bandwidth": (_int, []),
     "vivit_sb2st_f32_workspace_bytes": (_sz, [_i64]),
     "vivit_sb2st_f32": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
@@ -70,7 +74,7 @@ SIGNATURES = {
     "vivit_unpack_lower_f32": (_int, [_ptr, _i64, _ptr, _i64, _ptr]),
 }
 
-ABI_VERSION = 1004  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
+ABI_VERSION = 1005  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
 
 _lib = None
 

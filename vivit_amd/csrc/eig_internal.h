@@ -63,6 +63,14 @@ int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq,
 size_t sy2sb_workspace_bytes(int64_t n);
 int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_out, hipStream_t stream);
 int sy2sb_extract_band_launch(const float *A, int64_t lda, int64_t n, float *AB, hipStream_t stream);
+size_t sy2sb_panel_qr_workspace_bytes(int64_t mp);
+int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float *tau, float *betas, float *T, void *wsbase,
+                          size_t ws_bytes, hipStream_t stream);
+// symeig_large.hip: the two-stage solver entered AFTER the band reduction (A holds band + first-stage reflectors, as
+// sy2sb_launch leaves it; tau1, scal: device) -- rows r0 .. r1-1 of the eigenvector matrix
+int symeig_banded_rows_launch(float *A, int64_t n, int64_t lda, const float *tau1, const float *scal_in, float *w, float *Zt,
+                              int64_t ldz, int64_t r0, int64_t r1, void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream);
+int symeig_prepare_launch(float *A, int64_t n, int64_t lda, float *scal, void *ws, size_t ws_bytes, hipStream_t stream);
 int sb2st_num_levels(int64_t n);
 int64_t sb2st_ring_rows(int64_t n);
 int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ldr, int64_t r2rows, float *tau2,

@@ -420,6 +420,45 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
   return launch_status();
 }
 
+// ---- the panel factorisation on its own (the multi-GPU band reduction, vivit_amd/distributed.py: every rank factors
+// the broadcast panel itself, the trailing matrix is sharded).  pan: [mp][SNB] row-major, factored in place (R above the
+// diagonal of its first SNB rows, diagonal in betas); Vt: [SNB][ldv] k-major reflectors (row c = v_c, v_c[c] = 1, zeros
+// before); tau: [SNB]; T: [SNB][SNB] upper triangular, Q = I - V T V^T.
+size_t sy2sb_panel_qr_workspace_bytes(int64_t mp) {
+  const int64_t nwg = cdiv(mp, QT) + 1;
+  return align_up(sizeof(float) * 2 * nwg * SNB, 256) + align_up(sizeof(float) * 2 * SNB, 256) + align_up(sizeof(float) * SNB * SNB, 256) +
+         align_up(gemm_workspace_bytes(SNB, SNB, mp, false), 256) + 1024;
+}
+
+int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float *tau, float *betas, float *T, void *wsbase,
+                          size_t ws_bytes, hipStream_t stream) {
+  if (ws_bytes < sy2sb_panel_qr_workspace_bytes(mp)) return VIVIT_E_WORKSPACE;
+  char *p = reinterpret_cast<char *>(align_up(reinterpret_cast<uintptr_t>(wsbase), 256));
+  auto take = [&](size_t bytes) {
+    char *r = p;
+    p += align_up(bytes, 256);
+    return r;
+  };
+  const int64_t nwg = cdiv(mp, QT) + 1;
+  QrPart qp;
+  qp.u = (float *)take(sizeof(float) * 2 * nwg * SNB);
+  qp.diag = (float *)take(sizeof(float) * 2 * SNB);
+  float *S = (float *)take(sizeof(float) * SNB * SNB);
+  const size_t gws_bytes = gemm_workspace_bytes(SNB, SNB, mp, false);
+  void *gws = take(gws_bytes);
+  const int ncol = (int)(mp < SNB ? mp : SNB);
+  const int g = (int)cdiv(mp, QT);
+  if (hipMemsetAsync(tau, 0, sizeof(float) * SNB, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+  if (hipMemsetAsync(betas, 0, sizeof(float) * SNB, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+  if (hipMemset2DAsync(Vt, sizeof(float) * ldv, 0, sizeof(float) * mp, SNB, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+  for (int c = -1; c < ncol; ++c)  // (reflector row of "A" = the same row of Vt: written twice with the same values)
+    qr_step_kernel<<<g, 256, 0, stream>>>(pan, mp, c, ncol, g, qp, Vt, Vt, ldv, 0, Vt, ldv, 0, tau, betas);
+  int st = gemm_launch(LAY_K, LAY_K, Vt, Vt, S, SNB, SNB, mp, ldv, ldv, SNB, 1.f, 0.f, false, gws, gws_bytes, stream);
+  if (st != VIVIT_OK) return st;
+  larft_kernel<<<1, SNB, 0, stream>>>(S, tau, SNB, ncol, T);
+  return launch_status();
+}
+
 int sy2sb_extract_band_launch(const float *A, int64_t lda, int64_t n, float *AB, hipStream_t stream) {
   sb_extract_band_kernel<<<(unsigned)cdiv(n * (2 * SNB + 1), 256), 256, 0, stream>>>(A, lda, n, AB);
   return launch_status();
@@ -447,6 +486,16 @@ int vivit_sy2sb_f32(float *A, int64_t n, int64_t lda, float *AB, float *tau1, vo
   if (st != VIVIT_OK) return st;
   if (hipMemcpyAsync(tau1, t1, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return VIVIT_E_LAUNCH;
   return VIVIT_OK;
+}
+
+size_t vivit_sy2sb_panel_qr_f32_workspace_bytes(int64_t mp) { return mp > 0 ? sy2sb_panel_qr_workspace_bytes(mp) : 0; }
+
+// Householder QR of one sub-band panel (see sy2sb_panel_qr_launch): the replicated step of the multi-GPU band reduction.
+int vivit_sy2sb_panel_qr_f32(float *pan, int64_t mp, float *Vt, int64_t ldv, float *tau, float *betas, float *T, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+  if (mp < 1 || !pan || !Vt || !tau || !betas || !T || ldv < mp) return VIVIT_E_BADARG;
+  if (!workspace) return VIVIT_E_WORKSPACE;
+  return sy2sb_panel_qr_launch(pan, mp, Vt, ldv, tau, betas, T, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 } // extern "C"

@@ -538,11 +538,80 @@ int symeig_large_rows_launch(float *A, int64_t n, int64_t lda, float *w, float *
   return symeig_large_impl(A, n, lda, w, Zt, ldz, r0, r1, ws, ws_bytes, info, stream);
 }
 
+// ---- the two-stage solver in two halves, for a band reduction done elsewhere (multi-GPU: vivit_amd/distributed.py).
+// prepare: LAPACK-style scaling + mirror (what symeig_large_impl does in front of sy2sb_launch); scal: device [16].
+int symeig_prepare_launch(float *A, int64_t n, int64_t lda, float *scal, void *ws, size_t ws_bytes, hipStream_t stream) {
+  if (ws_bytes < sizeof(float) * 2 * (size_t)n + 256) return VIVIT_E_WORKSPACE;
+  float *part = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+  int st = prescale_launch(A, n, lda, scal, part, stream);
+  if (st != VIVIT_OK) return st;
+  return symmetrize_launch(A, n, lda, stream);
+}
+
+int symeig_banded_rows_launch(float *A, int64_t n, int64_t lda, const float *tau1, const float *scal_in, float *w, float *Zt,
+                              int64_t ldz, int64_t r0, int64_t r1, void *ws, size_t ws_bytes, int32_t *info, hipStream_t stream) {
+  if (!Zt || r0 < 0 || r1 < r0 || r1 > n || n <= 2 * TS_NB) return VIVIT_E_BADARG;
+  if (!ws || ws_bytes < symeig_large_workspace_bytes(n, true)) return VIVIT_E_WORKSPACE;
+  if (hipMemsetAsync(info, 0, sizeof(int32_t), stream) != hipSuccess) return VIVIT_E_LAUNCH;
+  char *p = reinterpret_cast<char *>(align_up(reinterpret_cast<uintptr_t>(ws), 256));
+  auto take = [&](size_t bytes) {
+    char *r = p;
+    p += align_up(bytes, 256);
+    return r;
+  };
+  float *scal = (float *)take(sizeof(float) * 16);
+  float *AB = (float *)take(sizeof(float) * n * (2 * TS_NB + 1));
+  float *R2 = (float *)take(sizeof(float) * n * n);
+  const size_t tau2_bytes = sizeof(float) * n * sb2st_num_levels(n);
+  float *tau2 = (float *)take(tau2_bytes);
+  float *d = (float *)take(sizeof(float) * n);
+  float *e = (float *)take(sizeof(float) * n);
+  if (hipMemcpyAsync(scal, scal_in, sizeof(float) * 16, hipMemcpyDeviceToDevice, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+  prof_mark(PROF_STAGE_BEGIN, stream);
+  int st = sy2sb_extract_band_launch(A, lda, n, AB, stream);
+  if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_SY2SB, stream);
+  if (hipMemsetAsync(tau2, 0, tau2_bytes, stream) != hipSuccess) return VIVIT_E_LAUNCH;
+  st = sb2st_launch(AB, n, d, e, R2, n, n, tau2, stream);
+  if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_SB2ST, stream);
+  void *dc_base = take(stedc_workspace_bytes(n, true));
+  float *Qt, *dd;
+  int *order;
+  st = stedc_dc_launch(d, e, n, dc_base, &Qt, &dd, &order, info, stream);
+  if (st != VIVIT_OK) return st;
+  void *q2ws = take(q2_workspace_bytes(n));
+  st = dc_rows_launch(n, dd, Qt, n, order, w, Zt, ldz, r0, r1, scal, stream);
+  if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_TRIDIAG, stream);
+  st = q2_apply_launch(Zt, ldz, r1 - r0, n, R2, n, tau2, q2ws, stream);
+  if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_Q2, stream);
+  st = backtransform_launch(A, n, lda, tau1, TS_NB, n - TS_NB - 1, Zt, ldz, r1 - r0, take, stream);
+  if (st != VIVIT_OK) return st;
+  prof_mark(PROF_STAGE_Q1, stream);
+  return info_scal_launch(info, n, scal, stream);
+}
+
 } // namespace vivit
 
 using namespace vivit;
 
 extern "C" {
+
+// The two halves of the two-stage solver around an externally computed band reduction (see vivit_hip.h).
+int vivit_symeig_prepare_f32(float *A, int64_t n, int64_t lda, float *scal, void *workspace, size_t workspace_bytes, void *stream) {
+  if (n < 1 || !A || !scal || lda < n || !workspace) return VIVIT_E_BADARG;
+  return symeig_prepare_launch(A, n, lda, scal, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int vivit_symeig_banded_rows_f32(float *A, int64_t n, int64_t lda, const float *tau1, const float *scal, float *w, float *Zt,
+                                 int64_t ldz, int64_t row_begin, int64_t row_end, void *workspace, size_t workspace_bytes,
+                                 int32_t *info, void *stream) {
+  if (n < 1 || !A || !tau1 || !scal || !w || !info || lda < n || ldz < n) return VIVIT_E_BADARG;
+  return symeig_banded_rows_launch(A, n, lda, tau1, scal, w, Zt, ldz, row_begin, row_end, workspace, workspace_bytes, info,
+                                   static_cast<hipStream_t>(stream));
+}
 
 size_t vivit_sytrd_f32_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;

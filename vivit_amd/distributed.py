@@ -17,10 +17,11 @@ forward/backward on its batch shard ``N_g`` and holds the sqrt-GGN factors of *i
   the only form that exists for BASELINE config 5): all-gather the small factors, every rank computes its **block row**
   ``G[N_g, :] = (z_g z^T) o (s_g s^T)`` (``1/R`` of the flops), block rows are all-gathered and stored class-major.
 
-The eigensolver's reduction and tridiagonal solve then run replicated (deterministic, no atomics: bit-identical on all
-ranks, nothing is broadcast); its back-transformations act on every eigenvector independently, so rank ``r``
-back-transforms the ``r``-th slice (``vivit_symeig_rows_f32``) and one all-gather delivers the eigenvectors
-(:func:`symeig`).  Back-projections ``V v`` are true sums over samples: each rank applies its own rows of ``V`` and one
+The eigensolver: the full -> band reduction is sharded by block rows of the trailing matrix with a replicated panel
+factorisation (:func:`sy2sb_sharded_`: two collectives per panel); bulge chasing and the tridiagonal solve run replicated
+(deterministic, no atomics: bit-identical on all ranks, nothing is broadcast); the back-transformations act on every
+eigenvector independently, so rank ``r`` back-transforms the ``r``-th slice (``vivit_symeig_banded_rows_f32`` /
+``vivit_symeig_rows_f32``) and one all-gather delivers the eigenvectors (:func:`symeig`).  Back-projections ``V v`` are true sums over samples: each rank applies its own rows of ``V`` and one
 all-reduce of ``P`` floats finishes the Newton step (vivit/optim/directional_damped_newton.py:370-373;
 :func:`all_reduce_sum_`).
 
@@ -100,6 +101,22 @@ def all_gather_cat(t: torch.Tensor, group=None, out: Optional[torch.Tensor] = No
     else:
         dist.all_gather_into_tensor(out, t, group=group)
     return out
+
+
+def broadcast_(t: torch.Tensor, src: int, group=None) -> torch.Tensor:
+    """In place: rank ``src``'s contiguous ``t`` to every rank of ``group`` (``src``: rank within the group)."""
+    if not _active(group):
+        return t
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, gsrc, group=group)
+        t.copy_(h)
+    else:
+        if not t.is_contiguous():
+            raise ValueError("broadcast_ needs a contiguous tensor")
+        dist.broadcast(t, gsrc, group=group)
+    return t
 
 
 class _Done:
@@ -418,14 +435,128 @@ def backproject_sum(coef: torch.Tensor, V_local: torch.Tensor, acc: BatchSharded
     return out.view(K, *V_local.shape[2:])
 
 
-def symeig(G: torch.Tensor, group=None, overwrite: bool = False):
-    """Eigenvalues (ascending) and column eigenvectors of the (replicated) symmetric ``G`` with the
-    back-transformations sharded over the ranks of ``group``.
+SHARDED_BAND_MIN_N = 8192  # smallest n whose band reduction is sharded by default (below: replicated, as the tridiagonal stages)
+
+
+def sy2sb_sharded_(A: torch.Tensor, group=None) -> torch.Tensor:
+    """Band reduction of the replicated symmetric ``A`` (BOTH triangles valid: ``kernels.symeig_prepare_``) with the
+    trailing matrix SHARDED over the ranks -- in place: on return every rank's ``A`` holds the band
+    (``A[i][j]``, ``0 <= i - j <= 64``) and the first-stage reflectors exactly where the single-GPU
+    ``vivit_sy2sb_f32`` leaves them; returns ``tau1 [n]``.
+
+    Rows are dealt to the ranks in blocks of 64 (block ``b`` -> rank ``b % R``: the work stays balanced while the
+    trailing matrix shrinks) and, the matrix being symmetric and stored in full, a rank's rows ARE its block columns.
+    Panel ``p`` (the reference has no counterpart: ``Tensor.symeig`` is one LAPACK call, vivit/linalg/eigh.py:248-250):
+
+      1. the owner of row block ``p`` broadcasts it (``64 x (n - j0)`` floats: the diagonal block and, transposed, the
+         panel); every rank factors the panel itself (``vivit_sy2sb_panel_qr_f32``: same kernels, same data --
+         bit-identical ``V``, ``T`` everywhere, nothing else to exchange) and files band entries and reflectors;
+      2. ``P = A22 V``: every rank multiplies its own rows (``1/R`` of the streamed panel product), one all-gather
+         of ``mp x 64`` floats puts ``P`` together;
+      3. ``W = X - V (T^T (V^T X)) / 2`` with ``X = P T`` -- four 64-wide products, replicated;
+      4. ``A22 -= V W^T + W V^T`` on the own rows only (``1/R`` of the rank-128 update), no communication.
+
+    Two collectives per panel.  Replicated per rank: the panel QR (its launch chain is the part of the single-GPU band
+    reduction that does not shrink) and the small products; sharded: the two passes over the trailing matrix
+    (0.43 s + 0.34 s of 1.27 s at n = 40 960 on one GPU)."""
+    NB = kernels.BAND_NB
+    n = A.shape[0]
+    R, q = world_size(group), rank_of(group)
+    nblk = -(-n // NB)
+    dev = A.device
+    my_blocks = list(range(q, nblk, R))
+    rows_idx = torch.cat([torch.arange(b * NB, min((b + 1) * NB, n), device=dev) for b in my_blocks]) if my_blocks else \
+        torch.empty(0, dtype=torch.long, device=dev)
+    Aloc = A.index_select(0, rows_idx).contiguous()            # [n_loc, n]: the own rows (= block columns)
+    tau1 = torch.zeros(n, dtype=torch.float32, device=dev)
+    gi_last = None
+    for p in range(nblk):
+        j0, gi = p * NB, (p + 1) * NB
+        mp = n - gi
+        if mp <= 0:
+            break
+        owner = p % R
+        # ---- 1. row block p from its owner: [D | panel^T]
+        Bt = torch.empty((NB, n - j0), dtype=torch.float32, device=dev)
+        if q == owner:
+            lb = p // R
+            Bt.copy_(Aloc[lb * NB:(lb + 1) * NB, j0:])
+        broadcast_(Bt, owner, group)
+        pan = Bt[:, NB:].t().contiguous()                         # [mp, 64]
+        Vt, tau, betas, T = kernels.panel_qr_(pan)
+        A[j0:gi, j0:gi] = Bt[:, :NB]                              # diagonal block of the band
+        top = min(NB, mp)
+        A[gi:gi + top, j0:gi] = torch.triu(pan[:top], 1) + torch.diag(betas)[:top]   # R: the sub-diagonal block of the band
+        A[j0:gi, gi:] = Vt                                        # reflector rows (dead upper triangle)
+        tau1[j0:gi] = tau
+        # ---- 2. P = A22 V on the own live rows, all-gather
+        lb0 = 0 if p < q else (p - q) // R + 1                    # own blocks with global index <= p are finished
+        live = Aloc[lb0 * NB:, gi:]                               # [nl, mp] view (row stride n)
+        nl = live.shape[0]
+        nl_max = _max_live_rows(n, NB, R, p)
+        send = torch.zeros((nl_max, NB), dtype=torch.float32, device=dev)
+        if nl > 0:
+            kernels.gemm_nt(live, Vt, out=send[:nl])
+        gathered = all_gather_cat(send, group).view(R, nl_max, NB)
+        P = torch.empty((mp, NB), dtype=torch.float32, device=dev)
+        for r in range(R):
+            idx = _live_rows(n, NB, R, r, p, dev)
+            if idx.numel():
+                P.index_copy_(0, idx - gi, gathered[r, : idx.numel()])
+        # ---- 3. W (replicated, 64-wide)
+        X = kernels.gemm_nn(P, T)
+        S2 = kernels.gemm_nn(Vt, X)
+        Y = kernels.gemm_tn(T, S2)
+        W = kernels.gemm_tn(Vt, Y, out=X, alpha=-0.5, beta=1.0)   # W = X - V Y / 2
+        # ---- 4. own rows of the trailing matrix
+        if nl > 0:
+            loc = rows_idx[lb0 * NB:] - gi
+            Lm = torch.cat([Vt.t().index_select(0, loc), W.index_select(0, loc)], 1).contiguous()   # [nl, 128] = [V_l | W_l]
+            Rm = torch.cat([W, Vt.t()], 1).contiguous()                                              # [mp, 128] = [W | V]
+            kernels.gemm_nt(Lm, Rm, out=live, alpha=-1.0, beta=1.0)
+        gi_last = gi
+    # ---- what is left of the trailing matrix (at most one block): the last diagonal block of the band
+    if gi_last is not None and gi_last < n:
+        b = gi_last // NB
+        owner = b % R
+        m = n - gi_last
+        Dl = torch.empty((m, m), dtype=torch.float32, device=dev)
+        if q == owner:
+            lb = b // R
+            Dl.copy_(Aloc[lb * NB:lb * NB + m, gi_last:])
+        broadcast_(Dl, owner, group)
+        A[gi_last:, gi_last:] = Dl
+    return tau1
+
+
+def _live_rows(n: int, NB: int, R: int, r: int, p: int, device) -> torch.Tensor:
+    """Global indices of rank ``r``'s rows in blocks ``b > p`` (its share of the trailing matrix of panel ``p``)."""
+    nblk = -(-n // NB)
+    blocks = [b for b in range(r, nblk, R) if b > p]
+    if not blocks:
+        return torch.empty(0, dtype=torch.long, device=device)
+    return torch.cat([torch.arange(b * NB, min((b + 1) * NB, n), device=device) for b in blocks])
+
+
+def _max_live_rows(n: int, NB: int, R: int, p: int) -> int:
+    nblk = -(-n // NB)
+    best = 1
+    for r in range(R):
+        rows = sum(min((b + 1) * NB, n) - b * NB for b in range(r, nblk, R) if b > p)
+        best = max(best, rows)
+    return best
+
+
+def symeig(G: torch.Tensor, group=None, overwrite: bool = False, sharded_reduction: Optional[bool] = None):
+    """Eigenvalues (ascending) and column eigenvectors of the (replicated) symmetric ``G`` with the band reduction and
+    the back-transformations sharded over the ranks of ``group``.
 
     Every rank must hold the same ``G`` (e.g. the result of :func:`sharded_gram`).  Returns
     ``(evals [n], evecs [n, n])`` like ``kernels.symeig(G, eigenvectors=True)``; ``evecs`` is the
     transposed view of the gathered row-major eigenvector matrix (``evecs[:, i]`` contiguous).
-    """
+    ``sharded_reduction``: shard the full -> band reduction too (:func:`sy2sb_sharded_`); default: for
+    ``n >= SHARDED_BAND_MIN_N``.  Bulge chasing and the tridiagonal solve stay replicated (L2-resident, launch-free:
+    nothing to shard)."""
     world = world_size(group)
     if world == 1:
         return kernels.symeig(G, eigenvectors=True, overwrite=overwrite)
@@ -433,7 +564,15 @@ def symeig(G: torch.Tensor, group=None, overwrite: bool = False):
     rank = rank_of(group)
     per = -(-n // world)
     lo, hi = row_slices(n, world)[rank]
-    w, Zt_local = kernels.symeig_rows(G, lo, hi, overwrite=overwrite)
+    if sharded_reduction is None:
+        sharded_reduction = n >= SHARDED_BAND_MIN_N
+    if sharded_reduction and n > 2 * kernels.BAND_NB:
+        A = G if overwrite else G.clone()
+        scal = kernels.symeig_prepare_(A)
+        tau1 = sy2sb_sharded_(A, group)
+        w, Zt_local = kernels.symeig_banded_rows(A, tau1, scal, lo, hi)
+    else:
+        w, Zt_local = kernels.symeig_rows(G, lo, hi, overwrite=overwrite)
     if hi - lo == per:
         send = Zt_local
     else:  # pad the short last slices: all_gather_into_tensor needs equal shapes

@@ -620,6 +620,67 @@ def sy2sb(G: torch.Tensor):
     return AB, tau1, A
 
 
+BAND_NB = 64  # half bandwidth of the two-stage reduction (vivit_sb2st_half_bandwidth())
+
+
+@_launcher
+def symeig_prepare_(A: torch.Tensor) -> torch.Tensor:
+    """In place: LAPACK-style scaling of symmetric ``A`` (lower triangle read) and mirror into the upper triangle --
+    the state the band reduction starts from.  Returns the device ``scal[16]`` block for
+    :func:`symeig_banded_rows` (``vivit_symeig_prepare_f32``)."""
+    _require_device(A)
+    n = A.shape[0]
+    scal = torch.zeros(16, dtype=torch.float32, device=A.device)
+    lib = _lib.load()
+    ws, wsb = _workspace(8 * n + 512, A)
+    st = lib.vivit_symeig_prepare_f32(A.data_ptr(), n, _ld(A), scal.data_ptr(), ws, wsb, _stream(A))
+    _lib.check(st, "vivit_symeig_prepare_f32")
+    return scal
+
+
+@_launcher
+def panel_qr_(pan: torch.Tensor):
+    """Householder QR of one sub-band panel ``pan [mp, 64]`` (contiguous, factored in place: R's strict upper triangle
+    stays in its first 64 rows).  Returns ``(Vt [64, mp], tau [64], betas [64], T [64, 64])`` with ``Q = I - V T V^T``
+    (``vivit_sy2sb_panel_qr_f32``): the step every rank of the sharded band reduction repeats."""
+    _require_device(pan)
+    mp = pan.shape[0]
+    if pan.dim() != 2 or pan.shape[1] != BAND_NB or not pan.is_contiguous():
+        raise ValueError(f"panel must be a contiguous [mp, {BAND_NB}] matrix, got {tuple(pan.shape)}")
+    dev = pan.device
+    Vt = torch.empty((BAND_NB, mp), dtype=torch.float32, device=dev)
+    tau = torch.empty(BAND_NB, dtype=torch.float32, device=dev)
+    betas = torch.empty(BAND_NB, dtype=torch.float32, device=dev)
+    T = torch.empty((BAND_NB, BAND_NB), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    ws, wsb = _workspace(lib.vivit_sy2sb_panel_qr_f32_workspace_bytes(mp), pan)
+    st = lib.vivit_sy2sb_panel_qr_f32(pan.data_ptr(), mp, Vt.data_ptr(), mp, tau.data_ptr(), betas.data_ptr(), T.data_ptr(), ws,
+                                      wsb, _stream(pan))
+    _lib.check(st, "vivit_sy2sb_panel_qr_f32")
+    return Vt, tau, betas, T
+
+
+@_launcher
+def symeig_banded_rows(A: torch.Tensor, tau1: torch.Tensor, scal: torch.Tensor, row_begin: int, row_end: int):
+    """The two-stage solver entered after the band reduction (``A``: band + first-stage reflectors as ``sy2sb`` leaves
+    them, destroyed): all eigenvalues and the eigenvectors ``row_begin .. row_end-1`` as rows
+    (``vivit_symeig_banded_rows_f32``)."""
+    _require_device(A)
+    n = A.shape[0]
+    w = torch.empty(n, dtype=torch.float32, device=A.device)
+    Zt = torch.empty((max(row_end - row_begin, 1), n), dtype=torch.float32, device=A.device)
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    lib = _lib.load()
+    ws, wsb = _workspace(lib.vivit_symeig_f32_workspace_bytes(n, 1), A)
+    st = lib.vivit_symeig_banded_rows_f32(A.data_ptr(), n, _ld(A), tau1.data_ptr(), scal.data_ptr(), w.data_ptr(), Zt.data_ptr(),
+                                          n, row_begin, row_end, ws, wsb, info.data_ptr(), _stream(A))
+    _lib.check(st, "vivit_symeig_banded_rows_f32")
+    nfail = int(info.item())
+    if nfail != 0:
+        raise RuntimeError(f"symeig: {nfail} eigenvalues did not converge")
+    return w, Zt[: row_end - row_begin]
+
+
 @_launcher
 def sb2st(AB: torch.Tensor):
     """Band -> tridiagonal by bulge chasing (testing). ``AB``: [n, 2*NB+1] row-band layout.

@@ -111,14 +111,17 @@ def _worker_band(rank, world, port, ret):
         # against the replicated reduction (same eigenvalues to fp32 accuracy; the band itself differs by rounding only)
         w_rep, _ = vd.symeig(S, sharded_reduction=False)
         ok[f"replicated{n}"] = bool((w - w_rep).abs().max() <= 5e-6 * scale)
-        _, tau1_single, A_single = kernels.sy2sb(S)
-        A = S.clone()
-        kernels.symeig_prepare_(A)
-        tau1 = vd.sy2sb_sharded_(A)
-        band = lambda X: torch.tril(X) - torch.tril(X, -65)   # noqa: E731
-        # (the single-GPU reduction delays the trailing update over groups of four panels: another rounding order; reflector
-        # signs are fixed by the data, so the bands agree entry by entry)
-        ok[f"band{n}"] = bool((band(A) - band(A_single)).abs().max() <= 2e-4 * scale)
+        if kind == "dense":
+            # The band itself, entry by entry, against vivit_sy2sb_f32 (which delays the trailing update over groups of four
+            # panels: another rounding order).  Reflector signs are fixed by the data as long as the panels have full rank --
+            # in the numerical null space of a low-rank Gram matrix the reflectors follow the rounding noise, and only the
+            # spectrum is comparable.
+            _, tau1_single, A_single = kernels.sy2sb(S)
+            A = S.clone()
+            kernels.symeig_prepare_(A)
+            vd.sy2sb_sharded_(A)
+            band = lambda X: torch.tril(X) - torch.tril(X, -65)   # noqa: E731
+            ok[f"band{n}"] = bool((band(A) - band(A_single)).abs().max() <= 2e-4 * scale)
     ret[rank] = ok
     dist.destroy_process_group()
 

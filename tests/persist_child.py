@@ -1,5 +1,6 @@
-"""Child process of tests/test_persistent_gpu.py: the two persistent kernels (sb2st bulge chasing, one-XCD sytrd) under ONE
-setting of their knobs (VIVIT_SB2ST_PERSIST / VIVIT_SYTRD_PERSIST are read once per process); SHA-1 of every output as JSON.
+"""Child process of tests/test_persistent_gpu.py: the persistent kernels (sb2st bulge chasing, one-XCD sytrd, one-XCD panel
+QR of sy2sb) under ONE setting of their knobs (VIVIT_SB2ST_PERSIST / VIVIT_SYTRD_PERSIST / VIVIT_QR_PERSIST are read once
+per process); SHA-1 of the outputs that must be bit-identical, the others in full, as JSON.
 
 usage: python persist_child.py OUT.json
 """
@@ -48,6 +49,14 @@ def main():
         S = (M + M.T).to(DEV)
         d, e, tau, A = kernels.sytrd(S)
         out["sytrd"][str(n)] = {"d": d.cpu().tolist(), "e": e.cpu().tolist()}
+    out["sy2sb"] = {}
+    for n in (200, 1000, 2500):
+        g = torch.Generator().manual_seed(n)
+        M = torch.randn(n, n, generator=g)
+        S = ((M + M.T) / 2).to(DEV)
+        AB, tau1, A = kernels.sy2sb(S)
+        torch.save({"AB": AB.cpu(), "tau1": tau1.cpu()}, sys.argv[1] + f".sy2sb{n}.pt")
+        out["sy2sb"][str(n)] = sys.argv[1] + f".sy2sb{n}.pt"
     with open(sys.argv[1], "w") as f:
         json.dump(out, f)
 

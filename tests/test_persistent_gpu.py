@@ -3,6 +3,8 @@
 * ``sb2st_persist_kernel`` (csrc/sb2st.hip) runs the same tasks with the same arithmetic as one launch per wavefront step:
   d, e, every reflector and every tau must be BIT-identical -- any stale band row (a missed dependency, a cache line
   served from the wrong L2) changes them.
+* ``qr_persist_kernel`` (csrc/sy2sb.hip) sums the column partials in another order than the launch chain: the band agrees
+  entry by entry to rounding (full-rank input: reflector signs are fixed by the data) and has the spectrum of the input.
 * ``trd_persist_kernel`` (csrc/sytrd_persist.hip) is an unblocked right-looking reduction, ``sytrd.hip`` a blocked one:
   different rounding, same tridiagonal matrix up to signs -- the spectra of (d, e) must agree to fp32 accuracy and with
   the fp64 spectrum of the input.
@@ -33,8 +35,8 @@ def _child(tmp, tag, **env):
 @pytest.fixture(scope="module")
 def runs(tmp_path_factory):
     tmp = tmp_path_factory.mktemp("persist")
-    return {"on": _child(tmp, "on", VIVIT_SB2ST_PERSIST="1", VIVIT_SYTRD_PERSIST="1"),
-            "off": _child(tmp, "off", VIVIT_SB2ST_PERSIST="0", VIVIT_SYTRD_PERSIST="0")}
+    return {"on": _child(tmp, "on", VIVIT_SB2ST_PERSIST="1", VIVIT_SYTRD_PERSIST="1", VIVIT_QR_PERSIST="1"),
+            "off": _child(tmp, "off", VIVIT_SB2ST_PERSIST="0", VIVIT_SYTRD_PERSIST="0", VIVIT_QR_PERSIST="0")}
 
 
 def test_sb2st_persistent_is_bit_identical_to_the_launch_chain(runs):
@@ -56,3 +58,28 @@ def test_sytrd_persistent_spectrum(runs, n):
         assert np.abs(w[tag] - ref).max() <= 5e-6 * scale, tag
     assert np.abs(w["on"] - w["off"]).max() <= 5e-6 * scale
     assert runs["on"]["sytrd"][str(n)] != runs["off"]["sytrd"][str(n)]   # (the knob did select another kernel)
+
+
+def _band_dense(AB):
+    NB = 64
+    n = AB.shape[0]
+    B = np.zeros((n, n))
+    for i in range(n):
+        lo = max(0, i - NB)
+        B[i, lo: i + 1] = AB[i, lo - i + 2 * NB: 2 * NB + 1]
+    return B + np.tril(B, -1).T
+
+
+@pytest.mark.parametrize("n", [200, 1000, 2500])
+def test_panel_qr_persistent_band(runs, n):
+    g = torch.Generator().manual_seed(n)
+    M = torch.randn(n, n, generator=g)
+    ref = np.linalg.eigvalsh(((M + M.T) / 2).double().numpy())
+    scale = np.abs(ref).max()
+    res = {tag: torch.load(runs[tag]["sy2sb"][str(n)]) for tag in ("on", "off")}
+    for tag in ("on", "off"):
+        w = np.linalg.eigvalsh(_band_dense(res[tag]["AB"].double().numpy()))
+        assert np.abs(w - ref).max() <= 5e-6 * scale, tag
+    assert float((res["on"]["AB"] - res["off"]["AB"]).abs().max()) <= 1e-4 * scale
+    assert float((res["on"]["tau1"] - res["off"]["tau1"]).abs().max()) <= 2e-3
+    assert not torch.equal(res["on"]["AB"], res["off"]["AB"])   # (the knob did select another kernel)

@@ -48,6 +48,7 @@ struct Sy2sbWs {
   float *tau1;     // [n]
   float *betas;    // [SNB] diagonal of R of the current panel
   QrPart qp;       // partials of the fused panel QR
+  void *qpw;       // exchange buffers of the persistent panel QR
   void *gws;       // split-K workspace
   size_t gws_bytes;
 };
@@ -213,6 +214,226 @@ __global__ __launch_bounds__(256) void qr_step_kernel(float *__restrict__ pan, i
   }
 }
 
+// ---- the same panel QR as ONE persistent launch on ONE XCD (the chain is 65 dependent launches of ~7.3 us per panel,
+// 0.31 s of the band reduction at n = 40 960).  The 32 workgroups of XCD 0 hold the whole panel in registers (10.5 MB at
+// mp = 40 960: workgroup w rows [w RW, (w + 1) RW), RW = 64 RI; thread (row slot rs = tid / 8, column group cg = tid % 8)
+// keeps rows rs + 64 i, columns 8 cg .. 8 cg + 7) and run the same fused column step with ONE exchange per column through
+// the shared L2: a workgroup's partial sums u_w[64] (and the diagonal row, always workgroup 0's) go out by plain stores, one
+// L2 atomic per workgroup, wave 0 polls the counter and sums the 32 partials with sc1 loads (2 us per exchange:
+// scripts/probe/grid_barrier.hip; see sytrd_persist.hip for the protocol and its fallback).  pan receives rows 0..63 only
+// (R; all that is read afterwards).
+constexpr int QP_WG = 32, QP_THREADS = 512;
+struct QrPersistWs {
+  float *ubuf;    // [2][QP_WG][SNB]
+  float *dbuf;    // [2][SNB]
+  int *counter;   // monotonic arrival counter; [32 ..]: XCC ids
+};
+
+__device__ __forceinline__ float sel8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, int j) {
+  const float t0 = (j & 1) ? a1 : a0, t1 = (j & 1) ? a3 : a2, t2 = (j & 1) ? a5 : a4, t3 = (j & 1) ? a7 : a6;
+  const float u0 = (j & 2) ? t1 : t0, u1 = (j & 2) ? t3 : t2;
+  return (j & 4) ? u1 : u0;
+}
+
+template <int RI>
+__global__ __launch_bounds__(QP_THREADS) void qr_persist_kernel(float *__restrict__ pan, int64_t mp, int ncol, QrPersistWs pw,
+                                                                float *__restrict__ vdst1, float *__restrict__ vdst2, int64_t lds_,
+                                                                int64_t gi0, float *__restrict__ A, int64_t lda, int64_t j0,
+                                                                float *__restrict__ tau1, float *__restrict__ betas) {
+  if ((blockIdx.x & 7) != 0) return;
+  const int w = blockIdx.x >> 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = tid & 7, rs = tid >> 3;
+  constexpr int RW = 64 * RI;
+  const int64_t rbase = (int64_t)w * RW;
+  __shared__ float s_u[SNB], s_d[SNB], s_dn[SNB];
+  __shared__ float s_red[QP_THREADS / 64][SNB];
+  __shared__ float s_v[RW];
+  __shared__ int s_flag[2];   // 0: slow (not one XCD), 1: dead (timeout)
+
+  float x[RI][8];
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int64_t r = rbase + rs + 64 * i;
+    const float *src = pan + (r < mp ? r : 0) * SNB + 8 * cg;
+    const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+    const bool ok = r < mp;
+    x[i][0] = ok ? a.x : 0.f; x[i][1] = ok ? a.y : 0.f; x[i][2] = ok ? a.z : 0.f; x[i][3] = ok ? a.w : 0.f;
+    x[i][4] = ok ? b.x : 0.f; x[i][5] = ok ? b.y : 0.f; x[i][6] = ok ? b.z : 0.f; x[i][7] = ok ? b.w : 0.f;
+  }
+  if (tid == 0) {   // are the 32 workgroups on one XCD?  (first exchange, the safe way)
+    int xcc;
+    __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    __hip_atomic_store(pw.counter + 32 + w, xcc & 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(pw.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int dead = 0;
+    while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < QP_WG)
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { dead = 1; break; }
+    int slow = 0;
+    const int x0 = __hip_atomic_load(pw.counter + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 1; i < QP_WG; ++i) slow |= __hip_atomic_load(pw.counter + 32 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != x0;
+    s_flag[0] = slow;
+    s_flag[1] = dead;
+  }
+  __syncthreads();
+  const bool slow = s_flag[0] != 0;
+  const int grp = lane & ~7;   // first lane of this row slot's eight threads
+
+  // partial sums of column cn over this workgroup's rows (x = the UPDATED column cn), diagonal row cn, out to the exchange
+  auto publish = [&](int cn) __attribute__((always_inline)) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      const int64_t r = rbase + rs + 64 * i;
+      float xn = __shfl(sel8(x[i][0], x[i][1], x[i][2], x[i][3], x[i][4], x[i][5], x[i][6], x[i][7], cn & 7), grp | (cn >> 3), 64);
+      xn = (r > cn && r < mp) ? xn : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(xn, x[i][j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[j] += __shfl_xor(acc[j], 8, 64);
+      acc[j] += __shfl_xor(acc[j], 16, 64);
+      acc[j] += __shfl_xor(acc[j], 32, 64);
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_red[wave][8 * lane + j] = acc[j];
+    }
+    if (w == 0 && rs == cn) {   // the diagonal row of column cn (rows 0..63 live in workgroup 0, i = 0)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_dn[8 * cg + j] = x[0][j];
+    }
+  };
+  // wave 0: the workgroup's partials (and diagonal row) to the exchange buffers of parity par, then the arrival counter
+  auto send = [&](int par) __attribute__((always_inline)) {
+    if (wave == 0) {
+      float u = 0.f;
+#pragma unroll
+      for (int q = 0; q < QP_THREADS / 64; ++q) u += s_red[q][lane];
+      float *ub = pw.ubuf + ((size_t)par * QP_WG + w) * SNB + lane, *db = pw.dbuf + (size_t)par * SNB + lane;
+      if (slow) {
+        __hip_atomic_store(ub, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) __hip_atomic_store(db, s_dn[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        *ub = u;
+        if (w == 0) *db = s_dn[lane];
+      }
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(pw.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+
+  publish(0);
+  __syncthreads();
+  send(0);
+  for (int c = 0; c < ncol && !s_flag[1]; ++c) {
+    const int par = c & 1;
+    if (wave == 0) {   // exchange: all 32 workgroups have delivered column c's partials
+      const int target = (c + 2) * QP_WG;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { s_flag[1] = 1; break; }
+      const float *ub = pw.ubuf + (size_t)par * QP_WG * SNB + lane;
+      float pv[QP_WG];
+#pragma unroll
+      for (int q = 0; q < QP_WG; ++q) pv[q] = __hip_atomic_load(ub + q * SNB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float dn = __hip_atomic_load(pw.dbuf + (size_t)par * SNB + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float u = 0.f;
+#pragma unroll
+      for (int q = 0; q < QP_WG; ++q) u += pv[q];
+      s_u[lane] = u;
+      s_d[lane] = dn;
+    }
+    __syncthreads();   // A
+    if (s_flag[1]) break;
+    const float ssq = s_u[c], alpha = s_d[c];
+    float tau = 0.f, beta = alpha, scal = 0.f;
+    if (ssq > 0.f) {
+      beta = -copysignf(sqrt_nr(alpha * alpha + ssq), alpha);
+      tau = (beta - alpha) * rcp_nr(beta);
+      scal = rcp_nr(alpha - beta);
+    }
+    float z[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cc = 8 * cg + j;
+      z[j] = cc > c ? tau * (s_d[cc] + scal * s_u[cc]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      const int64_t r = rbase + rs + 64 * i;
+      const float xc = __shfl(sel8(x[i][0], x[i][1], x[i][2], x[i][3], x[i][4], x[i][5], x[i][6], x[i][7], c & 7), grp | (c >> 3), 64);
+      const float v = r == c ? 1.f : ((r > c && r < mp) ? xc * scal : 0.f);
+      if (cg == 0) s_v[rs + 64 * i] = v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[i][j] = fmaf(-v, z[j], x[i][j]);
+    }
+    if (w == 0 && tid == 0) { tau1[j0 + c] = tau; betas[c] = beta; }
+    const bool has_next = c + 1 < ncol;
+    if (has_next) publish(c + 1);
+    __syncthreads();   // B
+    if (has_next) send(par ^ 1);
+    // v for this workgroup's rows: k-major copies for the GEMMs and the reflector row for the back-transformation
+    for (int idx = tid; idx < RW; idx += QP_THREADS) {
+      const int64_t r = rbase + idx;
+      if (r < mp) {
+        const float v = s_v[idx];
+        vdst1[(int64_t)c * lds_ + gi0 + r] = v;
+        vdst2[(int64_t)c * lds_ + gi0 + r] = v;
+        if (r >= c) A[(j0 + c) * lda + gi0 + r] = v;
+      }
+    }
+  }
+  if (w == 0) {   // R: rows 0..63 of the factored panel
+    const int64_t r = rs;
+    if (r < mp) {
+      float *dst = pan + r * SNB + 8 * cg;
+      *reinterpret_cast<float4 *>(dst) = make_float4(x[0][0], x[0][1], x[0][2], x[0][3]);
+      *reinterpret_cast<float4 *>(dst + 4) = make_float4(x[0][4], x[0][5], x[0][6], x[0][7]);
+    }
+    if (tid == 0 && s_flag[1]) betas[0] = __builtin_nanf("");   // a timed-out exchange: poison the band
+  }
+}
+
+static bool qr_persist_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("VIVIT_QR_PERSIST");
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
+constexpr size_t QR_PERSIST_WS_BYTES = sizeof(float) * (2 * QP_WG * SNB + 2 * SNB) + 64 * sizeof(int) + 256;
+
+// launches the persistent panel QR if the panel fits (mp <= 40 960); false = use the launch chain
+static bool qr_persist_launch(float *pan, int64_t mp, int ncol, void *wsp, float *v1, float *v2, int64_t ldn, int64_t gi0, float *A,
+                              int64_t lda, int64_t j0, float *tau1, float *betas, hipStream_t stream) {
+  if (!qr_persist_enabled() || mp > (int64_t)QP_WG * 64 * 20) return false;
+  QrPersistWs pw;
+  pw.ubuf = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(wsp), 256));
+  pw.dbuf = pw.ubuf + 2 * QP_WG * SNB;
+  pw.counter = reinterpret_cast<int *>(pw.dbuf + 2 * SNB);
+  if (hipMemsetAsync(pw.counter, 0, 64 * sizeof(int), stream) != hipSuccess) return false;
+  const int64_t ri = cdiv(mp, (int64_t)QP_WG * 64);
+  const dim3 grid(8 * QP_WG);
+#define QP_LAUNCH(RI) qr_persist_kernel<RI><<<grid, QP_THREADS, 0, stream>>>(pan, mp, ncol, pw, v1, v2, ldn, gi0, A, lda, j0, tau1, betas)
+  if (ri <= 1) QP_LAUNCH(1);
+  else if (ri <= 2) QP_LAUNCH(2);
+  else if (ri <= 3) QP_LAUNCH(3);
+  else if (ri <= 5) QP_LAUNCH(5);
+  else if (ri <= 8) QP_LAUNCH(8);
+  else if (ri <= 12) QP_LAUNCH(12);
+  else if (ri <= 16) QP_LAUNCH(16);
+  else QP_LAUNCH(20);
+#undef QP_LAUNCH
+  return true;
+}
+
 // R (upper triangular, rows 0..min(NB, mp)-1 of the factored panel) back into A; zeros below it inside
 // the band rows.
 __global__ __launch_bounds__(256) void sb_panel_store_kernel(float *__restrict__ A, int64_t lda, int64_t j0, int64_t mp,
@@ -283,6 +504,7 @@ size_t sy2sb_workspace_bytes(int64_t n) {
   b += align_up(sizeof(float) * SNB * 2 * SNB * SGRP, 256);    // G12
   b += align_up(sizeof(float) * 2 * nwg * SNB, 256);    // QR partials u (double-buffered)
   b += align_up(sizeof(float) * 2 * SNB, 256);          // QR diagonal row
+  b += align_up(QR_PERSIST_WS_BYTES, 256);              // persistent panel QR
   b += align_up(sizeof(float) * SNB * SNB, 256) * 4;    // S T Y3 S2
   b += align_up(sizeof(float) * n, 256);                // tau1
   b += align_up(sizeof(float) * SNB, 256);              // betas
@@ -308,6 +530,7 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
   ws.G12 = (float *)take(sizeof(float) * SNB * 2 * SNB * SGRP);
   ws.qp.u = (float *)take(sizeof(float) * 2 * nwg * SNB);
   ws.qp.diag = (float *)take(sizeof(float) * 2 * SNB);
+  ws.qpw = take(QR_PERSIST_WS_BYTES);
   ws.S = (float *)take(sizeof(float) * SNB * SNB);
   ws.T = (float *)take(sizeof(float) * SNB * SNB);
   ws.Y3 = (float *)take(sizeof(float) * SNB * SNB);
@@ -326,8 +549,9 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     const int ncol = (int)(mp < SNB ? mp : SNB);
     const int g = (int)cdiv(mp, QT);
     sb_panel_load_kernel<<<(unsigned)cdiv(mp * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan);
-    for (int c = -1; c < ncol; ++c)  // c = -1: partials of column 0
-      qr_step_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, ncol, g, ws.qp, v1, v2, ldn, gi0, A, lda, j0, ws.tau1, ws.betas);
+    if (!qr_persist_launch(ws.pan, mp, ncol, ws.qpw, v1, v2, ldn, gi0, A, lda, j0, ws.tau1, ws.betas, stream))
+      for (int c = -1; c < ncol; ++c)  // c = -1: partials of column 0
+        qr_step_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, ncol, g, ws.qp, v1, v2, ldn, gi0, A, lda, j0, ws.tau1, ws.betas);
     sb_panel_store_kernel<<<(unsigned)cdiv(SNB * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan, ws.betas);
     return launch_status();
   };
@@ -427,7 +651,7 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
 size_t sy2sb_panel_qr_workspace_bytes(int64_t mp) {
   const int64_t nwg = cdiv(mp, QT) + 1;
   return align_up(sizeof(float) * 2 * nwg * SNB, 256) + align_up(sizeof(float) * 2 * SNB, 256) + align_up(sizeof(float) * SNB * SNB, 256) +
-         align_up(gemm_workspace_bytes(SNB, SNB, mp, false), 256) + 1024;
+         align_up(QR_PERSIST_WS_BYTES, 256) + align_up(gemm_workspace_bytes(SNB, SNB, mp, false), 256) + 1024;
 }
 
 int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float *tau, float *betas, float *T, void *wsbase,
@@ -444,6 +668,7 @@ int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float 
   qp.u = (float *)take(sizeof(float) * 2 * nwg * SNB);
   qp.diag = (float *)take(sizeof(float) * 2 * SNB);
   float *S = (float *)take(sizeof(float) * SNB * SNB);
+  void *qpw = take(QR_PERSIST_WS_BYTES);
   const size_t gws_bytes = gemm_workspace_bytes(SNB, SNB, mp, false);
   void *gws = take(gws_bytes);
   const int ncol = (int)(mp < SNB ? mp : SNB);
@@ -451,8 +676,10 @@ int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float 
   if (hipMemsetAsync(tau, 0, sizeof(float) * SNB, stream) != hipSuccess) return VIVIT_E_LAUNCH;
   if (hipMemsetAsync(betas, 0, sizeof(float) * SNB, stream) != hipSuccess) return VIVIT_E_LAUNCH;
   if (hipMemset2DAsync(Vt, sizeof(float) * ldv, 0, sizeof(float) * mp, SNB, stream) != hipSuccess) return VIVIT_E_LAUNCH;
-  for (int c = -1; c < ncol; ++c)  // (reflector row of "A" = the same row of Vt: written twice with the same values)
-    qr_step_kernel<<<g, 256, 0, stream>>>(pan, mp, c, ncol, g, qp, Vt, Vt, ldv, 0, Vt, ldv, 0, tau, betas);
+  // (reflector row of "A" = the same row of Vt: written twice with the same values)
+  if (!qr_persist_launch(pan, mp, ncol, qpw, Vt, Vt, ldv, 0, Vt, ldv, 0, tau, betas, stream))
+    for (int c = -1; c < ncol; ++c)
+      qr_step_kernel<<<g, 256, 0, stream>>>(pan, mp, c, ncol, g, qp, Vt, Vt, ldv, 0, Vt, ldv, 0, tau, betas);
   int st = gemm_launch(LAY_K, LAY_K, Vt, Vt, S, SNB, SNB, mp, ldv, ldv, SNB, 1.f, 0.f, false, gws, gws_bytes, stream);
   if (st != VIVIT_OK) return st;
   larft_kernel<<<1, SNB, 0, stream>>>(S, tau, SNB, ncol, T);

@@ -1915,8 +1915,9 @@ static int gemm_split_mode() {
 //      512 -> 9.8e-7 / -6e-8       fp32 MFMA kernel (chains of 8192, correctly rounded): 1.6e-6 / -3.2e-7
 // and what a shorter chain costs at the headline shape (n = 40 960: C is 6.7 GB, every flush is HBM traffic that
 // competes with the operand panels for the L2 / Infinity Cache): 8192 -> 4096: + 2 %, -> 2048: + 6 %, -> 1024: + 10 %;
-// diagonal tiles at 512: + 1-2 % (1 % of the tiles).  Default: 4096 k (1.4 x the fp32 MFMA kernel's random-sign error),
-// 512 k on the diagonal tiles of a SYRK (no bias where every term has the same sign), 1024 k in the split-K form for
+// diagonal tiles at 512: + 1-2 % per launch, + 5 % at the headline shape (140 ms).  Default: 4096 k (1.4 x the fp32 MFMA
+// kernel's random-sign error) on ALL tiles -- the same-sign sums of a Gram matrix are its diagonal ENTRIES, which the
+// public SYRK computes separately in fp64 (syrk_diag_kernel: 16 ms instead of 140) --, 1024 k in the split-K form for
 // small outputs (whose yardstick is the 128-tile fp32 kernel with its chains of 2048); the eigensolver's internal
 // products on orthogonal factors (random signs, the measured off-diagonal case) keep 8192.
 // VIVIT_BX_FLUSH / VIVIT_BX_FLUSH_DIAG / VIVIT_BX_FLUSH_SPLITK / VIVIT_BX_FLUSH_INTERNAL override (in k).
@@ -1926,7 +1927,7 @@ static int bx_env_tiles(const char *name, int dflt_k) {
   return ft < 1 ? 1 : ft;
 }
 static int bx_flush_tiles() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH", 4096); return ft; }
-static int bx_flush_diag() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_DIAG", 512); return ft; }
+static int bx_flush_diag() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_DIAG", 4096); return ft; }
 static int bx_flush_internal() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_INTERNAL", 8192); return ft; }
 static int bx_flush_splitk() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_SPLITK", 1024); return ft; }
 
@@ -2471,6 +2472,62 @@ int gemm_batched_launch(int alay, int blay, const GemmDesc *desc, int batch, int
 
 } // namespace vivit
 
+namespace vivit {
+
+// dout[i] = beta G[i][i] + alpha sum_k A[i][k]^2, fp64 accumulation, one workgroup per row (16 float4 loads in flight per thread)
+template <bool VEC>
+__global__ __launch_bounds__(256) void syrk_diag_kernel(const float *__restrict__ A, int64_t K, int64_t lda, const float *__restrict__ G,
+                                                        int64_t ldg, float alpha, float beta, float *__restrict__ dout) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const float *a = A + row * lda;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if constexpr (VEC) {
+    const int64_t K4 = K / 4;
+    int64_t c = tid;
+    for (; c + 3 * 256 < K4; c += 4 * 256) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(a + 4 * (c + 256 * u));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[0] = fma((double)v[u].x, (double)v[u].x, acc[0]);
+        acc[1] = fma((double)v[u].y, (double)v[u].y, acc[1]);
+        acc[2] = fma((double)v[u].z, (double)v[u].z, acc[2]);
+        acc[3] = fma((double)v[u].w, (double)v[u].w, acc[3]);
+      }
+    }
+    for (; c < K4; c += 256) {
+      const float4 v = *reinterpret_cast<const float4 *>(a + 4 * c);
+      acc[0] = fma((double)v.x, (double)v.x, acc[0]);
+      acc[1] = fma((double)v.y, (double)v.y, acc[1]);
+      acc[2] = fma((double)v.z, (double)v.z, acc[2]);
+      acc[3] = fma((double)v.w, (double)v.w, acc[3]);
+    }
+    for (int64_t k = 4 * K4 + tid; k < K; k += 256) acc[0] = fma((double)a[k], (double)a[k], acc[0]);
+  } else {
+    for (int64_t k = tid; k < K; k += 256) acc[k & 3] = fma((double)a[k], (double)a[k], acc[k & 3]);
+  }
+  double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+    const double old = beta != 0.f ? (double)beta * (double)G[row * ldg + row] : 0.0;
+    dout[row] = (float)(old + (double)alpha * tot);
+  }
+}
+
+__global__ __launch_bounds__(256) void syrk_diag_store_kernel(float *__restrict__ G, int64_t ldg, int64_t n, const float *__restrict__ d) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) G[i * ldg + i] = d[i];
+}
+
+}  // namespace vivit
+
 using namespace vivit;
 
 extern "C" {
@@ -2486,13 +2543,34 @@ int vivit_debug_bx_stamp_buffer(void *buf, unsigned int capacity) {
 
 int vivit_gemm_split_mode(void) { return gemm_split_mode(); }
 
-size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p) { return gemm_workspace_bytes(n, n, p, true); }
+// The DIAGONAL of the public Gram product is computed on its own: G[i][i] = beta G[i][i] + alpha sum_k a_ik^2 is the one
+// place where every term of the sum has the same sign, i.e. where the bf16 MFMA's truncation of aligned partial sums
+// (see bx_flush_tiles) adds up to a bias instead of averaging out -- the reason the diagonal TILES ran chains of 512 k
+// (+ 140 ms of flushes at the headline shape).  One streaming pass over A (66.7 GB: ~16 ms) with fp64 accumulation
+// gives correctly rounded diagonal entries for every path, and the diagonal tiles keep the chain length of all others.
+static size_t syrk_diag_bytes(int64_t n) { return align_up(sizeof(float) * (size_t)n, 256) + 256; }
+constexpr int64_t SYRK_DIAG_MIN_K = 1024;   // below: the product's own diagonal (chains never end; nothing to fix)
+
+size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p) { return gemm_workspace_bytes(n, n, p, true) + syrk_diag_bytes(n); }
 
 int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float *G, int64_t ldg, float alpha,
                         float beta, void *workspace, size_t workspace_bytes, void *stream) {
   BxStrictScope strict;  // public product: both range bits reroute a chunk to the fp32 MFMA kernel
-  return gemm_launch(LAY_K, LAY_K, A, A, G, n, n, p, lda, lda, ldg, alpha, beta, true, workspace, workspace_bytes,
-                     static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool fix_diag = A && G && workspace && n > 0 && p >= SYRK_DIAG_MIN_K && workspace_bytes >= syrk_diag_bytes(n) + gemm_workspace_bytes(n, n, p, true);
+  float *diag = nullptr;
+  if (fix_diag) {
+    diag = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+    const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0;
+    if (vec) syrk_diag_kernel<true><<<(unsigned)n, 256, 0, s>>>(A, p, lda, G, ldg, alpha, beta, diag);
+    else syrk_diag_kernel<false><<<(unsigned)n, 256, 0, s>>>(A, p, lda, G, ldg, alpha, beta, diag);
+    workspace = reinterpret_cast<char *>(workspace) + syrk_diag_bytes(n);
+    workspace_bytes -= syrk_diag_bytes(n);
+  }
+  const int st = gemm_launch(LAY_K, LAY_K, A, A, G, n, n, p, lda, lda, ldg, alpha, beta, true, workspace, workspace_bytes, s);
+  if (st != VIVIT_OK || !fix_diag) return st;
+  syrk_diag_store_kernel<<<(unsigned)cdiv(n, 256), 256, 0, s>>>(G, ldg, n, diag);
+  return launch_status();
 }
 
 size_t vivit_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) {

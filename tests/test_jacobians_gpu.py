@@ -91,6 +91,38 @@ def test_conv2d_rules(cin, cout, hw, k, s, p, d):
     close(kernels.row_dot(M.reshape(-1, L)).view(Vd, N, cout), M.flatten(3).sum(3), rtol=1e-5, atol=1e-5 * math.sqrt(L))
 
 
+@pytest.mark.parametrize("cin,cout,L,k,s,p,d", [(4, 6, 33, 5, 1, 2, 1), (3, 8, 40, 3, 2, 1, 2), (17, 5, 12, 2, 1, 0, 1)])
+def test_conv1d_rules(cin, cout, L, k, s, p, d):
+    """Conv1d runs on the Conv2d kernels (one row): input rule and weight rule through the backend dispatch."""
+    from vivit_amd.backend.extensions import _jac_t_mat_prod, _param_factor
+
+    g = torch.Generator(device=DEV).manual_seed(6)
+    N, Vd = 4, 3
+    conv = nn.Conv1d(cin, cout, k, stride=s, padding=p, dilation=d).to(DEV)
+    x = torch.randn(N, cin, L, generator=g, device=DEV)
+    y = conv(x)
+    M = torch.randn(Vd, *y.shape, generator=g, device=DEV)
+    close(_jac_t_mat_prod(conv, M, x), jac_t_by_autograd(conv, x, M), rtol=1e-4, atol=1e-5)
+    gotw = _param_factor(conv, "weight", M, x)
+    ref = torch.empty_like(gotw)
+    for v in range(Vd):
+        for n in range(N):
+            ref[v, n] = torch.autograd.grad(F.conv1d(x[n:n + 1], conv.weight, None, conv.stride, conv.padding, conv.dilation),
+                                            conv.weight, grad_outputs=M[v, n:n + 1])[0]
+    close(gotw, ref, rtol=1e-4, atol=1e-5 * math.sqrt(y.shape[2]))
+    close(_param_factor(conv, "bias", M, x), M.sum(3), rtol=1e-5, atol=1e-5 * math.sqrt(y.shape[2]))
+
+
+def test_linear_extra_dims_input_rule():
+    from vivit_amd.backend.extensions import _jac_t_mat_prod
+
+    g = torch.Generator(device=DEV).manual_seed(7)
+    lin = nn.Linear(13, 9).to(DEV)
+    x = torch.randn(5, 3, 4, 13, generator=g, device=DEV)
+    M = torch.randn(2, 5, 3, 4, 9, generator=g, device=DEV)
+    close(_jac_t_mat_prod(lin, M, x), jac_t_by_autograd(lin, x, M), rtol=1e-4, atol=1e-5)
+
+
 def test_batchnorm_rules():
     from vivit_amd import kernels
     from vivit_amd.backend.extensions import _jac_t_mat_prod, _param_factor

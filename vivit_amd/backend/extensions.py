@@ -103,10 +103,16 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
     if isinstance(module, _CONVS):
         if name == "bias":
             return _spatial_sum(M, 3)
-        if (isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple)
+        if (isinstance(module, (nn.Conv2d, nn.Conv1d)) and module.groups == 1 and isinstance(module.padding, tuple)
                 and module.padding_mode == "zeros"):
-            # unfold + "vnol,nkl->vnok" in one HIP kernel (patch values gathered on the fly, no im2col buffer)
+            # unfold + "vnol,nkl->vnok" in one HIP kernel (patch values gathered on the fly, no im2col buffer);
+            # a Conv1d is the Conv2d with one row
+            one_d = isinstance(module, nn.Conv1d)
             try:
+                if one_d:
+                    out = kernels.conv2d_weight_mjp(M.unsqueeze(3), x.unsqueeze(2), (1, module.kernel_size[0]), (1, module.stride[0]),
+                                                    (0, module.padding[0]), (1, module.dilation[0]))
+                    return out.squeeze(4)
                 return kernels.conv2d_weight_mjp(M, x, module.kernel_size, module.stride, module.padding, module.dilation)
             except _lib.VivitHipError as exc:  # shapes outside the kernel's launch limits: the torch rule below
                 if "status -4" not in str(exc):
@@ -165,8 +171,8 @@ def _pair(v):
 
 def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
     """The layer rules that have a HIP kernel (csrc/jacobians.hip): activations, Flatten / Identity / Dropout(eval),
-    Max/AvgPool2d, Conv2d (groups = 1, zero padding), BatchNorm (eval).  ``None``: no kernel for this module
-    (Conv1d/3d, transposed and grouped convolutions, custom index modules) -- the generic autograd rule takes over."""
+    Max/AvgPool2d, Conv2d / Conv1d (groups = 1, zero padding), BatchNorm (eval).  ``None``: no kernel for this module
+    (Conv3d, transposed and grouped convolutions, custom index modules) -- the generic autograd rule takes over."""
     kind = _ACTIVATIONS.get(type(module))
     if kind is not None:
         return kernels.act_jac_t(M, x, kind[0], getattr(module, kind[1]) if kind[1] else 0.0)
@@ -184,6 +190,12 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
     if (isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple)
             and module.padding_mode == "zeros" and module.out_channels * module.kernel_size[0] * module.kernel_size[1] <= 1024):
         return kernels.conv2d_jac_t(M, module.weight.detach(), x.shape[2:], module.stride, module.padding, module.dilation)
+    if (isinstance(module, nn.Conv1d) and module.groups == 1 and isinstance(module.padding, tuple)
+            and module.padding_mode == "zeros" and module.out_channels * module.kernel_size[0] <= 1024):
+        # a Conv1d is the Conv2d with one row: same kernel
+        g = kernels.conv2d_jac_t(M.unsqueeze(3), module.weight.detach().unsqueeze(2), (1, x.shape[2]), (1, module.stride[0]),
+                                 (0, module.padding[0]), (1, module.dilation[0]))
+        return g.squeeze(3)
     if isinstance(module, _BATCHNORM) and x.dim() >= 2:
         scale = torch.rsqrt(module.running_var + module.eps)
         if module.weight is not None:
@@ -194,10 +206,10 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
 
 def _jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Tensor:
     """Apply the transposed input-Jacobian of ``module`` to ``M`` [V, N, *out] -> [V, N, *in]."""
-    if isinstance(module, nn.Linear) and M.dim() == 3:
-        V, N, O = M.shape
-        if M.is_cuda:
-            return kernels.gemm_nn(M.reshape(V * N, O), module.weight.detach()).view(V, N, -1)
+    if isinstance(module, nn.Linear):   # (any number of extra dimensions between batch and features: linear.py:38-39)
+        if M.is_cuda and M.dtype == torch.float32:
+            O = M.shape[-1]
+            return kernels.gemm_nn(M.reshape(-1, O), module.weight.detach()).view(*M.shape[:-1], -1)
         return M @ module.weight.detach()
     if isinstance(module, nn.Dropout) and module.training and module.p > 0:
         raise NotImplementedError("Dropout must be in eval mode")

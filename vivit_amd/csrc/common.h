@@ -94,4 +94,19 @@ enum { PROF_STAGE_BEGIN = 0, PROF_STAGE_PREP = 1, PROF_STAGE_SY2SB = 2, PROF_STA
        PROF_STAGE_Q2 = 5, PROF_STAGE_Q1 = 6, PROF_STAGE_OUTPUT = 7, PROF_STAGE_SYTRD = 8, PROF_NUM_STAGES = 9 };
 void prof_mark(int stage, hipStream_t stream);
 
+// Compute units of the current device (cached per device): the one-XCD persistent kernels (sytrd_persist.hip, the panel
+// QR of sy2sb.hip) need 32 co-resident workgroups of one per CU on XCD 0, i.e. an 8-XCD part with all 256 CUs visible.
+inline int device_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int &c = cached[dev & 63];
+  if (c == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = -1;
+    c = v > 0 ? v : -1;
+  }
+  return c;
+}
+
 } // namespace vivit

@@ -413,7 +413,7 @@ constexpr size_t QR_PERSIST_WS_BYTES = sizeof(float) * (2 * QP_WG * SNB + 2 * SN
 // launches the persistent panel QR if the panel fits (mp <= 40 960); false = use the launch chain
 static bool qr_persist_launch(float *pan, int64_t mp, int ncol, void *wsp, float *v1, float *v2, int64_t ldn, int64_t gi0, float *A,
                               int64_t lda, int64_t j0, float *tau1, float *betas, hipStream_t stream) {
-  if (!qr_persist_enabled() || mp > (int64_t)QP_WG * 64 * 20) return false;
+  if (!qr_persist_enabled() || mp > (int64_t)QP_WG * 64 * 20 || device_cu_count() < 256) return false;
   QrPersistWs pw;
   pw.ubuf = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(wsp), 256));
   pw.dbuf = pw.ubuf + 2 * QP_WG * SNB;

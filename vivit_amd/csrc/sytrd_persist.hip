@@ -254,7 +254,7 @@ bool sytrd_persist_ok(int64_t n) {
     const char *e = getenv("VIVIT_SYTRD_PERSIST");
     on = e ? atoi(e) : 1;
   }
-  return on != 0 && n >= 64 && n <= 1280;   // (n <= 1536 = <6, 6> spills 84 registers)
+  return on != 0 && n >= 64 && n <= 1280 && device_cu_count() >= 256;   // (n <= 1536 = <6, 6> spills 84 registers)
 }
 
 // workspace: 4 NP floats + 64 ints, carved from ws.vw (3 * 64 * n floats)

@@ -435,7 +435,12 @@ def backproject_sum(coef: torch.Tensor, V_local: torch.Tensor, acc: BatchSharded
     return out.view(K, *V_local.shape[2:])
 
 
-SHARDED_BAND_MIN_N = 8192  # smallest n whose band reduction is sharded by default (below: replicated, as the tridiagonal stages)
+# Smallest n whose band reduction is sharded by default; None = never (the prototype issues its two collectives per panel from
+# Python: at R = 8 its projected time equals the replicated reduction's, and no multi-GPU node could measure it -- so it is
+# opt-in: ``symeig(..., sharded_reduction=True)`` or VIVIT_SHARDED_BAND_MIN_N=<n> in the environment).
+import os as _os
+
+SHARDED_BAND_MIN_N = int(_os.environ["VIVIT_SHARDED_BAND_MIN_N"]) if _os.environ.get("VIVIT_SHARDED_BAND_MIN_N") else None
 
 
 def sy2sb_sharded_(A: torch.Tensor, group=None) -> torch.Tensor:
@@ -554,8 +559,8 @@ def symeig(G: torch.Tensor, group=None, overwrite: bool = False, sharded_reducti
     Every rank must hold the same ``G`` (e.g. the result of :func:`sharded_gram`).  Returns
     ``(evals [n], evecs [n, n])`` like ``kernels.symeig(G, eigenvectors=True)``; ``evecs`` is the
     transposed view of the gathered row-major eigenvector matrix (``evecs[:, i]`` contiguous).
-    ``sharded_reduction``: shard the full -> band reduction too (:func:`sy2sb_sharded_`); default: for
-    ``n >= SHARDED_BAND_MIN_N``.  Bulge chasing and the tridiagonal solve stay replicated (L2-resident, launch-free:
+    ``sharded_reduction``: shard the full -> band reduction too (:func:`sy2sb_sharded_`); default: off unless
+    ``SHARDED_BAND_MIN_N`` is set and ``n`` reaches it.  Bulge chasing and the tridiagonal solve stay replicated (L2-resident, launch-free:
     nothing to shard)."""
     world = world_size(group)
     if world == 1:
@@ -565,7 +570,7 @@ def symeig(G: torch.Tensor, group=None, overwrite: bool = False, sharded_reducti
     per = -(-n // world)
     lo, hi = row_slices(n, world)[rank]
     if sharded_reduction is None:
-        sharded_reduction = n >= SHARDED_BAND_MIN_N
+        sharded_reduction = SHARDED_BAND_MIN_N is not None and n >= SHARDED_BAND_MIN_N
     if sharded_reduction and n > 2 * kernels.BAND_NB:
         A = G if overwrite else G.clone()
         scal = kernels.symeig_prepare_(A)

@@ -431,6 +431,10 @@ def main():
     # (functional testing on a 1-GPU box: VIVIT_DIST_BACKEND=gloo lets several ranks share device 0)
     backend = os.environ.get("VIVIT_DIST_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    if world > torch.cuda.device_count():
+        # ranks share a card (functional runs only): the one-XCD persistent kernels want XCD 0 of their GPU to themselves
+        os.environ.setdefault("VIVIT_SYTRD_PERSIST", "0")
+        os.environ.setdefault("VIVIT_QR_PERSIST", "0")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None

@@ -13,7 +13,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 
+def _one_card_env():
+    """Two ranks share ONE card here.  The one-XCD persistent kernels need their 32 workgroups co-resident on XCD 0, one
+    per CU: two processes launching them at the same moment can each hold part of the XCD and wait for the rest until
+    the bounded spins give up.  The product runs one process per GPU; this test plumbing takes the launch chains."""
+    os.environ["VIVIT_SYTRD_PERSIST"] = "0"
+    os.environ["VIVIT_QR_PERSIST"] = "0"
+
+
 def _worker(rank, world, port, ret):
+    _one_card_env()
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -85,6 +94,7 @@ def test_data_parallel_on_hip_kernels_world2():
 
 def _worker_band(rank, world, port, ret):
     """The sharded band reduction on the HIP kernels (panel QR, GEMMs, banded solver): two ranks on the one GPU."""
+    _one_card_env()
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -19,7 +19,10 @@
 // Workgroups find themselves on one XCD because the dispatcher deals workgroup b to XCD b % 8: the launch has 256
 // workgroups, 224 return at once.  The first exchange compares the XCC ids; should they ever differ the stores become
 // agent-scope atomic stores (write-through), which is correct anywhere (4 us per exchange).  Every spin is bounded (2 s):
-// the grid always drains, a timeout raises the non-finite-input flag so that the solve fails loudly.
+// the grid always drains, a timeout raises the non-finite-input flag so that the solve fails loudly.  One process per GPU:
+// two processes that launch this kernel on the same card at the same moment can each hold part of XCD 0 and time out
+// (VIVIT_SYTRD_PERSIST=0 / VIVIT_QR_PERSIST=0 select the launch chains; tests/test_distributed_gpu.py does for its two ranks
+// on one card).
 #include <cstdlib>
 
 #include "common.h"

@@ -39,17 +39,18 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spe
 # bound).  PMC collection cannot run inside this process; the constant is only attached to the exact shape it
 # was measured on.
 SYRK_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * 3695931059.375 + 276639882.25) * 1024.0}
-# the same launch on the bf16-pipe path (profiles/r03_pmc/syrkbx_n40960_p401408_*.csv: 7 chunk launches of
-# gemm256_bx_kernel<6> + 7 of bx_split_kernel, summed; the in-loop chain flushes of round 3 add the Gram matrix's own
-# read-modify-write traffic: 7.74 TB fetched / 0.56 TB written, round 2: 5.97 / 0.27)
-SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (3.77784e9 + 3.2235e7) + (5.45788e8 + 9.6339e7)) * 1024.0}
+# the same launch on the bf16-pipe path (profiles/r03_pmc/v3_syrkbx_n40960_p401408_*.csv, final code of round 3: 7 chunk
+# launches of gemm256_bx_kernel<6> + 7 of bx_split_kernel, summed; the in-loop chain flushes add the Gram matrix's own
+# read-modify-write traffic: 6.16 TB fetched / 0.61 TB written; with 512-k chains on the diagonal tiles it was 7.74 / 0.66,
+# round 2 on 8192-k chains: 5.97 / 0.27)
+SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.975917e9 + 3.2229e7) + (5.02774e8 + 9.6339e7)) * 1024.0}
 # clock the chip holds under that kernel, measured OUTSIDE this process (the product library carries no stamps):
 # in-kernel s_memtime / s_memrealtime stamps of a diagnostic build (scripts/probe/bx_clock.py + libstamp.so, median over
 # the 12 880 workgroups of the last chunk launch after 6 s of back-to-back SYRKs on the bench's own factors;
-# profiles/r03_pmc/bx_clock_real.txt) and GRBM_GUI_ACTIVE / 8 / duration of the PMC pass on N(0,1) data
-SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors": 1.825, "in_kernel_stamps_randn": 1.707,
-                                                  "pmc_grbm_gui_active_randn": 1.733, "nominal": 2.4,
-                                                  "mfma_pipe_busy_pmc": 0.724}}
+# profiles/r03_pmc/v3_bx_clock_real.txt) and GRBM_GUI_ACTIVE / 8 / duration of the PMC pass on N(0,1) data
+SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors": 1.862, "in_kernel_stamps_randn": 1.725,
+                                                  "pmc_grbm_gui_active_randn": 1.771, "nominal": 2.4,
+                                                  "mfma_pipe_busy_pmc": 0.728}}
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
 MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 MFMA peak (256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz; same guide)
 
@@ -715,7 +716,7 @@ def main():
                     "traffic_note": "bytes of the first-layer weight's SYRK (98.6 % of the Gram flops: split pass + 7 chunk launches), "
                                     "separate rocprofv3 --pmc passes (profiles/r03_pmc), FETCH_SIZE includes Infinity-Cache hits",
                     "clock_ghz": SYRK_BX_CLOCK_GHZ.get((args.workload, world)) if split == 6 else None,
-                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.72) x (clock / 2.4 GHz); "
+                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.73) x (clock / 2.4 GHz); "
                                   "measured with a diagnostic build and a PMC pass, not in this run (profiles/r03_pmc)",
                 }
             roofline.update({

@@ -316,12 +316,16 @@ __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ 
     for (int k = 0; k < ks; ++k) {
       const int c0 = s + 1 + k * NB;
       const int L = (n - c0) < NB ? (n - c0) : NB;
+#if !(defined(SB2ST_PVAR) && SB2ST_PVAR == 2)   // (2: timing only, wrong results: nobody waits -- the throughput without the chain)
       if (tid == 0 && s > 0) wait_for(s - 1, false, k + 1);
+#endif
       __syncthreads();   // (also: the previous task's LDS reads are done)
       if (s_info[1]) break;
       Sb2stRows rows;
       sb2st_load<true>(AB, c0, L, wave, lane, rows);
+#if !(defined(SB2ST_PVAR) && SB2ST_PVAR == 2)
       if (tid == 0 && s > 0) wait_for(s - 1, true, k + 2 < kprev ? k + 2 : kprev);
+#endif
       __syncthreads();
       if (s_info[1]) break;
       if (wave == 3 && L == NB) {   // the last row again, now that its owner has stored it
@@ -331,7 +335,13 @@ __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ 
       }
       float x = 0.f;
       if (k == 0) x = lane < L ? band_ld<true>(AB + (int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)) : 0.f;  // column s of the band
+#if defined(SB2ST_PVAR) && SB2ST_PVAR == 1   // timing only (wrong results): no arithmetic, the hand-over chain alone
+      float beta = x;
+      lds.sE[tid] = rows.ev[0]; lds.sD[tid] = rows.dv[0];
+      __syncthreads();
+#else
       const float beta = sb2st_core(k, L, wave, lane, rows, x, pv, ptau, lds);
+#endif
       // ---- first row out, counter A
       if (wave == 0) {
         if (k == 0 && lane == 0) band_st<true>(AB + (int64_t)c0 * LDAB + (2 * NB - 1), beta);

@@ -434,6 +434,142 @@ static bool qr_persist_launch(float *pan, int64_t mp, int ncol, void *wsp, float
   return true;
 }
 
+// ---- 64-row products against a k-major operand:  Out[64][N] = alpha Coef[64][K] B[K][N] + beta Out  (B rows = the k-major
+// stacks of the band reduction, leading dimension ldb; K = 64 .. 384, a multiple of 32).  The tile kernels spend 36-69 us on
+// these shapes at N = 40 960 (one 16-k pipeline step per 64 bytes of an operand row: 0.3 TB/s); this kernel gives a workgroup
+// 256 columns, stages 32 k at a time (B chunk 32 x 256 as float4 rows, Coef chunk 64 x 32) and runs v_mfma_f32_32x32x2f32 from
+// LDS: MFMA-bound at ~7 us for K = 128.
+struct Sk64Args {
+  const float *Coef;   // [64][ldcoef], Coef[m][k]
+  const float *B;
+  float *Out;
+  int64_t ldcoef, ldb, ldo, N;
+  int K;
+  float alpha, beta;
+};
+constexpr int SK_LDC = 36, SK_COLS = 128, SK_LDB = SK_COLS + 4, SK_NT = SK_COLS / 64;   // 128 columns per workgroup: 320 workgroups at N = 40 960
+
+__global__ __launch_bounds__(256) void skinny64_kernel(Sk64Args p) {
+  __shared__ __attribute__((aligned(16))) float sC[64 * SK_LDC];
+  __shared__ __attribute__((aligned(16))) float sB[32 * SK_LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int64_t c0 = (int64_t)blockIdx.x * SK_COLS;
+  f32x16 acc[SK_NT];
+#pragma unroll
+  for (int t = 0; t < SK_NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  constexpr int NLB = 32 * SK_COLS / 4 / 256;   // float4 loads of the B chunk per thread
+  float4 rc[2], rb[NLB];
+  auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      const int m = idx >> 3, kq = (idx & 7) * 4;
+      rc[i] = *reinterpret_cast<const float4 *>(p.Coef + (int64_t)m * p.ldcoef + k0 + kq);
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int idx = tid + 256 * i;
+      const int kr = idx / (SK_COLS / 4), cq = (idx % (SK_COLS / 4)) * 4;
+      const int64_t c = c0 + cq;
+      rb[i] = *reinterpret_cast<const float4 *>(p.B + (int64_t)(k0 + kr) * p.ldb + (c < p.N ? c : 0));   // (N % 4 == 0)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  gload(0);
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      *reinterpret_cast<float4 *>(sC + (idx >> 3) * SK_LDC + (idx & 7) * 4) = rc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int idx = tid + 256 * i;
+      const int kr = idx / (SK_COLS / 4), cq = (idx % (SK_COLS / 4)) * 4;
+      *reinterpret_cast<float4 *>(sB + kr * SK_LDB + cq) = c0 + cq < p.N ? rb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    if (k0 + 32 < p.K) gload(k0 + 32);
+    const float *pa = sC + (32 * wm + r) * SK_LDC + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // k = 8 j + 4 h + i: lanes 0-31 supply k, lanes 32-63 k + 4
+      const float4 a4 = *reinterpret_cast<const float4 *>(pa + 8 * j);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+      float bv[4][SK_NT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < SK_NT; ++t) bv[i][t] = sB[(8 * j + 4 * h + i) * SK_LDB + 64 * wn + 32 * t + r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < SK_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i][t], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < SK_NT; ++t) {
+    const int64_t c = c0 + 64 * wn + 32 * t + r;
+    if (c < p.N) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float *o = p.Out + (int64_t)m * p.ldo + c;
+        float v = p.alpha * acc[t][e];
+        if (p.beta != 0.f) v += p.beta * *o;
+        *o = v;
+      }
+    }
+  }
+}
+
+// applicable: 16-byte aligned rows everywhere, K a multiple of 32, N a multiple of 4
+static bool skinny64_launch(const float *Coef, int64_t ldcoef, const float *B, int64_t ldb, float *Out, int64_t ldo, int64_t N, int64_t K,
+                            float alpha, float beta, hipStream_t stream) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("VIVIT_SY2SB_FUSED"); on = e ? atoi(e) : 1; }
+  if (!on || K < 32 || K % 32 != 0 || K > 4096 || N % 4 != 0 || ldb % 4 != 0 || ldcoef % 4 != 0 ||
+      (reinterpret_cast<uintptr_t>(Coef) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
+    return false;
+  Sk64Args a;
+  a.Coef = Coef; a.B = B; a.Out = Out; a.ldcoef = ldcoef; a.ldb = ldb; a.ldo = ldo; a.N = N; a.K = (int)K; a.alpha = alpha; a.beta = beta;
+  skinny64_kernel<<<(unsigned)cdiv(N, SK_COLS), 256, 0, stream>>>(a);
+  return true;
+}
+
+// Coef[64][128] = [ -1/2 T^T G T | T^T ]  (G = P^T-side Gram block Pt Vt^T): with the k-major rows [Vt; Pt] of the stack,
+// Wt = Coef [Vt; Pt] = T^T Pt - 1/2 (T^T G T) Vt  -- the panel's W in ONE pass, X = P T never materialised.  One workgroup.
+__global__ __launch_bounds__(256) void w_coef_kernel(const float *__restrict__ T, const float *__restrict__ G, float *__restrict__ Coef) {
+  __shared__ float sT[SNB][SNB + 1], sG[SNB][SNB + 1], sU[SNB][SNB + 1];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < SNB * SNB; idx += 256) {
+    sT[idx / SNB][idx % SNB] = T[idx];
+    sG[idx / SNB][idx % SNB] = G[idx];
+  }
+  __syncthreads();
+  // U = T^T G:  U[a][b] = sum_k T[k][a] G[k][b]
+  for (int idx = tid; idx < SNB * SNB; idx += 256) {
+    const int a = idx / SNB, b = idx % SNB;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < SNB; ++k) acc = fmaf(sT[k][a], sG[k][b], acc);
+    sU[a][b] = acc;
+  }
+  __syncthreads();
+  // Y = U T:  Y[a][b] = sum_k U[a][k] T[k][b]
+  for (int idx = tid; idx < SNB * SNB; idx += 256) {
+    const int a = idx / SNB, b = idx % SNB;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < SNB; ++k) acc = fmaf(sU[a][k], sT[k][b], acc);
+    Coef[a * 2 * SNB + b] = -0.5f * acc;
+    Coef[a * 2 * SNB + SNB + b] = sT[b][a];
+  }
+}
+
 // R (upper triangular, rows 0..min(NB, mp)-1 of the factored panel) back into A; zeros below it inside
 // the band rows.
 __global__ __launch_bounds__(256) void sb_panel_store_kernel(float *__restrict__ A, int64_t lda, int64_t j0, int64_t mp,
@@ -557,7 +693,7 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
   };
   // W = X - 1/2 V (T^T V^T X) with X = A22 V T for the panel at j0; Vt, Wt: [SNB][mp] k-major at column offset gi0.
   // fix_pt (optional) corrects P^T = V^T A22 for updates of A22 that have not been applied to memory yet.
-  auto compute_w = [&](int64_t j0, float *Vt, float *Wt, auto fix_pt) -> int {
+  auto compute_w = [&](int64_t j0, float *Vt, float *Wt, float *Wcopy, auto fix_pt) -> int {
     const int64_t mp = n - j0 - SNB, gi0 = j0 + SNB;
     const int ncol = (int)(mp < SNB ? mp : SNB);
     float *A22 = A + gi0 * lda + gi0;
@@ -572,25 +708,27 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     if (st != VIVIT_OK) return st;
     st = fix_pt(Wt);
     if (st != VIVIT_OK) return st;
-    // Xt = T^T Pt  (in place is not possible for a GEMM: scratch block)
+    // W in one pass over the stack rows [Vt; Pt] (they are adjacent: Vt = Wt - SNB rows):  Wt = T^T Pt - 1/2 (T^T G T) Vt,
+    // G = Pt Vt^T.  The result goes to the copy in the other stack first (a product cannot overwrite its operand).
+    st = gemm_launch(LAY_K, LAY_K, Wt, Vt, ws.S2, SNB, SNB, mp, ldn, ldn, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    w_coef_kernel<<<1, 256, 0, stream>>>(ws.T, ws.S2, ws.G12);   // (G12 is free again: fix_pt is done)
+    if (Wt == Vt + (int64_t)SNB * ldn &&
+        skinny64_launch(ws.G12, 2 * SNB, Vt, ldn, Wcopy, ldn, mp, 2 * SNB, 1.f, 0.f, stream))
+      return hipMemcpy2DAsync(Wt, sizeof(float) * ldn, Wcopy, sizeof(float) * ldn, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
+                              stream) == hipSuccess ? VIVIT_OK : VIVIT_E_LAUNCH;
+    // (unaligned leading dimension: the general products)  Xt = T^T Pt, Wt = Xt - 1/2 Y3 Vt with Y3 = T^T G T
     float *Xt = ws.xt + gi0;
     st = gemm_launch(LAY_M, LAY_M, ws.T, Wt, Xt, SNB, mp, SNB, SNB, ldn, ldn, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    // S2^T = Xt Vt^T                   [SNB x SNB]
-    st = gemm_launch(LAY_K, LAY_K, Xt, Vt, ws.S2, SNB, SNB, mp, ldn, ldn, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
-    if (st != VIVIT_OK) return st;
-    // Y3 = S2^T T
-    st = gemm_launch(LAY_K, LAY_M, ws.S2, ws.T, ws.Y3, SNB, SNB, SNB, SNB, SNB, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
-    if (st != VIVIT_OK) return st;
-    // Wt = Xt - 1/2 Y3 Vt
     if (hipMemcpy2DAsync(Wt, sizeof(float) * ldn, Xt, sizeof(float) * ldn, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
                          stream) != hipSuccess)
       return VIVIT_E_LAUNCH;
-    return gemm_launch(LAY_K, LAY_M, ws.Y3, Vt, Wt, SNB, mp, SNB, SNB, ldn, ldn, -0.5f, 1.f, false, ws.gws, ws.gws_bytes, stream);
-  };
-  auto copy_rows = [&](float *dst, const float *src, int64_t cols) -> int {  // [SNB][cols] between k-major stacks
-    return hipMemcpy2DAsync(dst, sizeof(float) * ldn, src, sizeof(float) * ldn, sizeof(float) * cols, SNB,
-                            hipMemcpyDeviceToDevice, stream) == hipSuccess ? VIVIT_OK : VIVIT_E_LAUNCH;
+    // (first half of the coefficient block, ld 2 SNB, is -1/2 Y3)
+    st = gemm_launch(LAY_K, LAY_M, ws.G12, Vt, Wt, SNB, mp, SNB, 2 * SNB, ldn, ldn, 1.f, 1.f, false, ws.gws, ws.gws_bytes, stream);
+    if (st != VIVIT_OK) return st;
+    return hipMemcpy2DAsync(Wcopy, sizeof(float) * ldn, Wt, sizeof(float) * ldn, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
+                            stream) == hipSuccess ? VIVIT_OK : VIVIT_E_LAUNCH;
   };
 
   // Panels are processed in GROUPS of SGRP with ONE rank-(2 SNB SGRP) update of the trailing matrix per group
@@ -626,12 +764,11 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
         int s2 = gemm_launch(LAY_K, LAY_K, Vrow + gi, sA + gi, ws.G12, SNB, kp, mp, ldn, ldn, kp, 1.f, 0.f, false, ws.gws,
                              ws.gws_bytes, stream);
         if (s2 != VIVIT_OK) return s2;
+        if (skinny64_launch(ws.G12, kp, sB + gi, ldn, Pt, ldn, mp, kp, -1.f, 1.f, stream)) return VIVIT_OK;
         return gemm_launch(LAY_K, LAY_M, ws.G12, sB + gi, Pt, SNB, mp, kp, kp, ldn, ldn, -1.f, 1.f, false, ws.gws, ws.gws_bytes,
                            stream);
       };
-      st = compute_w(j0, Vrow + gi, Wrow + gi, fix);
-      if (st != VIVIT_OK) return st;
-      st = copy_rows(sB + kp * n + gi, Wrow + gi, mp);
+      st = compute_w(j0, Vrow + gi, Wrow + gi, sB + kp * n + gi, fix);   // W -> sA rows kp + SNB.. and sB rows kp..
       if (st != VIVIT_OK) return st;
       gi_last = gi;
     }

@@ -12,7 +12,7 @@ def med(fn, reps=5):
         torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     return sorted(ts)[len(ts) // 2] * 1e3
 
-for n in (256, 512, 768, 1024, 1280, 1536):
+for n in (256, 512, 768, 1024, 1280, 1536, 2048):
     V = torch.randn(n, 2 * n, device="cuda")
     G = V @ V.T
     w64 = torch.linalg.eigvalsh(G.double().cpu())

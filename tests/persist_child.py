@@ -43,7 +43,7 @@ def main():
         nk = tau2.shape[1]
         # (the last column and the last two rows of tau2 are scratch of the persistent kernel)
         out["sb2st"][str(n)] = {"de": sha(d, e), "tau2": sha(tau2[: n - 2, : nk - 1]), "R2": sha(R2)}
-    for n in (193, 256, 300, 777, 1024, 1280):
+    for n in (193, 256, 300, 777, 1024, 1280, 1500, 2048):
         g = torch.Generator().manual_seed(n)
         M = torch.randn(n, n, generator=g)
         S = (M + M.T).to(DEV)

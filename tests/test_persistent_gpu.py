@@ -43,7 +43,7 @@ def test_sb2st_persistent_is_bit_identical_to_the_launch_chain(runs):
     assert runs["on"]["sb2st"] == runs["off"]["sb2st"]
 
 
-@pytest.mark.parametrize("n", [193, 256, 300, 777, 1024, 1280])
+@pytest.mark.parametrize("n", [193, 256, 300, 777, 1024, 1280, 1500, 2048])   # (above 1280: all 256 CUs, agent-scope exchanges)
 def test_sytrd_persistent_spectrum(runs, n):
     g = torch.Generator().manual_seed(n)
     M = torch.randn(n, n, generator=g)

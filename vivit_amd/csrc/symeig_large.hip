@@ -169,6 +169,7 @@ static bool use_two_stage(int64_t n, bool vectors) {
     forced = e ? atoi(e) : -1;
   }
   if (forced >= 0) return forced != 0 && n > 2 * TS_NB;
+  if (!vectors && sytrd_persist_ok(n)) return false;   // the persistent one-stage reduction (n <= 2048) beats the two stages for values, too
   return vectors ? n >= 4096 : n >= 2048;
 }
 

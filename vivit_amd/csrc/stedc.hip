@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void stebz_kernel(const float *__restrict__ d,
   const double span = fmax((double)gu - (double)gl, 1e-300);
   double a = (double)gl - 1e-7 * span - 1e-300, b = (double)gu + 1e-7 * span + 1e-300;
   const double pivmin = 1e-290;
-  for (int it = 0; it < SB_ROUNDS; ++it) {
+  // nine rounds leave a bracket of 2.6e-9 span, a twentieth of the fp32 spacing at the largest eigenvalue: enough for the fp32
+  // result; the fp64 shifts of the inverse iteration (w64) take all twelve
+  const int rounds = w64 ? SB_ROUNDS : SB_ROUNDS - 3;
+  for (int it = 0; it < rounds; ++it) {
     const double h = (b - a) / (double)(SB_LANES + 1);
     const double x = a + h * (double)(sub + 1);
     // count eigenvalues < x

@@ -10,7 +10,7 @@ Every line is timed three ways so that the share of the factor provider is visib
                      back-projection and normalisation for ``eigh``; + gammas / lambdas / step for the Newton step)
   path_s             total_s - factors_s: the hot path itself (what the reference spends in vivit/utils/gram.py,
                      Tensor.symeig and the einsums behind them)
-Median of ``reps`` after one warm-up, wall clock around ``torch.cuda.synchronize()``.
+Median of ``reps`` (3) after one warm-up, wall clock around ``torch.cuda.synchronize()``.
 """
 import time
 
@@ -77,7 +77,7 @@ def _median(fn, reps):
         fn()
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
-    return sorted(ts)[len(ts) // 2]
+    return sorted(ts)[(len(ts) - 1) // 2]   # median (the lower one of an even count: a single hiccup must not set the line)
 
 
 class _Problem:
@@ -128,7 +128,7 @@ class _Problem:
                 "factor_share": t_fac / t_tot, "note": note}
 
 
-def run_configs(device, reps=2, which=("1", "3", "4", "5"), progress=lambda m: None):
+def run_configs(device, reps=3, which=("1", "3", "4", "5"), progress=lambda m: None):
     """Returns the list of config lines; each config is skipped (with the reason) rather than failing the benchmark."""
     import vivit_amd
 

@@ -37,7 +37,7 @@ extern "C" {
 #define VIVIT_E_UNSUPPORTED (-4)
 
 /* Library/ABI version (major*1000 + minor) and the gfx target it was compiled for. */
-int vivit_hip_abi_version(void);   /* 1004 in this release; _lib.py refuses an older library */
+int vivit_hip_abi_version(void);   /* 1005 in this release; _lib.py refuses any other library */
 const char *vivit_hip_target(void);
 const char *vivit_hip_status_string(int status);
 

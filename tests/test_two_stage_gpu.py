@@ -194,3 +194,35 @@ def test_two_stage_default_size_degenerate_inputs():
     w, Z = kernels.symeig(3.0 * torch.eye(n, device=DEV), eigenvectors=True)
     assert float((w - 3.0).abs().max()) == 0.0
     assert float((Z.T @ Z - torch.eye(n, device=DEV)).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("mp", [64, 100, 1000, 5000, 20000])
+def test_panel_qr_entry(mp):
+    """vivit_sy2sb_panel_qr_f32 on its own (the replicated step of the sharded band reduction): Q = I - V T V^T is
+    orthogonal, Q^T A = [R; 0] with R = strict upper triangle left in the panel + betas, and |R| equals LAPACK's."""
+    from vivit_amd import kernels
+
+    g = torch.Generator().manual_seed(mp)
+    A0 = torch.randn(mp, NB, generator=g)
+    pan = A0.clone().to(DEV)
+    Vt, tau, betas, T = kernels.panel_qr_(pan)
+    V = Vt.double().cpu().T                      # [mp, 64]
+    Td, A0d = T.double().cpu(), A0.double()
+    ncol = min(mp, NB)
+    R = torch.triu(pan[:ncol].double().cpu(), 1) + torch.diag(betas.double().cpu())[:ncol]
+    # unit lower trapezoidal V
+    assert torch.equal(torch.diagonal(V[:ncol]), torch.ones(ncol, dtype=torch.float64))
+    assert float(torch.triu(V[:ncol], 1).abs().max()) == 0.0
+    QtA = A0d - V @ (Td.T @ (V.T @ A0d))         # Q^T A = (I - V T^T V^T) A
+    scale = float(A0d.abs().max()) * (mp ** 0.5)
+    assert float((QtA[:ncol] - R).abs().max()) <= 2e-6 * scale
+    if mp > ncol:
+        assert float(QtA[ncol:].abs().max()) <= 2e-6 * scale
+    # T^-1 + T^-T = V^T V  (the defining identity of the compact-WY factor of an orthogonal Q)
+    S = V.T @ V
+    kk = int((tau != 0).sum())                   # (a square panel's last reflector is the identity: tau = 0)
+    assert kk >= ncol - 1 and bool((tau[:kk] != 0).all())
+    Tinv = torch.linalg.inv(Td[:kk, :kk])
+    assert float((Tinv + Tinv.T - S[:kk, :kk]).abs().max()) <= 1e-4
+    Rl = np.linalg.qr(A0d.numpy(), mode="r")
+    assert np.abs(np.abs(Rl[:ncol]) - np.abs(R.numpy())).max() <= 2e-6 * scale

@@ -63,6 +63,34 @@ __global__ __launch_bounds__(256) void sb_panel_load_kernel(const float *__restr
   pan[idx] = A[(j0 + SNB + r) * lda + j0 + c];
 }
 
+// The same panel read from the block ROW j0 (the matrix is stored in full: A[j0 + c][j0 + SNB + r] = A[j0 + SNB + r][j0 + c]):
+// 64 x 64 tiles transposed through LDS, reads and writes both contiguous.  (Row mode: the pending updates of a group are
+// applied to the block row with the 64-row kernel, see sy2sb_launch.)
+__global__ __launch_bounds__(256) void sb_panel_load_row_kernel(const float *__restrict__ A, int64_t lda, int64_t j0, int64_t mp,
+                                                                float *__restrict__ pan) {
+  __shared__ float t[SNB][SNB + 1];
+  const int64_t r0 = (int64_t)blockIdx.x * SNB;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < SNB * SNB; idx += 256) {
+    const int c = idx / SNB, rr = idx % SNB;
+    t[c][rr] = r0 + rr < mp ? A[(j0 + c) * lda + j0 + SNB + r0 + rr] : 0.f;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < SNB * SNB; idx += 256) {
+    const int rr = idx / SNB, c = idx % SNB;
+    if (r0 + rr < mp) pan[(r0 + rr) * SNB + c] = t[c][rr];
+  }
+}
+
+// Coef[m][k] = S[k][g + m]: the 64 x kp coefficient block of a block-row update from the k-major stack
+__global__ __launch_bounds__(256) void coef_gather_kernel(const float *__restrict__ S, int64_t lds_, int64_t g, int kp,
+                                                          float *__restrict__ Coef) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= SNB * kp) return;
+  const int k = idx / SNB, m = idx % SNB;
+  Coef[(int64_t)m * kp + k] = S[(int64_t)k * lds_ + g + m];
+}
+
 // ---- fused panel QR step: ONE launch per column (the dependent kernel boundary is what a column costs).
 // Launch c (c = -1: prologue) does, per 128-row workgroup tile held in LDS:
 //   1. sums the per-workgroup partials of column c left by launch c-1:  u[cc] = sum_{r>c} x_r pan[r][cc]
@@ -529,11 +557,14 @@ __global__ __launch_bounds__(256) void skinny64_kernel(Sk64Args p) {
 }
 
 // applicable: 16-byte aligned rows everywhere, K a multiple of 32, N a multiple of 4
-static bool skinny64_launch(const float *Coef, int64_t ldcoef, const float *B, int64_t ldb, float *Out, int64_t ldo, int64_t N, int64_t K,
-                            float alpha, float beta, hipStream_t stream) {
+static bool skinny64_enabled() {
   static int on = -1;
   if (on < 0) { const char *e = getenv("VIVIT_SY2SB_FUSED"); on = e ? atoi(e) : 1; }
-  if (!on || K < 32 || K % 32 != 0 || K > 4096 || N % 4 != 0 || ldb % 4 != 0 || ldcoef % 4 != 0 ||
+  return on != 0;
+}
+static bool skinny64_launch(const float *Coef, int64_t ldcoef, const float *B, int64_t ldb, float *Out, int64_t ldo, int64_t N, int64_t K,
+                            float alpha, float beta, hipStream_t stream) {
+  if (!skinny64_enabled() || K < 32 || K % 32 != 0 || K > 4096 || N % 4 != 0 || ldb % 4 != 0 || ldcoef % 4 != 0 ||
       (reinterpret_cast<uintptr_t>(Coef) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
     return false;
   Sk64Args a;
@@ -705,11 +736,16 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
 
   const int64_t ldn = n;
   // Householder QR of the panel at column j0 (rows gi0 = j0 + SNB ..): reflector t in row t of v1 and v2
+  // Row mode (16-byte aligned rows, n % 4 == 0): the pending updates of a group go to the block ROW that holds the next panel
+  // (64 x (n - j0): the 64-row MFMA kernel; the tall 64-column form on the tile kernels took 60-100 us per panel) and the panel
+  // is read from there; the block column below the band then keeps stale values that nothing reads.
+  const bool rowmode = skinny64_enabled() && (n % 4 == 0) && (lda % 4 == 0) && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
   auto factor_panel = [&](int64_t j0, float *v1, float *v2) -> int {
     const int64_t mp = n - j0 - SNB, gi0 = j0 + SNB;
     const int ncol = (int)(mp < SNB ? mp : SNB);
     const int g = (int)cdiv(mp, QT);
-    sb_panel_load_kernel<<<(unsigned)cdiv(mp * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan);
+    if (rowmode) sb_panel_load_row_kernel<<<(unsigned)cdiv(mp, SNB), 256, 0, stream>>>(A, lda, j0, mp, ws.pan);
+    else sb_panel_load_kernel<<<(unsigned)cdiv(mp * SNB, 256), 256, 0, stream>>>(A, lda, j0, mp, ws.pan);
     if (!qr_persist_launch(ws.pan, mp, ncol, ws.qpw, v1, v2, ldn, gi0, A, lda, j0, ws.tau1, ws.betas, stream))
       for (int c = -1; c < ncol; ++c)  // c = -1: partials of column 0
         qr_step_kernel<<<g, 256, 0, stream>>>(ws.pan, mp, c, ncol, g, ws.qp, v1, v2, ldn, gi0, A, lda, j0, ws.tau1, ws.betas);
@@ -775,9 +811,17 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
       if (np > 0) {
         // pending updates on the block column that becomes this panel: rows gi - SNB .., columns gi - SNB .. gi - 1
         const int64_t gc = gi - SNB;
-        st = gemm_launch(LAY_M, LAY_M, sA + gc, sB + gc, A + gc * lda + gc, n - gc, SNB, kp, ldn, ldn, lda, -1.f, 1.f, false,
-                         ws.gws, ws.gws_bytes, stream);
-        if (st != VIVIT_OK) return st;
+        bool done = false;
+        if (rowmode) {   // A[gc : gc + 64, gc :] -= (sA[:, gc : gc + 64])^T sB[:, gc :]   (the update matrix is symmetric)
+          coef_gather_kernel<<<(unsigned)cdiv(SNB * kp, 256), 256, 0, stream>>>(sA, ldn, gc, (int)kp, ws.G12);
+          done = skinny64_launch(ws.G12, kp, sB + gc, ldn, A + gc * lda + gc, lda, n - gc, kp, -1.f, 1.f, stream);
+        }
+        if (!done) {
+          if (rowmode) return VIVIT_E_UNSUPPORTED;   // (cannot happen: rowmode implies the kernel applies)
+          st = gemm_launch(LAY_M, LAY_M, sA + gc, sB + gc, A + gc * lda + gc, n - gc, SNB, kp, ldn, ldn, lda, -1.f, 1.f, false,
+                           ws.gws, ws.gws_bytes, stream);
+          if (st != VIVIT_OK) return st;
+        }
       }
       // V -> sA rows kp.., sB rows kp + SNB..;  W -> sA rows kp + SNB.., sB rows kp..
       float *Vrow = sA + kp * n, *Wrow = sA + (kp + SNB) * n;

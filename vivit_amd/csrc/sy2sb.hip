@@ -618,13 +618,13 @@ __global__ __launch_bounds__(256) void sb_panel_store_kernel(float *__restrict__
 // Two diagonal half blocks by column-parallel back substitution (device_utils.h:tfactor_column: the longest column is 496
 // dependent multiply-adds instead of 2016), then the coupling block T12 = -T11 S12 T22 as two 32^3 products over 256 threads:
 // 43 -> ~16 us per panel.
-__global__ __launch_bounds__(256) void larft_kernel(const float *__restrict__ S, const float *__restrict__ tau, int nb,
+__global__ __launch_bounds__(256) void larft_kernel(const float *__restrict__ S, int64_t lds_, const float *__restrict__ tau, int nb,
                                                     int nvalid, float *__restrict__ T) {
   constexpr int H = SNB / 2, LD = SNB + 1;
   __shared__ float Ss[SNB * LD], Ts[SNB * LD], Xs[H * (H + 1)], taus[SNB];
   const int tid = threadIdx.x;
   for (int idx = tid; idx < SNB * SNB; idx += 256) {
-    Ss[(idx / SNB) * LD + (idx % SNB)] = S[idx];
+    Ss[(idx / SNB) * LD + (idx % SNB)] = S[(int64_t)(idx / SNB) * lds_ + (idx % SNB)];
     Ts[(idx / SNB) * LD + (idx % SNB)] = 0.f;
   }
   if (tid < SNB) taus[tid] = (tid < nvalid && tid < nb) ? tau[tid] : 0.f;
@@ -673,7 +673,7 @@ static size_t sy2sb_gemm_ws_bytes(int64_t n) {
     size_t c = gemm_workspace_bytes(SNB, q, SNB, false);
     size_t d = 0, e = 0, f = 0;
     for (int g = 1; g < SGRP; ++g) {
-      const size_t d1 = gemm_workspace_bytes(SNB, 2 * SNB * g, q, false), e1 = gemm_workspace_bytes(SNB, q, 2 * SNB * g, false);
+      const size_t d1 = gemm_workspace_bytes(SNB, 2 * SNB * g + SNB, q, false), e1 = gemm_workspace_bytes(SNB, q, 2 * SNB * g, false);
       const size_t f1 = gemm_workspace_bytes(q, SNB, 2 * SNB * g, false);
       d = d1 > d ? d1 : d; e = e1 > e ? e1 : e; f = f1 > f ? f1 : f;
     }
@@ -753,27 +753,33 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     return launch_status();
   };
   // W = X - 1/2 V (T^T V^T X) with X = A22 V T for the panel at j0; Vt, Wt: [SNB][mp] k-major at column offset gi0.
-  // fix_pt (optional) corrects P^T = V^T A22 for updates of A22 that have not been applied to memory yet.
-  auto compute_w = [&](int64_t j0, float *Vt, float *Wt, float *Wcopy, auto fix_pt) -> int {
+  // kp > 0: P^T = V^T A22 is corrected for the kp / 2 SNB pending updates of A22 that have not been applied to memory yet.
+  auto compute_w = [&](int64_t j0, float *Vt, float *Wt, float *Wcopy, int64_t kp, const float *sAg, const float *sBg) -> int {
     const int64_t mp = n - j0 - SNB, gi0 = j0 + SNB;
     const int ncol = (int)(mp < SNB ? mp : SNB);
     float *A22 = A + gi0 * lda + gi0;
     int st;
-    // S = Vt Vt^T, T = larft(S, tau)
-    st = gemm_launch(LAY_K, LAY_K, Vt, Vt, ws.S, SNB, SNB, mp, ldn, ldn, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
-    if (st != VIVIT_OK) return st;
-    larft_kernel<<<1, 256, 0, stream>>>(ws.S, ws.tau1 + j0, SNB, ncol, ws.T);
     // Pt = Vt A22                      [SNB x mp]   (A22 symmetric: B operand k-major = A22 itself; the big
     // operand is streamed exactly once: gemm64_dma_kernel)
     st = gemm_launch(LAY_K, LAY_M, Vt, A22, Wt, SNB, mp, mp, ldn, lda, ldn, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    st = fix_pt(Wt);
+    // [G12 | S] = Vt [V1 W1 .. V]^T: the stack rows 0 .. kp + SNB - 1 end with this panel's V, so the Gram blocks against the
+    // pending updates (G12, for the correction of Pt) and against itself (S, for T) are ONE deep-K product
+    const int64_t ldg = kp + SNB;
+    st = gemm_launch(LAY_K, LAY_K, Vt, sAg, ws.G12, SNB, ldg, mp, ldn, ldn, ldg, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
+    larft_kernel<<<1, 256, 0, stream>>>(ws.G12 + kp, ldg, ws.tau1 + j0, SNB, ncol, ws.T);
+    if (kp > 0) {   // Pt -= G12 [W1^T; V1^T; ...]: P^T = V^T A22 was formed from the not yet updated trailing matrix
+      if (!skinny64_launch(ws.G12, ldg, sBg, ldn, Wt, ldn, mp, kp, -1.f, 1.f, stream)) {
+        st = gemm_launch(LAY_K, LAY_M, ws.G12, sBg, Wt, SNB, mp, kp, ldg, ldn, ldn, -1.f, 1.f, false, ws.gws, ws.gws_bytes, stream);
+        if (st != VIVIT_OK) return st;
+      }
+    }
     // W in one pass over the stack rows [Vt; Pt] (they are adjacent: Vt = Wt - SNB rows):  Wt = T^T Pt - 1/2 (T^T G T) Vt,
     // G = Pt Vt^T.  The result goes to the copy in the other stack first (a product cannot overwrite its operand).
     st = gemm_launch(LAY_K, LAY_K, Wt, Vt, ws.S2, SNB, SNB, mp, ldn, ldn, SNB, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
     if (st != VIVIT_OK) return st;
-    w_coef_kernel<<<1, 256, 0, stream>>>(ws.T, ws.S2, ws.G12);   // (G12 is free again: fix_pt is done)
+    w_coef_kernel<<<1, 256, 0, stream>>>(ws.T, ws.S2, ws.G12);   // (G12 is free again: T and the correction are done)
     if (Wt == Vt + (int64_t)SNB * ldn &&
         skinny64_launch(ws.G12, 2 * SNB, Vt, ldn, Wcopy, ldn, mp, 2 * SNB, 1.f, 0.f, stream))
       return hipMemcpy2DAsync(Wt, sizeof(float) * ldn, Wcopy, sizeof(float) * ldn, sizeof(float) * mp, SNB, hipMemcpyDeviceToDevice,
@@ -827,17 +833,7 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
       float *Vrow = sA + kp * n, *Wrow = sA + (kp + SNB) * n;
       st = factor_panel(j0, Vrow, sB + (kp + SNB) * n);
       if (st != VIVIT_OK) return st;
-      auto fix = [&](float *Pt) -> int {
-        if (np == 0) return VIVIT_OK;
-        // G = V^T [V1 W1 ...] (rows >= gi), Pt -= G [W1^T; V1^T; ...]
-        int s2 = gemm_launch(LAY_K, LAY_K, Vrow + gi, sA + gi, ws.G12, SNB, kp, mp, ldn, ldn, kp, 1.f, 0.f, false, ws.gws,
-                             ws.gws_bytes, stream);
-        if (s2 != VIVIT_OK) return s2;
-        if (skinny64_launch(ws.G12, kp, sB + gi, ldn, Pt, ldn, mp, kp, -1.f, 1.f, stream)) return VIVIT_OK;
-        return gemm_launch(LAY_K, LAY_M, ws.G12, sB + gi, Pt, SNB, mp, kp, kp, ldn, ldn, -1.f, 1.f, false, ws.gws, ws.gws_bytes,
-                           stream);
-      };
-      st = compute_w(j0, Vrow + gi, Wrow + gi, sB + kp * n + gi, fix);   // W -> sA rows kp + SNB.. and sB rows kp..
+      st = compute_w(j0, Vrow + gi, Wrow + gi, sB + kp * n + gi, kp, sA + gi, sB + gi);   // W -> sA rows kp + SNB.. and sB rows kp..
       if (st != VIVIT_OK) return st;
       gi_last = gi;
     }
@@ -888,7 +884,7 @@ int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float 
       qr_step_kernel<<<g, 256, 0, stream>>>(pan, mp, c, ncol, g, qp, Vt, Vt, ldv, 0, Vt, ldv, 0, tau, betas);
   int st = gemm_launch(LAY_K, LAY_K, Vt, Vt, S, SNB, SNB, mp, ldv, ldv, SNB, 1.f, 0.f, false, gws, gws_bytes, stream);
   if (st != VIVIT_OK) return st;
-  larft_kernel<<<1, 256, 0, stream>>>(S, tau, SNB, ncol, T);
+  larft_kernel<<<1, 256, 0, stream>>>(S, SNB, tau, SNB, ncol, T);
   return launch_status();
 }
 

@@ -18,7 +18,12 @@
  *     eigensolver is reported asynchronously through the device-side `info` word
  *     (0 = converged, k>0 = k off-diagonal elements did not converge), which the host maps to
  *     the reference's RuntimeError (vivit/utils/eig.py:37-40,103-106);
- *   - results are deterministic: no float atomics, fixed reduction orders.
+ *   - results are deterministic (bit-identical from call to call and from process to process on the same device
+ *     type; tests/test_determinism_gpu.py): every reduction has a fixed order.  The one kernel that uses float
+ *     atomics, the bf16-pipe 256 x 256 tile product, adds the partial sum of each 4096-k accumulation chain into C
+ *     with no-return fp32 atomics executed at the memory side -- each output element has exactly ONE writing
+ *     workgroup and ONE writing lane, whose adds to that address are issued and applied in program order, so the
+ *     sum is a fixed-order sum; no two workgroups ever add into the same element.
  */
 #ifndef VIVIT_HIP_H
 #define VIVIT_HIP_H

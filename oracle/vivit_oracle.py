@@ -302,6 +302,16 @@ def loss_hessian_sqrt_mc(output: Tensor, onehots: Tensor) -> Tensor:
     return (p.unsqueeze(0) - onehots) / math.sqrt(M * N)
 
 
+def loss_hessian_sqrt_mc_mse(eps: Tensor) -> Tensor:
+    """MC factor of the MEAN squared error (vivit/extensions/secondorder/vivit/__init__.py:84-86 -> BackPACK
+    ``SqrtGGNMSELoss`` with ``LossHessianStrategy.SAMPLING``, :155-181): the Hessian w.r.t. output[n] is
+    ``2 / (N C) I`` whatever the output is, so its sampled square root is a scaled standard-normal draw,
+    ``S[m, n, :] = sqrt(2 / (M N C)) eps[m, n, :]`` with ``E[sum_m S S^T] = 2 / (N C) I``.
+    ``eps``: [M, N, C] externally supplied N(0, 1) samples (parity needs identical samples)."""
+    M, N, C = eps.shape
+    return eps * math.sqrt(2.0 / (M * N * C))
+
+
 def per_sample_jacobians(model: torch.nn.Module, X: Tensor) -> List[Tensor]:
     """J[p]: [N, C, *param.shape] by brute-force autograd (one backward per (n, c))."""
     params = [p for p in model.parameters() if p.requires_grad]

@@ -138,15 +138,18 @@ def test_sqrt_ggn_and_batch_grad_factors(problem, subsampling, device):
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_mc_factors_with_supplied_samples(problem, device):
     model, X, y, lossf, loss = make_problem(problem)
-    if loss != "ce":
-        pytest.skip("MC factor oracle is stated for cross-entropy")
     ref_model = make_problem(problem)[0]
     out = ref_model(X).detach()
     N, C = out.shape
     gen = torch.Generator().manual_seed(1)
-    idx = torch.multinomial(out.softmax(1), 3, replacement=True, generator=gen)  # [N, M]
-    onehots = torch.nn.functional.one_hot(idx.t(), C).float()
-    V_ref = oracle.sqrt_ggn_factors(ref_model, X, oracle.loss_hessian_sqrt_mc(out, onehots))
+    if loss == "ce":
+        idx = torch.multinomial(out.softmax(1), 3, replacement=True, generator=gen)  # [N, M]
+        onehots = torch.nn.functional.one_hot(idx.t(), C).to(out.dtype)
+        S_ref = oracle.loss_hessian_sqrt_mc(out, onehots)
+    else:  # MSE: the samples are the standard-normal draws themselves (SqrtGGNMSELoss, sampled strategy)
+        onehots = torch.randn(3, N, C, generator=gen, dtype=out.dtype)
+        S_ref = oracle.loss_hessian_sqrt_mc_mse(onehots)
+    V_ref = oracle.sqrt_ggn_factors(ref_model, X, S_ref)
     model, X, y = model.to(device), X.to(device), y.to(device)
     run_backward(model, X, y, lossf, [SqrtGGNMC(mc_samples=3, samples=onehots)])
     for p, v in zip(model.parameters(), V_ref):

@@ -93,3 +93,23 @@ def test_factor_oracle_properties(loss):
     ggn_w = torch.linalg.eigvalsh(ggn)
     k = min(gram_w.numel(), ggn_w.numel())
     np.testing.assert_allclose(gram_w[-k:].numpy(), ggn_w[-k:].numpy(), rtol=1e-8, atol=1e-12)
+
+
+def test_mc_mse_factor_oracle_is_unbiased():
+    """The sampled square root of the MSE loss Hessian (oracle.loss_hessian_sqrt_mc_mse; the reference gets it from
+    BackPACK's SqrtGGNMSELoss, vivit/extensions/secondorder/vivit/__init__.py:84-86,155-181): sum_m S_m S_m^T must
+    converge to the exact Hessian 2 / (N C) I, i.e. to the exact factor's S S^T, and with orthonormal draws it must
+    reproduce it exactly."""
+    N, C, M = 4, 5, 40000
+    gen = torch.Generator().manual_seed(0)
+    eps = torch.randn(M, N, C, generator=gen, dtype=torch.float64)
+    S = oracle.loss_hessian_sqrt_mc_mse(eps)
+    H = torch.einsum("mnc,mnd->ncd", S, S)
+    S_exact = oracle.loss_hessian_sqrt_exact(torch.zeros(N, C, dtype=torch.float64), "mse")
+    H_exact = torch.einsum("vnc,vnd->ncd", S_exact, S_exact)
+    np.testing.assert_allclose(H.numpy(), H_exact.numpy(), atol=0.03 * 2.0 / (N * C))
+    # M = C draws that are sqrt(C) times an orthogonal matrix per sample: the sampled factor IS a square root
+    Qm = torch.linalg.qr(torch.randn(C, C, generator=gen, dtype=torch.float64))[0] * C ** 0.5
+    eps = Qm.unsqueeze(1).expand(C, N, C)
+    S = oracle.loss_hessian_sqrt_mc_mse(eps)
+    np.testing.assert_allclose(torch.einsum("mnc,mnd->ncd", S, S).numpy(), H_exact.numpy(), rtol=1e-12, atol=1e-15)

@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvivit_hip.so")
+# VIVIT_HIP_LIB: another build of the same sources (tests/test_abi_errors_sanitized.py points it at the host-only
+# AddressSanitizer + UBSan build of _build.build_host_sanitized(), which has no device code and cannot compute)
+LIB_PATH = os.environ.get("VIVIT_HIP_LIB") or os.path.join(_HERE, "libvivit_hip.so")
 
 _i64 = ctypes.c_int64
 _f32 = ctypes.c_float
@@ -79,8 +81,16 @@ ABI_VERSION = 1005  # include/vivit_hip.h of this checkout (vivit_hip_abi_versio
 _lib = None
 
 
+# status codes of include/vivit_hip.h
+VIVIT_OK, VIVIT_E_BADARG, VIVIT_E_WORKSPACE, VIVIT_E_LAUNCH, VIVIT_E_UNSUPPORTED = 0, -1, -2, -3, -4
+
+
 class VivitHipError(RuntimeError):
-    """A libvivit_hip.so entry point returned a non-zero status."""
+    """A libvivit_hip.so entry point returned a non-zero status (``.status``: the VIVIT_E_* code)."""
+
+    def __init__(self, message, status=None):
+        super().__init__(message)
+        self.status = status
 
 
 def load():
@@ -112,4 +122,4 @@ def load():
 def check(status, what):
     if status != 0:
         msg = load().vivit_hip_status_string(int(status)).decode()
-        raise VivitHipError(f"{what}: status {status} ({msg})")
+        raise VivitHipError(f"{what}: status {status} ({msg})", int(status))

@@ -115,7 +115,7 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
                     return out.squeeze(4)
                 return kernels.conv2d_weight_mjp(M, x, module.kernel_size, module.stride, module.padding, module.dilation)
             except _lib.VivitHipError as exc:  # shapes outside the kernel's launch limits: the torch rule below
-                if "status -4" not in str(exc):
+                if exc.status != _lib.VIVIT_E_UNSUPPORTED:
                     raise
         return _conv_weight_factor(module, M, x)
     if isinstance(module, _BATCHNORM):
@@ -216,7 +216,12 @@ def _jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Tensor:
     if isinstance(module, _BATCHNORM) and module.training:
         raise NotImplementedError("BatchNorm must be in eval mode")
     if M.is_cuda and M.dtype == torch.float32:
-        g = _hip_jac_t_mat_prod(module, M, x)
+        try:
+            g = _hip_jac_t_mat_prod(module, M, x)
+        except _lib.VivitHipError as exc:  # a shape beyond a kernel's launch limits: the generic rule below
+            if exc.status != _lib.VIVIT_E_UNSUPPORTED:
+                raise
+            g = None
         if g is not None:
             return g
     # generic rule: batched vector-Jacobian product through a recomputed forward (bypasses hooks)

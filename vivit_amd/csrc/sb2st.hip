@@ -406,7 +406,10 @@ int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ld
   const int nk = sb2st_num_levels(n);
   // persistent form: the progress counters sit in tau2's last column (never a task: k < nk - 1), the control block in
   // its unused last row (sweeps end at n - 3)
-  const bool persist = sb2st_persist_enabled() && n >= 960 && (size_t)nk * sizeof(float) >= sizeof(Sb2stCtl);
+  // (all 256 workgroups must be co-resident for the kernel's arrival barrier: one per CU of an unpartitioned 8-XCD part,
+  // as for the other persistent kernels; a CPX partition or a CU-masked device takes the launch chain)
+  const bool persist = sb2st_persist_enabled() && n >= 960 && (size_t)nk * sizeof(float) >= sizeof(Sb2stCtl) &&
+                       device_cu_count() >= 256;
   if (n >= 3 && persist) {
     Sb2stCtl *ctl = reinterpret_cast<Sb2stCtl *>(tau2 + (n - 1) * nk);
     sb2st_zero_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(tau2, ni, nk);

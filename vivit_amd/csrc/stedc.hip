@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void stebz_kernel(const float *__restrict__ d,
       double rq = __builtin_amdgcn_rcp(q);
       rq = fma(fma(-q, rq, 1.0), rq, rq);
       q = (double)d[i] - x - ee * ee * rq;
-      if (fabs(q) < pivmin) q = -pivmin;
+      // |q| is kept inside [pivmin, 1e300]: e^2 / pivmin overflows for |e| > 1e9 and rcp(inf) = 0 would turn the Newton
+      // step (and every later count) into NaN, where the IEEE division recovered with e^2 / inf = 0
+      const double aq = fabs(q);
+      q = aq < pivmin ? -pivmin : (aq > 1e300 ? copysign(1e300, q) : q);   // (a NaN stays a NaN)
       cnt += q < 0.0;
     }
     // shifts are ascending in `sub`, counts non-decreasing: the eigenvalue lies between the last shift with
@@ -708,12 +711,13 @@ int vivit_stedc_f32(float *d, float *e, int64_t n, float *w, float *Z, int64_t l
                     size_t workspace_bytes, int32_t *info, void *stream) {
   if (n < 0 || !info) return VIVIT_E_BADARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // every argument check comes before the first enqueue (a refused call leaves *info untouched)
+  if (n > 0 && (!d || !w || (n > 1 && !e) || (Z && ldz < n))) return VIVIT_E_BADARG;
+  if (n > 0x7fffffffLL / 4) return VIVIT_E_UNSUPPORTED;
+  if (n > 0 && Z && (!workspace || workspace_bytes < stedc_workspace_bytes(n, true))) return VIVIT_E_WORKSPACE;
   if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess) return VIVIT_E_LAUNCH;
   if (n == 0) return VIVIT_OK;
-  if (!d || !w || (n > 1 && !e) || (Z && ldz < n)) return VIVIT_E_BADARG;
-  if (n > 0x7fffffffLL / 4) return VIVIT_E_UNSUPPORTED;
   if (!Z) return stebz_launch(d, e, n, w, nullptr, s);
-  if (!workspace || workspace_bytes < stedc_workspace_bytes(n, true)) return VIVIT_E_WORKSPACE;
   float *Qt, *dd;
   int *order;
   int st = stedc_dc_launch(d, e, n, workspace, &Qt, &dd, &order, info, s);

@@ -207,7 +207,22 @@ def to_parameter_shard(local: torch.Tensor, lead_dims: int, group=None, index: i
     if R == 1:
         return F.reshape(C * Ng, P)
     slices = parameter_slices(P, R, index)
-    return _exchange_columns(F, [(lo, hi) for lo, hi in slices], slices[me][1] - slices[me][0], group)
+    widths = [hi - lo for lo, hi in slices]
+    w_mine = widths[me]
+    nch = -(-max(widths) // EXCHANGE_CHUNK_COLUMNS)
+    if nch <= 1:
+        return _exchange_columns(F, [(lo, hi) for lo, hi in slices], w_mine, group)
+    # column chunks into the final buffer: the peak beside the result is one chunk's send, receive and permuted copy
+    # (a one-shot exchange holds three more copies of the whole shard)
+    out = torch.empty(C * Ng * R, w_mine, dtype=F.dtype, device=F.device)
+    for j in range(nch):
+        cols = [(lo + min(j * EXCHANGE_CHUNK_COLUMNS, w), lo + min((j + 1) * EXCHANGE_CHUNK_COLUMNS, w))
+                for (lo, _), w in zip(slices, widths)]
+        j0, j1 = cols[me][0] - slices[me][0], cols[me][1] - slices[me][0]
+        part = _exchange_columns(F, cols, j1 - j0, group)
+        if j1 > j0:
+            out[:, j0:j1].copy_(part)
+    return out
 
 
 def _pack_columns(F: torch.Tensor, cols: Sequence[Tuple[int, int]]) -> Tuple[torch.Tensor, List[int]]:
@@ -247,13 +262,17 @@ def _exchange_columns(F: torch.Tensor, cols, w_mine: int, group) -> torch.Tensor
     return _class_major(recv, R, C, Ng, w_mine)
 
 
-def check_equal_shards(n_local: int, group=None) -> int:
-    """Global batch size; raises if the ranks' shards differ in size (the block layout needs equal shards)."""
+def check_equal_shards(n_local: int, group=None, *more) -> int:
+    """Global batch size; raises if the ranks' shards differ in size (the block layout needs equal shards).
+
+    ``more``: further per-rank sizes (``None`` allowed) checked in the SAME collective -- every rank makes exactly one
+    call whatever its arguments are, so ranks that disagree on an optional size raise instead of hanging."""
     R = world_size(group)
     if R == 1:
         return n_local
+    mine = (int(n_local),) + tuple(-1 if m is None else int(m) for m in more)
     sizes = [None] * R
-    dist.all_gather_object(sizes, int(n_local), group=group)
+    dist.all_gather_object(sizes, mine, group=group)
     if any(s != sizes[0] for s in sizes):
         raise ValueError(f"batch shards must have equal size on every rank, got {sizes}")
     return n_local * R
@@ -271,9 +290,8 @@ class BatchShardedGram:
         self.group = group
         self.R, self.me = world_size(group), rank_of(group)
         self.C, self.Ng = int(C), int(N_local)
-        check_equal_shards(self.Ng, group)  # unequal shards would give mismatched collective sizes (hang / corruption)
-        if N_grad_local is not None:
-            check_equal_shards(int(N_grad_local), group)
+        # unequal shards would give mismatched collective sizes (hang / corruption); one collective for both sizes
+        check_equal_shards(self.Ng, group, N_grad_local)
         self.N = self.Ng * self.R
         self.n = self.C * self.N
         self.Mg = None if N_grad_local is None else int(N_grad_local)

@@ -170,6 +170,20 @@ def verify_symeig(G, w, Z, block=4096):
             del gram, r
         out["orth_err"] = orth
         out["residual_err"] = res / lam
+        # the same quantity with fp64 ACCUMULATION on 256 sampled eigenvectors against all n (the checker's own fp32 sums
+        # over n terms are not what limits orth_err), and its rms: the maximum above is taken over n^2 = 1.7e9 entries of
+        # rounding noise of size ~ sqrt(n) eps (LAPACK's bound for ||Z^T Z - I|| is p(n) eps), i.e. ~6 sigma
+        g = torch.Generator().manual_seed(0)
+        cols = torch.randperm(n, generator=g)[:256].to(G.device)
+        Zc = Z[:, cols].double()
+        acc = torch.zeros((n, cols.numel()), dtype=torch.float64, device=G.device)
+        for i in range(0, n, block):
+            acc += Z[i:i + block].double().T @ Zc[i:i + block]
+        acc[cols, torch.arange(cols.numel(), device=G.device)] -= 1.0
+        out["orth_err_fp64_sampled"] = acc.abs().max().item()
+        out["orth_rms_fp64_sampled"] = acc.pow(2).mean().sqrt().item()
+        out["orth_noise_scale_sqrt_n_eps"] = float(n) ** 0.5 * 2.0 ** -24
+        del acc, Zc
     return out
 
 
@@ -237,30 +251,44 @@ def _median_time(fn, repeats=3, warm=True):
     return sorted(ts)[len(ts) // 2]
 
 
-def _tune_threads():
+def _tune_threads(dims=(784, 512, 10), C=10, gram_batch=256, eig_n=5120):
     """The box may expose far more hardware threads than this process' CPU share (the r01 baseline ran 128 threads
-    on a 16-core share and was ~5x too slow; OpenMP spin-waits under a CFS quota can be catastrophically slow): time a
-    small GEMM + eigh probe for ascending thread counts, stop as soon as more threads stop helping."""
+    on a 16-core share and was ~5x too slow; OpenMP spin-waits under a CFS quota can be catastrophically slow): time the
+    SAMPLE'S OWN two phases -- the oracle's einsum Gram of the first-layer weight at n = C * gram_batch and
+    torch.linalg.eigh at n = eig_n -- for ascending thread counts up to what the affinity mask allows (32 and 64
+    included where present), and keep the fastest per phase-sum; stop as soon as more threads are clearly slower."""
+    from oracle import vivit_oracle as oracle
+
     ncpu = os.cpu_count() or 8
     try:
-        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
+        affinity = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        pass
-    cands = [c for c in (4, 8, 16, 32, 64) if c <= ncpu] or [ncpu]
-    A = torch.randn(1024, 4096)
-    S = A[:, :1024] + A[:, :1024].T
+        affinity = ncpu
+    ncpu = min(ncpu, affinity)
+    _progress(f"cpu baseline: os.cpu_count() = {os.cpu_count()}, len(os.sched_getaffinity(0)) = {affinity}")
+    cands = [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]
+    if ncpu not in cands and ncpu < 128:
+        cands.append(ncpu)
+    facs = mlp_sqrt_ggn_factors(dims, gram_batch, torch.device("cpu"))
+    V = [max(facs, key=lambda f: f.shape[1]).view(C, gram_batch, -1)]           # the first-layer weight: 98.6 % of the flops
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(eig_n, 64, generator=g)
+    S = A @ A.T + torch.eye(eig_n)
     best, best_t, table = cands[0], float("inf"), {}
     for c in cands:
         torch.set_num_threads(c)
-        t = _median_time(lambda: (A @ A.T, torch.linalg.eigh(S)), repeats=2)
-        table[c] = round(t, 4)
-        _progress(f"cpu baseline: thread probe {c} threads: {t:.3f} s")
+        tg = _median_time(lambda: oracle.compute_gram_mat(V, start_dim=2, flatten=True), repeats=1, warm=c == cands[0])
+        te = _median_time(lambda: torch.linalg.eigh(S), repeats=1, warm=c == cands[0])
+        # weight the phases as the full problem does (Gram ~ n^2 P, eigh ~ n^3): extrapolate each to the headline size
+        t = tg + te
+        table[c] = {"einsum_gram_s": round(tg, 3), "eigh_s": round(te, 3)}
+        _progress(f"cpu baseline: thread probe {c} threads: einsum Gram (n={C * gram_batch}) {tg:.2f} s, eigh (n={eig_n}) {te:.2f} s")
         if t < best_t * 0.97:  # prefer fewer threads unless clearly faster
             best, best_t = c, t
         elif t > best_t * 1.3:
             break              # oversubscribed: do not try even more threads
     torch.set_num_threads(best)
-    return best, table
+    return best, {"affinity": affinity, "cpu_count": os.cpu_count(), "probe": table}
 
 
 def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), eig_batches=(256, 512), repeats=3):
@@ -278,7 +306,7 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), eig_batches=(256, 
     Thread count tuned first (``_tune_threads``)."""
     from oracle import vivit_oracle as oracle
 
-    threads, table = _tune_threads()
+    threads, table = _tune_threads(dims, C, gram_batch=max(batches), eig_n=C * min(eig_batches))
     _progress(f"cpu baseline: {threads} threads (probe {table})")
     cpu = torch.device("cpu")
 
@@ -418,6 +446,9 @@ def main():
     ap.add_argument("--cpu-batches", default="128,256", help="batch sizes of the CPU baseline's einsum-Gram sample")
     ap.add_argument("--cpu-eig-batches", default="512,1024", help="batch sizes of the CPU baseline's eigh sample (n = 10 x batch)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (configs block)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="torch.distributed backend of a multi-rank run (default nccl = RCCL over xGMI; gloo: functional "
+                         "runs, several ranks may share one card)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -430,7 +461,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP device); there is no CPU fallback")
     # (functional testing on a 1-GPU box: VIVIT_DIST_BACKEND=gloo lets several ranks share device 0)
-    backend = os.environ.get("VIVIT_DIST_BACKEND", "nccl")
+    backend = args.backend or os.environ.get("VIVIT_DIST_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     if world > torch.cuda.device_count():
         # ranks share a card (functional runs only): the one-XCD persistent kernels want XCD 0 of their GPU to themselves
@@ -506,9 +537,25 @@ def main():
     if rank == 0:
         _progress(f"factors resident ({sum(f.numel() for f in facs) * 4 / 1e9:.1f} GB on rank 0); warm-up x{args.warmup}")
     for i in range(args.warmup):
-        step(i)
+        w, Z = step(i)
         if rank == 0:
             _progress(f"warm-up step {i + 1} issued")
+    if dist is not None and args.warmup > 0:
+        # self-check before timing: the replicated stages (band reduction, bulge chase, tridiagonal solve) run on every rank
+        # and nothing is broadcast -- the eigenvalues (and the gathered eigenvectors) must be BIT-identical on all ranks
+        gathered = [torch.empty_like(w) for _ in range(world)]
+        dist.all_gather(gathered, w)
+        same = all(torch.equal(gathered[0], g_) for g_ in gathered[1:])
+        if same and Z is not None:
+            chk = Z.view(torch.int32).to(torch.int64).sum().reshape(1)      # order-independent checksum of the bit patterns
+            sums = [torch.empty_like(chk) for _ in range(world)]
+            dist.all_gather(sums, chk)
+            same = all(torch.equal(sums[0], s_) for s_ in sums[1:])
+        if not same:
+            raise SystemExit("ranks disagree bitwise on the eigendecomposition: the replicated stages are not deterministic")
+        if rank == 0:
+            _progress(f"self-check: eigenvalues and eigenvector checksum bit-identical on all {world} ranks")
+        del gathered
     barrier()
     if rank == 0:
         _progress(f"timing {args.steps} steps")
@@ -737,7 +784,7 @@ def main():
             "symv_gbs": (symv_bytes / (symv_ms / 1e3) / 1e9) if symv_ms > 0 else None,
         }
         out = {
-            "metric": "GGN eigenpairs/sec (Gram build + symeig), MLP 784-512-10, batch=4096",
+            "metric": f"GGN eigenpairs/sec (Gram build + symeig), MLP {dims[0]}-{dims[1]}-{dims[2]}, batch={batch}",
             "value": value,
             "unit": "eigenpairs/s",
             "n_gpus": world,

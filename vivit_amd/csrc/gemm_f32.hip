@@ -1963,6 +1963,10 @@ static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same) {
 // factors only reroute non-finite / out-of-range chunks (a localised eigenvector has entries below 2^-100 whose
 // 2^-126-level piece is immaterial, and the reroute would cost that chunk the bf16 pipe's 2.7x).
 static thread_local int tls_bx_gate_mask = BX_GATE_RANGE;
+// true inside a public product (vivit_gram_syrk_f32 / vivit_gemm_*_f32): the profile (roofline.achieved of bench.py) counts
+// the Gram SYRKs of the caller, not the reflector Gram matrices the eigensolver's back-transformation builds internally
+static bool bx_public_product() { return (tls_bx_gate_mask & BX_GATE_TINY) != 0; }
+
 struct BxStrictScope {
   int saved;
   BxStrictScope() : saved(tls_bx_gate_mask) { tls_bx_gate_mask = BX_GATE_RANGE | BX_GATE_TINY; }
@@ -2021,7 +2025,7 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
   if (nsb * 256 > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
   dim3 grid((unsigned)(nsb * 256), (unsigned)p.ksplit, 1);
-  const bool prof = syrk && p.A == p.B && prof_enabled();
+  const bool prof = syrk && p.A == p.B && prof_enabled() && bx_public_product();
   if (prof) prof_begin(0, (double)p.M * (double)(p.M + 1) * (double)p.K, stream);
   const int bx = gemm_split_mode();
   if (bx != 0 && p.ksplit == 1 && workspace &&
@@ -2177,7 +2181,7 @@ static int bx_splitk_launch(int alay, int blay, const GemmArgs &p, bool syrk, vo
   float *slab = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(workspace) + pieces, 256));
   int *flag = reinterpret_cast<int *>(align_up(reinterpret_cast<uintptr_t>(slab) + (size_t)nsplit * (size_t)p.M * (size_t)p.N * sizeof(float), 256));
   if (hipMemsetAsync(flag, 0, 4, stream) != hipSuccess) return VIVIT_E_LAUNCH;
-  const bool prof = syrk && same && prof_enabled();
+  const bool prof = syrk && same && prof_enabled() && bx_public_product();
   if (prof) prof_begin(0, (double)p.M * (double)(p.M + 1) * (double)p.K, stream);
   const unsigned gy = (unsigned)cdiv(p.K / 16, 4);
   if (alay == LAY_K)
@@ -2385,7 +2389,7 @@ int gemm_launch(int alay, int blay, const float *A, const float *B, float *C, in
   if (nsb * 256 > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
   dim3 grid((unsigned)(nsb * 256), (unsigned)p.ksplit, 1);
   dim3 block(256, 1, 1);
-  const bool prof = syrk && A == B && prof_enabled();  // only the Gram SYRK is profiled as such
+  const bool prof = syrk && A == B && prof_enabled() && bx_public_product();  // only the caller's Gram SYRK is profiled as such
   if (prof) prof_begin(0, (double)M * (double)(M + 1) * (double)K, stream);
   if (wm == 1) {
     if (alay == LAY_K && blay == LAY_K)

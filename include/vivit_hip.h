@@ -42,7 +42,7 @@ extern "C" {
 #define VIVIT_E_UNSUPPORTED (-4)
 
 /* Library/ABI version (major*1000 + minor) and the gfx target it was compiled for. */
-int vivit_hip_abi_version(void);   /* 1005 in this release; _lib.py refuses any other library */
+int vivit_hip_abi_version(void);   /* 1006 in this release; _lib.py refuses any other library */
 const char *vivit_hip_target(void);
 const char *vivit_hip_status_string(int status);
 
@@ -293,6 +293,19 @@ int vivit_sb2st_half_bandwidth(void);
 size_t vivit_sb2st_f32_workspace_bytes(int64_t n);
 int vivit_sb2st_f32(float *AB, int64_t n, float *d, float *e, float *R2, void *workspace,
                     size_t workspace_bytes, void *stream);
+
+/* Stage 3a of the two-stage path, exported for testing: the back-transformation through the bulge-chasing reflectors,
+ *   Zt <- Zt * Q2^T,   Q2 = product of all H(s, k) = I - tau2[s][k] v(s,k) v(s,k)^T in generation order,
+ * Zt: [nrows][ldz] (rows = eigenvectors of the tridiagonal matrix on entry, of the band matrix on return; any subset of
+ * rows: rows are independent), R2 / tau2 as vivit_sb2st_f32 leaves them (tau2: [n][n / NB + 1 rounded up, see
+ * vivit_sb2st_f32_workspace_bytes] in its workspace).  mode 0: one launch per wavefront step of reflector blocks
+ * (fp32 MFMA, q2apply.hip); mode 1: one persistent launch per ~2 GB of block images, a row slab per workgroup with a
+ * sliding column window, fp32 products from exact three-way bf16 splits (q2slide.hip; needs n % 4 == 0, ldz % 4 == 0,
+ * 16-byte aligned Zt: VIVIT_E_UNSUPPORTED otherwise); mode -1: what vivit_symeig_f32 would pick for this shape.
+ * Replaces the eigenvector half of Tensor.symeig(eigenvectors=True), vivit/linalg/eigh.py:248-250. */
+size_t vivit_q2_apply_f32_workspace_bytes(int64_t n);
+int vivit_q2_apply_f32(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const float *R2, int64_t ldr, const float *tau2,
+                       void *workspace, size_t workspace_bytes, int mode, void *stream);
 
 /* Eigen-decomposition of a symmetric TRIDIAGONAL matrix (d: [n] diagonal, e: [n-1]
  * off-diagonal; both destroyed).  Stage 2 of vivit_symeig_f32, exported for testing. */

@@ -115,6 +115,10 @@ BADARG_CASES = [
     ("vivit_symeig_banded_rows_f32", (P, 100, 100, Q, Q, R, R, 100, 0, 8, W, BIG, P, None)),  # n <= 2 NB
     ("vivit_sb2st_f32", (None, n, Q, R, R, W, BIG, None)),
     ("vivit_sb2st_f32", (P, 0, Q, R, R, W, BIG, None)),
+    ("vivit_q2_apply_f32", (None, n, 16, n, Q, n, R, W, BIG, 0, None)),
+    ("vivit_q2_apply_f32", (P, n - 1, 16, n, Q, n, R, W, BIG, 0, None)),                    # ldz < n
+    ("vivit_q2_apply_f32", (P, n, 16, n, Q, n, None, W, BIG, 1, None)),
+    ("vivit_q2_apply_f32", (P, n, 16, n, Q, n, R, W, BIG, 2, None)),                        # unknown mode
     ("vivit_stedc_f32", (None, Q, n, R, None, n, W, BIG, P, None)),
     ("vivit_stedc_f32", (P, Q, n, R, R, n - 1, W, BIG, P, None)),
     # K5 / K6 / K10 epilogues, packed triangles
@@ -167,6 +171,8 @@ def test_workspace_one_byte_short_is_refused():
     need = L.vivit_row_sqnorm_workspace_bytes(4, 100000)
     assert need > 0
     assert L.vivit_row_sqnorm_acc_f32(P, Q, 4, 100000, W, need - 1, None) == WORKSPACE
+    need = L.vivit_q2_apply_f32_workspace_bytes(nn)
+    assert L.vivit_q2_apply_f32(P, nn, 16, nn, Q, nn, R, W, need - 1, 0, None) == WORKSPACE
     need = L.vivit_symeig_f32_workspace_bytes(nn, 1)
     assert L.vivit_symeig_banded_rows_f32(P, nn, nn, Q, Q, R, R, nn, 0, 8, W, need - 1, P, None) == WORKSPACE
 
@@ -179,6 +185,8 @@ def test_unsupported_sizes_are_refused():
     assert L.vivit_symeig_select_f32(P, small, small, Q, 4, R, small, W, BIG, W, BIG, P, None) == UNSUPPORTED
     huge = (1 << 31) // 8 + 8   # beyond the 32-bit index range of the multi-kernel solver
     assert L.vivit_symeig_f32(P, huge, huge, Q, None, huge, W, BIG << 8, P, None) == UNSUPPORTED
+    # sliding-window Q2: n % 4 != 0
+    assert L.vivit_q2_apply_f32(P, 512, 16, 510, Q, 510, R, W, BIG, 1, None) == UNSUPPORTED
     # conv weight rule: more rows x tiles than one launch can index
     assert L.vivit_conv2d_weight_mjp_f32(P, Q, R, 1 << 40, 1 << 20, 2, 8, 8, 4, 3, 3, 6, 6, 1, 1, 0, 0, 1, 1, None) == UNSUPPORTED
 

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvivit_hip.so")
-SOURCES = ["gemm_f32.hip", "symeig_small.hip", "sytrd.hip", "sytrd_persist.hip", "sy2sb.hip", "sb2st.hip", "q2apply.hip", "stedc.hip", "stein.hip", "symeig_large.hip", "elementwise.hip", "factors.hip", "jacobians.hip", "skinny.hip", "profile.hip", "api.hip"]
+SOURCES = ["gemm_f32.hip", "symeig_small.hip", "sytrd.hip", "sytrd_persist.hip", "sy2sb.hip", "sb2st.hip", "q2apply.hip", "q2slide.hip", "stedc.hip", "stein.hip", "symeig_large.hip", "elementwise.hip", "factors.hip", "jacobians.hip", "skinny.hip", "profile.hip", "api.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -61,6 +61,8 @@ SIGNATURES = {
     "vivit_sb2st_half_bandwidth": (_int, []),
     "vivit_sb2st_f32_workspace_bytes": (_sz, [_i64]),
     "vivit_sb2st_f32": (_int, [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _sz, _ptr]),
+    "vivit_q2_apply_f32_workspace_bytes": (_sz, [_i64]),
+    "vivit_q2_apply_f32": (_int, [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _ptr, _sz, _int, _ptr]),
     "vivit_stedc_f32_workspace_bytes": (_sz, [_i64, _int]),
     "vivit_stedc_f32": (_int, [_ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),
     "vivit_dir_curvature_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr]),
@@ -76,7 +78,7 @@ SIGNATURES = {
     "vivit_unpack_lower_f32": (_int, [_ptr, _i64, _ptr, _i64, _ptr]),
 }
 
-ABI_VERSION = 1005  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
+ABI_VERSION = 1006  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
 
 _lib = None
 

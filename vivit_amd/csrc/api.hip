@@ -22,7 +22,7 @@ using namespace vivit;
 
 extern "C" {
 
-int vivit_hip_abi_version(void) { return 1005; }
+int vivit_hip_abi_version(void) { return 1006; }
 const char *vivit_hip_target(void) { return "gfx950"; }
 
 const char *vivit_hip_status_string(int status) {

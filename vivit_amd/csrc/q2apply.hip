@@ -454,15 +454,24 @@ __global__ __launch_bounds__(Q2W_THREADS) void q2_apply16_kernel(Q2Step a, const
 
 constexpr int Q2_LDS_BYTES = 4 * QW * LDS_V * 4;  // V and T V of both blocks: 135 KB
 
-size_t q2_workspace_bytes(int64_t n) {
+static size_t q2_step_workspace_bytes(int64_t n) {
   const int64_t ngroups = cdiv(n - 2 > 0 ? n - 2 : 1, QW);
   return (size_t)Q2_WIN * 2 * (ngroups + 2) * QW * QWIN * sizeof(float) + 256;
 }
 
+// either form may be selected at run time (q2slide.hip: the sliding-window form for many rows)
+size_t q2_workspace_bytes(int64_t n) {
+  const size_t a = q2_step_workspace_bytes(n), b = q2_slide_workspace_bytes(n);
+  return a > b ? a : b;
+}
+
 // Zt[nrows x n] (ldz) <- Zt * Q2^T
 int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const float *R2, int64_t ldr, const float *tau2,
-                    void *ws, hipStream_t stream) {
+                    void *ws, hipStream_t stream, int mode) {
   if (n < 3) return VIVIT_OK;
+  // mode: -1 automatic, 0 block steps (this file), 1 sliding window (q2slide.hip)
+  if (mode == 1 || (mode < 0 && q2_slide_ok(nrows, n, Zt, ldz)))
+    return q2_slide_launch(Zt, ldz, nrows, n, R2, ldr, tau2, ws, q2_workspace_bytes(n), stream);
   static unsigned long long attr_done = 0;
   {
     int dev = 0;
@@ -541,3 +550,22 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
 }
 
 } // namespace vivit
+
+using namespace vivit;
+
+extern "C" {
+
+size_t vivit_q2_apply_f32_workspace_bytes(int64_t n) { return n < 3 ? 0 : q2_workspace_bytes(n) + 512; }
+
+int vivit_q2_apply_f32(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const float *R2, int64_t ldr, const float *tau2,
+                       void *workspace, size_t workspace_bytes, int mode, void *stream) {
+  if (n < 0 || nrows < 0 || mode < -1 || mode > 1) return VIVIT_E_BADARG;
+  if (n < 3 || nrows == 0) return VIVIT_OK;
+  if (!Zt || !R2 || !tau2 || ldz < n || ldr < n) return VIVIT_E_BADARG;
+  if (!workspace || workspace_bytes < vivit_q2_apply_f32_workspace_bytes(n)) return VIVIT_E_WORKSPACE;
+  if (mode == 1 && (n < 128 || n % 4 != 0 || ldz % 4 != 0 || (reinterpret_cast<uintptr_t>(Zt) & 15) != 0)) return VIVIT_E_UNSUPPORTED;
+  void *ws = reinterpret_cast<void *>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
+  return q2_apply_launch(Zt, ldz, nrows, n, R2, ldr, tau2, ws, static_cast<hipStream_t>(stream), mode);
+}
+
+} // extern "C"

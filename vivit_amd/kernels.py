@@ -705,6 +705,22 @@ def sb2st(AB: torch.Tensor):
 
 
 @_launcher
+def q2_apply_(Zt: torch.Tensor, R2: torch.Tensor, tau2: torch.Tensor, mode: int = -1) -> torch.Tensor:
+    """``Zt <- Zt Q2^T`` in place (testing): the back-transformation through the bulge-chasing reflectors ``(R2, tau2)``
+    of :func:`sb2st`.  ``mode``: 0 block steps (fp32 MFMA), 1 sliding window on the bf16 pipe, -1 the solver's choice."""
+    _require_device(Zt, R2, tau2)
+    n = R2.shape[0]
+    assert Zt.dim() == 2 and Zt.shape[1] == n and Zt.stride(1) == 1 and R2.is_contiguous() and tau2.is_contiguous()
+    lib = _lib.load()
+    nbytes = lib.vivit_q2_apply_f32_workspace_bytes(n)
+    ws, wsb = _workspace(nbytes, Zt)
+    st = lib.vivit_q2_apply_f32(Zt.data_ptr(), Zt.stride(0), Zt.shape[0], n, R2.data_ptr(), n, tau2.data_ptr(), ws, wsb, int(mode),
+                                _stream(Zt))
+    _lib.check(st, "vivit_q2_apply_f32")
+    return Zt
+
+
+@_launcher
 def dir_curvature(GE, evals, C: int, N: int, scale: float):
     """``lambdas[n,k] = scale * sum_c GE[(c,n),k]^2 / evals[k]`` (K6 epilogue)."""
     _require_device(GE, evals)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Timing-only builds of the sliding-window Q2 kernel (csrc/q2slide.hip, -DQS_VAR=1..4: wrong results) as separate
+# libraries scripts/probe/libq2v<N>.so; select one with VIVIT_HIP_LIB.  Run on the CPU box (hipcc cross-compiles).
+set -e
+cd "$(dirname "$0")/../.."
+for v in "$@"; do
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -DQS_VAR=$v -c vivit_amd/csrc/q2slide.hip -o /tmp/q2slide_v$v.o
+  objs=$(ls vivit_amd/csrc/obj/*.o | grep -v q2slide.o)
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o scripts/probe/libq2v$v.so $objs /tmp/q2slide_v$v.o
+  echo built scripts/probe/libq2v$v.so
+done

@@ -272,5 +272,164 @@ def main():
             print(f"n={n} exact={exact} blocks={len(images)} max err {err:.3e} (|Z| ~ {np.abs(ref).max():.2f})")
 
 
+
+
+# ======================================================================================================================
+# 32-row waves on v_mfma_f32_32x32x16_bf16 (csrc/q2slide.hip:qs32_*): lane (r = l & 31, h = l >> 5) keeps
+# S[row r][8 q + 4 h .. + 3], q = 0..23; k order of a 16-deep step: k(h, j) = 16 step + 8 (j >> 2) + 4 h + (j & 3)
+def kcol32(step, h, j):
+    return 16 * step + 8 * (j >> 2) + 4 * h + (j & 3)
+
+
+def mfma32(Af, Bf, C):
+    """Af, Bf: [64][8]; C: [64][16].  A[row l&31][k = 8 (l>>5) + j], B[k][col l&31]; D[(e&3) + 8 (e>>2) + 4 (l>>5)][l&31]."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for ln in range(64):
+        for j in range(8):
+            A[ln & 31, 8 * (ln >> 5) + j] = Af[ln, j]
+            B[8 * (ln >> 5) + j, ln & 31] = Bf[ln, j]
+    D = A @ B
+    out = C.copy()
+    for ln in range(64):
+        for e in range(16):
+            out[ln, e] = np.float32(out[ln, e] + D[(e & 3) + 8 * (e >> 2) + 4 * (ln >> 5), ln & 31])
+    return out
+
+
+def mfma32_6(Ap, Bp, C):
+    for a, b in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
+        C = mfma32(Ap[a], Bp[b], C)
+    return C
+
+
+W2_LIST32 = [(ks, ta) for ks in range(8) for ta in range(2) if 16 * ks + 15 >= 32 * ta + 1]
+U_LIST32 = [(wt, kt) for wt in range(4) for kt in range(4) if 16 * kt <= 32 * wt + 30 and 16 * kt + 15 >= 32 * wt - 64]
+assert len(W2_LIST32) == 14 and len(U_LIST32) == 12, (len(W2_LIST32), len(U_LIST32))
+
+
+def prepare_block32(R2, tau2, n, g, k, exact=False):
+    Vw, taus = block_V(R2, tau2, n, g, k)
+    S = (Vw.astype(np.float64) @ Vw.astype(np.float64).T).astype(np.float32)
+    T = np.zeros((QW, QW), dtype=np.float32)
+    for j in range(QW):
+        T[j, j] = taus[j]
+        for i in range(j - 1, -1, -1):
+            T[i, j] = -taus[i] * np.float32(np.dot(S[i, i + 1:j + 1].astype(np.float64), T[i + 1:j + 1, j].astype(np.float64)))
+    TV = (np.triu(T).astype(np.float64) @ Vw.astype(np.float64)).astype(np.float32)
+    img = np.zeros((NFRAG, 64, 8), dtype=np.float32)
+    f = 0
+    for ks, ta in W2_LIST32:
+        vals = np.array([[TV[32 * ta + (ln & 31), kcol32(ks, ln >> 5, j)] for j in range(8)] for ln in range(64)], dtype=np.float32)
+        pcs = (vals, np.zeros_like(vals), np.zeros_like(vals)) if exact else split3(vals)
+        for p in range(3):
+            img[f + p] = pcs[p]
+        f += 3
+    for wt, kt in U_LIST32:
+        vals = np.array([[Vw[kcol32(kt, ln >> 5, j), 32 * wt + (ln & 31)] for j in range(8)] for ln in range(64)], dtype=np.float32)
+        pcs = (vals, np.zeros_like(vals), np.zeros_like(vals)) if exact else split3(vals)
+        for p in range(3):
+            img[f + p] = pcs[p]
+        f += 3
+    return img
+
+
+def apply_block32(sw, Q0, img, exact=False):
+    """sw: [24][64][4]; block on float4s Q0 .. Q0 + 15"""
+    sp = (lambda v: (v, np.zeros_like(v), np.zeros_like(v))) if exact else split3
+    acc2 = [np.zeros((64, 16), dtype=np.float32) for _ in range(2)]
+    f = 0
+    cur, Bp = -1, None
+    for ks, ta in W2_LIST32:
+        if ks != cur:
+            Bp = sp(np.concatenate([sw[Q0 + 2 * ks], sw[Q0 + 2 * ks + 1]], axis=1))
+            cur = ks
+        acc2[ta] = mfma32_6((img[f], img[f + 1], img[f + 2]), Bp, acc2[ta])
+        f += 3
+    Wp = [sp(acc2[kt >> 1][:, 8 * (kt & 1):8 * (kt & 1) + 8]) for kt in range(4)]
+    u, cur = None, -1
+    for idx, (wt, kt) in enumerate(U_LIST32):
+        if wt != cur:
+            u = np.zeros((64, 16), dtype=np.float32)
+            cur = wt
+        u = mfma32_6((img[f], img[f + 1], img[f + 2]), Wp[kt], u)
+        f += 3
+        if idx + 1 == len(U_LIST32) or U_LIST32[idx + 1][0] != wt:
+            for c in range(4):
+                sw[Q0 + 4 * wt + c] = (sw[Q0 + 4 * wt + c] - u[:, 4 * c:4 * c + 4]).astype(np.float32)
+    assert f == NFRAG
+
+
+def load_unit32(Zt, rows, u, n):
+    out = np.zeros((8, 64, 4), dtype=np.float32)
+    for c in range(8):
+        for ln in range(64):
+            col = 64 * u + 8 * c + 4 * (ln >> 5)
+            r = rows[ln & 31]
+            if r is not None and col < n:
+                out[c, ln] = Zt[r, col:col + 4]
+    return out
+
+
+def store_unit32(Zt, rows, u, n, regs):
+    for c in range(8):
+        for ln in range(64):
+            col = 64 * u + 8 * c + 4 * (ln >> 5)
+            r = rows[ln & 31]
+            if r is not None and col < n:
+                Zt[r, col:col + 4] = regs[c, ln]
+
+
+def walk_wave32(Zt, rows, R2, tau2, n, images, exact):
+    for K, gmax in passes(n):
+        g = gmax
+        sw = np.zeros((24, 64, 4), dtype=np.float32)
+        sw[0:8] = load_unit32(Zt, rows, g + 2 * K, n)      # units G0 + 1, G0 + 2 lie outside the matrix
+        while g >= 0:
+            up = g - 1 + 2 * K
+            nxt = load_unit32(Zt, rows, max(up, 0), n)
+            apply_block32(sw, 0, images[(g, 2 * K)], exact)
+            if g < gmax:
+                apply_block32(sw, 8, images[(g, 2 * K + 1)], exact)
+            store_unit32(Zt, rows, g + 2 * K + 2, n, sw[16:24])
+            sw[16:24] = sw[8:16]
+            sw[8:16] = sw[0:8]
+            sw[0:8] = nxt
+            g -= 1
+        store_unit32(Zt, rows, 2 * K, n, sw[8:16])
+        store_unit32(Zt, rows, 2 * K + 1, n, sw[16:24])
+
+
+def main32():
+    rng = np.random.default_rng(1)
+    for n in (132, 200, 324):
+        M = rng.standard_normal((n, n)); M = (M + M.T) / 2
+        band = np.triu(np.tril(M, NB), -NB)
+        d, e, refl, off = sb2st(band, NB, "wavefront")
+        R2 = np.zeros((n, n), dtype=np.float32)
+        tau2 = np.zeros((n, n // NB + 2), dtype=np.float32)
+        for (s, k), (c0, v, tau) in refl.items():
+            R2[s, c0:c0 + len(v)] = v
+            tau2[s, k] = tau
+        refl32 = {key: (c0, R2[key[0], c0:c0 + len(v)].astype(np.float64), float(tau2[key[0], key[1]]))
+                  for key, (c0, v, tau) in refl.items()}
+        nrows = 27
+        Z0 = rng.standard_normal((nrows, n)).astype(np.float32) / np.sqrt(n)
+        ref = reference(Z0, refl32, n)
+        for exact in (True, False):
+            images = {}
+            for K, gmax in passes(n):
+                for g in range(gmax, -1, -1):
+                    images[(g, 2 * K)] = prepare_block32(R2, tau2, n, g, 2 * K, exact)
+                    if g < gmax:
+                        images[(g, 2 * K + 1)] = prepare_block32(R2, tau2, n, g, 2 * K + 1, exact)
+            Zt = Z0.copy()
+            rows = [r if r < nrows else None for r in range(32)]
+            walk_wave32(Zt, rows, R2, tau2, n, images, exact)
+            print(f"32-row: n={n} exact={exact} max err {np.abs(Zt - ref).max():.3e}")
+
+
 if __name__ == "__main__":
-    main()
+    if "16" in sys.argv[1:] or len(sys.argv) == 1:
+        main()
+    if "32" in sys.argv[1:] or len(sys.argv) == 1:
+        main32()

@@ -23,6 +23,7 @@
 // computes, and an A operand is ONE conflict-free ds_read_b128.  Structurally zero 16 x 32 tiles of the parallelogram V
 // and of the trapezoid T V are skipped: 26 tile steps x 6 = 156 MFMAs per block and wave.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "device_utils.h"
@@ -59,6 +60,22 @@ static_assert(QS_NW2 == 14 && QS_NU == 12, "fragment lists");
 constexpr int QS_NFRAG = 3 * (QS_NW2 + QS_NU);  // 78
 constexpr int QS_IMG = QS_NFRAG * 1024;        // bytes per block image
 
+// 32-row waves (v_mfma_f32_32x32x16_bf16: t' tiles of 32, k steps of 16): the same counts, 14 + 12 steps of six MFMAs
+__host__ __device__ constexpr bool qs32_w2_need(int ks, int ta) { return 16 * ks + 15 >= 32 * ta + 1; }
+__host__ __device__ constexpr bool qs32_u_need(int wt, int kt) { return 16 * kt <= 32 * wt + 30 && 16 * kt + 15 >= 32 * wt - 64; }
+__host__ __device__ constexpr int qs32_count() {
+  int c = 0;
+  for (int ks = 0; ks < 8; ++ks)
+    for (int ta = 0; ta < 2; ++ta) c += qs32_w2_need(ks, ta) ? 1 : 0;
+  for (int wt = 0; wt < 4; ++wt)
+    for (int kt = 0; kt < 4; ++kt) c += qs32_u_need(wt, kt) ? 100 : 0;
+  return c;
+}
+static_assert(qs32_count() == 1214, "fragment lists of the 32-row form");
+// k index of element j of the lane half h in a 16-deep MFMA step of the 32-row form (both operands): the order in which
+// registers 8 s .. 8 s + 7 of a 32 x 32 accumulator hold its rows
+__host__ __device__ constexpr int qs32_kcol(int step, int h, int j) { return 16 * step + 8 * (j >> 2) + 4 * h + (j & 3); }
+
 // k index of element j of the lanes kq in MFMA step `step` (both operands)
 __host__ __device__ constexpr int qs_kcol(int step, int kq, int j) { return 32 * step + 16 * (j >> 2) + 4 * kq + (j & 3); }
 
@@ -93,12 +110,13 @@ __device__ __forceinline__ QsPieces qs_split8(const float4 x, const float4 y) {
   return p;
 }
 
-// pass K = levels 2K, 2K + 1 of the groups gmax(K) = G0 - 2K .. 0, G0 = (n - 2) / 64; level 2K + 1 exists for
-// g < gmax(K) only.  Blocks of a pass in walk order: (gmax, 2K), then (g, 2K), (g, 2K + 1) for g = gmax - 1 .. 0:
-// 2 gmax + 1 blocks.  Blocks in front of pass K counted from pass K0:
+// pass K = levels 2K, 2K + 1 of the groups gmax(K) = G0 - 2K .. 0, G0 = (n - 2) / 64.  Blocks of a pass in walk order:
+// (g, 2K), (g, 2K + 1) for g = gmax .. 0: 2 (gmax + 1) blocks.  Level 2K + 1 does not exist for g = gmax: that block is
+// kept as an IDENTITY block (no reflector: all-zero image) so that every step of the walk has the same two blocks and the
+// kernel's loop has no branch between them.  Blocks in front of pass K counted from pass K0:
 __host__ __device__ inline int64_t qs_pass_offset(int G0, int K0, int K) {
   const int64_t d = K - K0;
-  return d * (2 * (int64_t)G0 + 1) - 4 * d * K0 - 2 * d * (d - 1);
+  return d * (2 * (int64_t)G0 + 2) - 4 * d * K0 - 2 * d * (d - 1);
 }
 
 struct QsPrep {
@@ -114,6 +132,8 @@ constexpr int QS_LDV = QS_WIN + 1;  // 129: odd row stride, column walks are con
 constexpr int QS_LDT = QS_W + 1;
 constexpr int QS_PREP_LDS = (2 * QS_W * QS_LDV + 2 * QS_W * QS_LDT + QS_W) * 4;
 
+// S32: fragments for 32-row waves on v_mfma_f32_32x32x16_bf16 (qs32_apply_kernel) instead of 16-row waves
+template <bool S32>
 __global__ __launch_bounds__(256) void qs_prepare_kernel(QsPrep a) {
   extern __shared__ __attribute__((aligned(16))) float qsp_lds[];
   float *Vw = qsp_lds;                 // [64][129]  Vw[t][w] = v_t[w - 1]
@@ -124,10 +144,8 @@ __global__ __launch_bounds__(256) void qs_prepare_kernel(QsPrep a) {
   const int tid = threadIdx.x;
   const int K = a.K0 + blockIdx.y;
   const int gmax = a.G0 - 2 * K;
-  if (gmax < 0 || (int)blockIdx.x > 2 * gmax) return;
-  int g, k;
-  if (blockIdx.x == 0) { g = gmax; k = 2 * K; }
-  else { g = gmax - 1 - ((int)blockIdx.x - 1) / 2; k = 2 * K + (((int)blockIdx.x - 1) & 1); }
+  if (gmax < 0 || (int)blockIdx.x > 2 * gmax + 1) return;
+  const int g = gmax - (int)blockIdx.x / 2, k = 2 * K + ((int)blockIdx.x & 1);   // (gmax, 2K + 1): no reflector is live
   unsigned char *img = a.img + (qs_pass_offset(a.G0, a.K0, K) + blockIdx.x) * (int64_t)QS_IMG;
   const int g0 = g * QS_W;
   const int c_start = g0 + 1 + k * QS_B;
@@ -193,19 +211,35 @@ __global__ __launch_bounds__(256) void qs_prepare_kernel(QsPrep a) {
   // fragments: (fragment triple ft, lane) items; a thread writes the three 16-byte pieces of its lane
   for (int idx = tid; idx < (QS_NW2 + QS_NU) * 64; idx += 256) {
     const int ft = idx >> 6, ln = idx & 63;
-    const int m16 = ln & 15, kq = ln >> 4;
     float v[8];
-    if (ft < QS_NW2) {
-      // walk order of the W2 steps: ks outer, ta inner over the needed tiles: ks = 0: ta 0, 1; ks >= 1: ta 0..3
-      const int ks = ft < 2 ? 0 : 1 + (ft - 2) / 4, ta = ft < 2 ? ft : (ft - 2) & 3;
+    if constexpr (S32) {
+      const int r = ln & 31, hh = ln >> 5;
+      if (ft < QS_NW2) {
+        // walk order of the W2 steps: ks outer (0..7), t' tile inner: ks = 0, 1: tile 0 only; ks >= 2: tiles 0, 1
+        const int ks = ft < 2 ? ft : 2 + (ft - 2) / 2, ta = ft < 2 ? 0 : (ft - 2) & 1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = TV[(16 * ta + m16) * QS_LDV + qs_kcol(ks, kq, j)];
+        for (int j = 0; j < 8; ++j) v[j] = TV[(32 * ta + r) * QS_LDV + qs32_kcol(ks, hh, j)];
+      } else {
+        // walk order of the U steps (qs32_step): (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) | (1,2) (1,3) (2,2) (2,3) (3,2) (3,3)
+        const int fu = ft - QS_NW2;
+        const int wt = fu < 6 ? fu / 2 : 1 + (fu - 6) / 2, kt = fu < 6 ? (fu & 1) : 2 + ((fu - 6) & 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Vw[qs32_kcol(kt, hh, j) * QS_LDV + 32 * wt + r];
+      }
     } else {
-      // walk order of the U steps: wt outer, kt inner: (0,0) (1,0) (2,0) (2,1) ... (5,0) (5,1) (6,1) (7,1)
-      const int fu = ft - QS_NW2;
-      const int wt = fu < 2 ? fu : (fu < 10 ? 2 + (fu - 2) / 2 : fu - 4), kt = fu < 2 ? 0 : (fu < 10 ? (fu - 2) & 1 : 1);
+      const int m16 = ln & 15, kq = ln >> 4;
+      if (ft < QS_NW2) {
+        // walk order of the W2 steps: ks outer, ta inner over the needed tiles: ks = 0: ta 0, 1; ks >= 1: ta 0..3
+        const int ks = ft < 2 ? 0 : 1 + (ft - 2) / 4, ta = ft < 2 ? ft : (ft - 2) & 3;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = Vw[qs_kcol(kt, kq, j) * QS_LDV + 16 * wt + m16];
+        for (int j = 0; j < 8; ++j) v[j] = TV[(16 * ta + m16) * QS_LDV + qs_kcol(ks, kq, j)];
+      } else {
+        // walk order of the U steps: wt outer, kt inner: (0,0) (1,0) (2,0) (2,1) ... (5,0) (5,1) (6,1) (7,1)
+        const int fu = ft - QS_NW2;
+        const int wt = fu < 2 ? fu : (fu < 10 ? 2 + (fu - 2) / 2 : fu - 4), kt = fu < 2 ? 0 : (fu < 10 ? (fu - 2) & 1 : 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = Vw[qs_kcol(kt, kq, j) * QS_LDV + 16 * wt + m16];
+      }
     }
     qu32x4 h, m, l;
 #pragma unroll
@@ -242,51 +276,103 @@ struct QsArgs {
 typedef const __attribute__((address_space(3))) unsigned char *qs_lds_ptr;
 typedef const __attribute__((address_space(3))) qbf16x8 *qs_lds_frag;
 
-template <int Q0>
-__device__ __forceinline__ void qs_apply_block(float4 (&sw)[12], qs_lds_ptr frag) {
+// QS_VAR (timing-only builds, wrong results; scripts/probe/q2_variants.sh): 1 no arithmetic (DMA, barriers and Zt traffic
+// only), 2 no image DMA, 3 no DMA and no barriers, 4 no Zt loads / stores
+#ifndef QS_VAR
+#define QS_VAR 0
+#endif
+
+// the 26 tile steps of a block in walk order: steps 0..13 form W2^T (ks outer, t'-tile inner), 14..25 form U^T (w-tile
+// outer, kt inner).  Compile-time tables (every index below is a constant after unrolling).
+struct QsStep {
+  int ks, ta;   // W2 step: k step of the window, t' tile
+  int wt, kt;   // U step: w tile, k step over t'
+};
+__host__ __device__ constexpr QsStep qs_step(int i) {
+  int c = 0;
+  for (int ks = 0; ks < 4; ++ks)
+    for (int ta = 0; ta < 4; ++ta)
+      if (qs_w2_need(ks, ta)) {
+        if (c == i) return QsStep{ks, ta, -1, -1};
+        ++c;
+      }
+  for (int wt = 0; wt < 8; ++wt)
+    for (int kt = 0; kt < 2; ++kt)
+      if (qs_u_need(wt, kt)) {
+        if (c == i) return QsStep{-1, -1, wt, kt};
+        ++c;
+      }
+  return QsStep{-1, -1, -1, -1};
+}
+constexpr int QS_NSTEP = QS_NW2 + QS_NU;  // 26
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void qs_static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    qs_static_for<N, I + 1>(f);
+  }
+}
+
+struct QsFrag {
+  qbf16x8 h, m, l;
+};
+__device__ __forceinline__ QsFrag qs_frag(qs_lds_ptr frag, int i) {
+  QsFrag f;
+  f.h = *reinterpret_cast<qs_lds_frag>(frag + (3 * i + 0) * 1024);
+  f.m = *reinterpret_cast<qs_lds_frag>(frag + (3 * i + 1) * 1024);
+  f.l = *reinterpret_cast<qs_lds_frag>(frag + (3 * i + 2) * 1024);
+  return f;
+}
+
+// One block on the float4s Q0 .. Q0 + 7 of the window; frag: this lane's 16 bytes of fragment 0 of the block's image.
+// The A fragments of step i + 1 are read from LDS before the six MFMAs of step i are issued (a wave then waits for an LDS
+// read only when the matrix pipe is already ahead of it); `mid(i)` is called once per step between the reads and the MFMAs
+// (the caller spreads its image DMA requests over the block with it).
+template <int Q0, class Mid>
+__device__ __forceinline__ void qs_apply_block(float4 (&sw)[12], qs_lds_ptr frag, Mid mid) {
+#if QS_VAR == 1
+  __asm__ volatile("" : "+v"(sw[Q0].x), "+v"(sw[Q0 + 7].w));
+  qs_static_for<QS_NSTEP>([&](auto itag) __attribute__((always_inline)) { mid(decltype(itag)::value); });
+  return;
+#endif
   f32x4 acc2[4];
 #pragma unroll
   for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc2[ta][e] = 0.f;
-  int f = 0;
+  QsPieces bp, wp[2];
+  f32x4 u;
+  QsFrag cur = qs_frag(frag, 0);
+  qs_static_for<QS_NSTEP>([&](auto itag) __attribute__((always_inline)) {
+    constexpr int i = decltype(itag)::value;
+    constexpr QsStep st = qs_step(i), prev = qs_step(i > 0 ? i - 1 : 0), next = qs_step(i + 1 < QS_NSTEP ? i + 1 : i);
+    QsFrag nxt = cur;
+    if constexpr (i + 1 < QS_NSTEP) nxt = qs_frag(frag, i + 1);
+    mid(i);
+    if constexpr (st.ks >= 0) {
+      if constexpr (i == 0 || st.ks != prev.ks) bp = qs_split8(sw[Q0 + 2 * st.ks], sw[Q0 + 2 * st.ks + 1]);
+      QS_MFMA6(acc2[st.ta], cur.h, cur.m, cur.l, bp)
+    } else {
+      if constexpr (i == QS_NW2) {
+        wp[0] = qs_split8(make_float4(acc2[0][0], acc2[0][1], acc2[0][2], acc2[0][3]),
+                          make_float4(acc2[1][0], acc2[1][1], acc2[1][2], acc2[1][3]));
+        wp[1] = qs_split8(make_float4(acc2[2][0], acc2[2][1], acc2[2][2], acc2[2][3]),
+                          make_float4(acc2[3][0], acc2[3][1], acc2[3][2], acc2[3][3]));
+      }
+      if constexpr (prev.wt != st.wt) {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const QsPieces bp = qs_split8(sw[Q0 + 2 * ks], sw[Q0 + 2 * ks + 1]);
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta) {
-      if (qs_w2_need(ks, ta)) {
-        const qbf16x8 ah = *reinterpret_cast<qs_lds_frag>(frag + (f + 0) * 1024);
-        const qbf16x8 am = *reinterpret_cast<qs_lds_frag>(frag + (f + 1) * 1024);
-        const qbf16x8 al = *reinterpret_cast<qs_lds_frag>(frag + (f + 2) * 1024);
-        QS_MFMA6(acc2[ta], ah, am, al, bp)
-        f += 3;
+        for (int e = 0; e < 4; ++e) u[e] = 0.f;
+      }
+      QS_MFMA6(u, cur.h, cur.m, cur.l, wp[st.kt])
+      if constexpr (i + 1 == QS_NSTEP || next.wt != st.wt) {
+        float4 &x = sw[Q0 + st.wt];
+        x.x -= u[0]; x.y -= u[1]; x.z -= u[2]; x.w -= u[3];
       }
     }
-  }
-  QsPieces wp[2];
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-    wp[kt] = qs_split8(make_float4(acc2[2 * kt][0], acc2[2 * kt][1], acc2[2 * kt][2], acc2[2 * kt][3]),
-                       make_float4(acc2[2 * kt + 1][0], acc2[2 * kt + 1][1], acc2[2 * kt + 1][2], acc2[2 * kt + 1][3]));
-#pragma unroll
-  for (int wt = 0; wt < 8; ++wt) {
-    f32x4 u;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) u[e] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      if (qs_u_need(wt, kt)) {
-        const qbf16x8 ah = *reinterpret_cast<qs_lds_frag>(frag + (f + 0) * 1024);
-        const qbf16x8 am = *reinterpret_cast<qs_lds_frag>(frag + (f + 1) * 1024);
-        const qbf16x8 al = *reinterpret_cast<qs_lds_frag>(frag + (f + 2) * 1024);
-        QS_MFMA6(u, ah, am, al, wp[kt])
-        f += 3;
-      }
-    }
-    float4 &x = sw[Q0 + wt];
-    x.x -= u[0]; x.y -= u[1]; x.z -= u[2]; x.w -= u[3];
-  }
+    cur = nxt;
+  });
 }
 
 // MAXW: most waves per workgroup of the instantiation (register budget 512 / ceil(MAXW / 4) per lane)
@@ -305,14 +391,31 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
   qs_lds_ptr myfrag = (qs_lds_ptr)qs_lds + lane * 16;
 
   const int64_t nseq = qs_pass_offset(a.G0, a.K0, a.K1);
-  // image `seq` -> LDS buffer seq & 1: this wave's share of the 78 one-KB pieces (lane i's 16 bytes land at M0 + 16 i)
-  auto dma = [&](int64_t seq) __attribute__((always_inline)) {
-    const unsigned char *src = a.img + seq * (int64_t)QS_IMG + lane * 16;
-    const unsigned dst = lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG;
-    for (int f = wave; f < QS_NFRAG; f += nw) {
-      const unsigned d = __builtin_amdgcn_readfirstlane(dst + (unsigned)f * 1024u);
-      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(d), "v"(src + (int64_t)f * 1024) : "memory");
+  // image `seq` -> LDS buffer seq & 1: this wave's share of the 78 one-KB pieces is wave, wave + nw, ... (lane i's 16
+  // bytes land at M0 + 16 i); piece j of the share is requested at tile step QS_DMA_AT(j) of the block that computes
+  // while the image lands, so that the requests do not all queue up behind the barrier
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto dma_piece = [&](int64_t seq, int j) __attribute__((always_inline)) {
+    const int f = wave + nw * j;
+    if (f < QS_NFRAG) {
+      // scalar base + 32-bit lane offset: no per-piece address registers (eight 64-bit addresses kept across the block
+      // were spilled by the 168-register instantiation)
+      const unsigned char *src = a.img + seq * (int64_t)QS_IMG + (int64_t)f * 1024;
+      const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG + (unsigned)f * 1024u);
+      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");
     }
+  };
+  const int npiece = (QS_NFRAG + nw - 1) / nw;   // pieces per wave (the last one only for some waves)
+  auto dma = [&](int64_t seq) __attribute__((always_inline)) {
+    for (int j = 0; j < npiece; ++j) dma_piece(seq, j);
+  };
+  // pieces requested at tile step i of the block that computes while the image lands: piece i / 2 at the even steps
+  // (13 slots; no loop and no branch but the piece's own bound check inside the unrolled step code), whatever is left
+  // (fewer than six waves) at step 0
+  auto dma_step = [&](int64_t seq, int i) __attribute__((always_inline)) {
+    if (i == 0)
+      for (int j = QS_NSTEP / 2; j < npiece; ++j) dma_piece(seq, j);
+    if ((i & 1) == 0) dma_piece(seq, i / 2);
   };
   // unit u entirely inside the matrix (64 u + 63 < n): unguarded loads (rows beyond nrows read row 0, never stored)
   auto load_unit = [&](int u, float4 (&dst)[4]) __attribute__((always_inline)) {
@@ -371,35 +474,49 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
       // ---- block (g, 2K): its image has landed once every wave is past this wait and the barrier
       if (steady) __asm__ volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if QS_VAR != 3
       __builtin_amdgcn_s_barrier();
-      if (seq + 1 < nseq) dma(seq + 1);
+#endif
+      const int64_t seq_a = seq + 1 < nseq ? seq + 1 : 0;   // (the very last block re-requests image 0: never read)
       // next group's left unit (g - 1 + 2K < G0: inside the matrix), in flight during the block.  Unconditional (the last
       // group of a pass fetches a unit it does not use): a branch around the loads makes hipcc wait for them at the join
       float4 pre[4];
       {
         const int up = g - 1 + 2 * K;
+#if QS_VAR == 4
+        for (int q = 0; q < 4; ++q) pre[q] = sw[q];
+#else
         load_unit(up > 0 ? up : 0, pre);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);   // (the loads stay up here)
-      qs_apply_block<0>(sw, myfrag + (seq & 1) * QS_IMG);
+      qs_apply_block<0>(sw, myfrag + (seq & 1) * QS_IMG, [&](int i) __attribute__((always_inline)) {
+#if QS_VAR != 2 && QS_VAR != 3
+        dma_step(seq_a, i);
+#endif
+      });
       ++seq;
-      if (g < gmax) {
-        // ---- block (g, 2K + 1)
+      {
+        // ---- block (g, 2K + 1) (g = gmax: the identity block)
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if QS_VAR != 3
         __builtin_amdgcn_s_barrier();
+#endif
         __asm__ volatile("" : QS_USE4(pre[0]), QS_USE4(pre[1]), QS_USE4(pre[2]), QS_USE4(pre[3]));
-        if (seq + 1 < nseq) dma(seq + 1);
-        qs_apply_block<4>(sw, myfrag + (seq & 1) * QS_IMG);
+        const int64_t seq_b = seq + 1 < nseq ? seq + 1 : 0;
+        qs_apply_block<4>(sw, myfrag + (seq & 1) * QS_IMG, [&](int i) __attribute__((always_inline)) {
+#if QS_VAR != 2 && QS_VAR != 3
+          dma_step(seq_b, i);
+#endif
+        });
         ++seq;
-      } else {
-        // first group of a pass (no second block): settle `pre` here, so that hipcc has nothing pending where the paths join
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __asm__ volatile("" : QS_USE4(pre[0]), QS_USE4(pre[1]), QS_USE4(pre[2]), QS_USE4(pre[3]));
       }
       // the right unit is final: store it, slide the window
       const int ur = g + 2 * K + 2;
+#if QS_VAR != 4
       store_unit(ur, &sw[8]);
-      steady = wave_valid && g < gmax && 64 * ur + 63 < n;
+#endif
+      steady = wave_valid && 64 * ur + 63 < n;
 #pragma unroll
       for (int q = 0; q < 4; ++q) { sw[8 + q] = sw[4 + q]; sw[4 + q] = sw[q]; sw[q] = pre[q]; }
     }
@@ -408,6 +525,226 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
     store_unit(2 * K + 1, &sw[8]);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // the next pass reads what this one stored
   }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last image request
+#undef QS_USE4
+}
+
+
+// ====================================================================================================================
+// 32-row waves on v_mfma_f32_32x32x16_bf16.  The 16-row form above is bound by the SIMD's instruction ISSUE, not by its
+// matrix pipe: a 16x16x32 MFMA holds the vector issue port for 8 of its 16 cycles, which leaves two issue slots per MFMA
+// for the ~1.7 split instructions, the LDS reads and the pads that go with it (measured: the three waves of a SIMD need
+// MFMA time + VALU time, 5.0 us per block against 3.45 us of MFMAs).  A 32x32x16 MFMA holds the port for 8 of 32 cycles
+// and does twice the work: six free slots per MFMA for the same split work per row.  Lane (r = lane & 31, h = lane >> 5)
+// keeps S[row r][8 q + 4 h .. + 3], q = 0..23 (three units of eight float4); k order of a 16-deep step as qs32_kcol.
+#define QS32_MFMA6(acc, ah, am, al, bp)                                                 \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, (bp).h, acc, 0, 0, 0);              \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, (bp).l, acc, 0, 0, 0);              \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, (bp).m, acc, 0, 0, 0);              \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, (bp).h, acc, 0, 0, 0);              \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, (bp).m, acc, 0, 0, 0);              \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, (bp).h, acc, 0, 0, 0);
+
+// U steps in two halves over t': (w tile 0..2) x (kt 0, 1), then (w tile 1..3) x (kt 2, 3) -- each half needs the pieces of
+// ONE accumulator tile of W2^T only (24 registers instead of 48), at the price of two more subtractions from the window
+__host__ __device__ constexpr QsStep qs32_step(int i) {
+  int c = 0;
+  for (int ks = 0; ks < 8; ++ks)
+    for (int ta = 0; ta < 2; ++ta)
+      if (qs32_w2_need(ks, ta)) {
+        if (c == i) return QsStep{ks, ta, -1, -1};
+        ++c;
+      }
+  for (int half = 0; half < 2; ++half)
+    for (int wt = 0; wt < 4; ++wt)
+      for (int kt = 2 * half; kt < 2 * half + 2; ++kt)
+        if (qs32_u_need(wt, kt)) {
+          if (c == i) return QsStep{-1, -1, wt, kt};
+          ++c;
+        }
+  return QsStep{-1, -1, -1, -1};
+}
+
+// one block on the float4s Q0 .. Q0 + 15 of the window (two units); see qs_apply_block
+template <int Q0, class Mid>
+__device__ __forceinline__ void qs32_apply_block(float4 (&sw)[24], qs_lds_ptr frag, Mid mid) {
+#if QS_VAR == 1
+  __asm__ volatile("" : "+v"(sw[Q0].x), "+v"(sw[Q0 + 15].w));
+  qs_static_for<QS_NSTEP>([&](auto itag) __attribute__((always_inline)) { mid(decltype(itag)::value); });
+  return;
+#endif
+  f32x16 acc2[2];
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[ta][e] = 0.f;
+  QsPieces bp, wp[2];
+  f32x16 u;
+  QsFrag cur = qs_frag(frag, 0);
+  qs_static_for<QS_NSTEP>([&](auto itag) __attribute__((always_inline)) {
+    constexpr int i = decltype(itag)::value;
+    constexpr QsStep st = qs32_step(i), prev = qs32_step(i > 0 ? i - 1 : 0), next = qs32_step(i + 1 < QS_NSTEP ? i + 1 : i);
+    QsFrag nxt = cur;
+    if constexpr (i + 1 < QS_NSTEP) nxt = qs_frag(frag, i + 1);
+    mid(i);
+    if constexpr (st.ks >= 0) {
+      if constexpr (i == 0 || st.ks != prev.ks) bp = qs_split8(sw[Q0 + 2 * st.ks], sw[Q0 + 2 * st.ks + 1]);
+      QS32_MFMA6(acc2[st.ta], cur.h, cur.m, cur.l, bp)
+    } else {
+      if constexpr (i == QS_NW2 || (prev.wt >= 0 && (prev.kt >> 1) != (st.kt >> 1))) {
+        // registers 8 s .. 8 s + 7 of accumulator tile kt >> 1 are the B operand of t' step kt (s = kt & 1)
+        const f32x16 &x = acc2[st.kt >> 1];
+        wp[0] = qs_split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
+        wp[1] = qs_split8(make_float4(x[8], x[9], x[10], x[11]), make_float4(x[12], x[13], x[14], x[15]));
+      }
+      if constexpr (i == QS_NW2 || prev.wt != st.wt || (prev.kt >> 1) != (st.kt >> 1)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u[e] = 0.f;
+      }
+      QS32_MFMA6(u, cur.h, cur.m, cur.l, wp[st.kt & 1])
+      if constexpr (i + 1 == QS_NSTEP || next.wt != st.wt || (next.kt >> 1) != (st.kt >> 1)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float4 &x = sw[Q0 + 4 * st.wt + c];
+          x.x -= u[4 * c]; x.y -= u[4 * c + 1]; x.z -= u[4 * c + 2]; x.w -= u[4 * c + 3];
+        }
+      }
+    }
+    cur = nxt;
+    // the scheduler may not move anything across a step boundary: it would hoist the fragment reads of several steps
+    // and the next split to the front (the window, the prefetched unit and the pieces already take ~220 registers)
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// MAXW = 8: up to eight waves of 32 rows per workgroup (two per SIMD, 256 registers each: the window, the prefetched unit
+// and the pieces do not fit, hipcc spills); MAXW = 4: one wave per SIMD, up to 512 registers
+template <int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void qs32_apply_kernel(QsArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char qs_lds[];  // two images
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = (int)(blockDim.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t row = (int64_t)blockIdx.x * (32 * nw) + wave * 32 + r;
+  const bool rok = row < a.nrows;
+  float *zrow = a.Zt + (rok ? row : 0) * a.ldz + 4 * h;   // + 64 unit + 8 c
+  const int n = a.n;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)qs_lds);
+  qs_lds_ptr myfrag = (qs_lds_ptr)qs_lds + lane * 16;
+  const int64_t nseq = qs_pass_offset(a.G0, a.K0, a.K1);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto dma_piece = [&](int64_t seq, int j) __attribute__((always_inline)) {
+    const int f = wave + nw * j;
+    if (f < QS_NFRAG) {
+      const unsigned char *src = a.img + seq * (int64_t)QS_IMG + (int64_t)f * 1024;
+      const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG + (unsigned)f * 1024u);
+      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");
+    }
+  };
+  const int npiece = (QS_NFRAG + nw - 1) / nw;
+  // pieces requested at tile step i of the block that computes while the image lands: piece i / 2 at the even steps
+  // (13 slots; no loop and no branch but the piece's own bound check inside the unrolled step code), whatever is left
+  // (fewer than six waves) at step 0
+  auto dma_step = [&](int64_t seq, int i) __attribute__((always_inline)) {
+    if (i == 0)
+      for (int j = QS_NSTEP / 2; j < npiece; ++j) dma_piece(seq, j);
+    if ((i & 1) == 0) dma_piece(seq, i / 2);
+  };
+  auto load_unit = [&](int u, float4 (&dst)[8]) __attribute__((always_inline)) {
+    const float4 *src = reinterpret_cast<const float4 *>(zrow + (int64_t)64 * u);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dst[c] = src[2 * c];
+  };
+  auto load_unit_edge = [&](int u, float4 (&dst)[8]) __attribute__((always_inline)) {
+    const int c0 = 64 * u + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const bool ok = c0 + 8 * c < n;
+      dst[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) dst[c] = *reinterpret_cast<const float4 *>(zrow + (int64_t)64 * u + 8 * c);
+    }
+  };
+  auto store_unit = [&](int u, const float4 *src) __attribute__((always_inline)) {
+    const int c0 = 64 * u + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (rok && c0 + 8 * c < n) *reinterpret_cast<float4 *>(zrow + (int64_t)64 * u + 8 * c) = src[c];
+  };
+#define QS_USE4(a) "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)
+  const bool wave_valid = (int64_t)blockIdx.x * (32 * nw) + wave * 32 < a.nrows;
+  int64_t seq = 0;
+  if (nseq > 0)
+    for (int j = 0; j < npiece; ++j) dma_piece(0, j);
+  float4 sw[24];
+  for (int K = a.K0; K < a.K1; ++K) {
+    const int gmax = a.G0 - 2 * K;
+    {
+      float4 t0[8];
+      load_unit_edge(gmax + 2 * K, t0);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        sw[c] = t0[c];
+        sw[8 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sw[16 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible
+      __asm__ volatile("" : QS_USE4(sw[0]), QS_USE4(sw[1]), QS_USE4(sw[2]), QS_USE4(sw[3]));
+      __asm__ volatile("" : QS_USE4(sw[4]), QS_USE4(sw[5]), QS_USE4(sw[6]), QS_USE4(sw[7]));
+    }
+    bool steady = false;   // the previous step issued exactly eight stores behind the image requests
+    for (int g = gmax; g >= 0; --g) {
+      if (steady) __asm__ volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if QS_VAR != 3
+      __builtin_amdgcn_s_barrier();
+#endif
+      const int64_t seq_a = seq + 1 < nseq ? seq + 1 : 0;   // (the very last block re-requests image 0: never read)
+      float4 pre[8];
+      {
+        const int up = g - 1 + 2 * K;
+#if QS_VAR == 4
+        for (int c = 0; c < 8; ++c) pre[c] = sw[c];
+#else
+        load_unit(up > 0 ? up : 0, pre);
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (the loads stay up here)
+      qs32_apply_block<0>(sw, myfrag + (seq & 1) * QS_IMG, [&](int i) __attribute__((always_inline)) {
+#if QS_VAR != 2 && QS_VAR != 3
+        dma_step(seq_a, i);
+#endif
+      });
+      ++seq;
+      {
+        // ---- block (g, 2K + 1) (g = gmax: the identity block)
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if QS_VAR != 3
+        __builtin_amdgcn_s_barrier();
+#endif
+        __asm__ volatile("" : QS_USE4(pre[0]), QS_USE4(pre[1]), QS_USE4(pre[2]), QS_USE4(pre[3]));
+        __asm__ volatile("" : QS_USE4(pre[4]), QS_USE4(pre[5]), QS_USE4(pre[6]), QS_USE4(pre[7]));
+        const int64_t seq_b = seq + 1 < nseq ? seq + 1 : 0;
+        qs32_apply_block<8>(sw, myfrag + (seq & 1) * QS_IMG, [&](int i) __attribute__((always_inline)) {
+#if QS_VAR != 2 && QS_VAR != 3
+          dma_step(seq_b, i);
+#endif
+        });
+        ++seq;
+      }
+      const int ur = g + 2 * K + 2;
+#if QS_VAR != 4
+      store_unit(ur, &sw[16]);
+#endif
+      steady = wave_valid && 64 * ur + 63 < n;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { sw[16 + c] = sw[8 + c]; sw[8 + c] = sw[c]; sw[c] = pre[c]; }
+    }
+    store_unit(2 * K, &sw[8]);
+    store_unit(2 * K + 1, &sw[16]);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // the next pass reads what this one stored
+  }
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last image request
 #undef QS_USE4
 }
 
@@ -425,8 +762,8 @@ constexpr size_t QS_WS_TARGET = (size_t)2 << 30;   // images of ~2 GB per chunk 
 size_t q2_slide_workspace_bytes(int64_t n) {
   if (n < 3) return 0;
   const int G0 = (int)((n - 2) / 64);
-  // all images, at most ~2 GB of them at a time, at least the first pass (the longest): 2 G0 + 1 blocks
-  const size_t all = (size_t)qs_pass_offset(G0, 0, G0 / 2 + 1) * QS_IMG, one = (size_t)(2 * G0 + 1) * QS_IMG;
+  // all images, at most ~2 GB of them at a time, at least the first pass (the longest): 2 G0 + 2 blocks
+  const size_t all = (size_t)qs_pass_offset(G0, 0, G0 / 2 + 1) * QS_IMG, one = (size_t)(2 * G0 + 2) * QS_IMG;
   const size_t cap = all < QS_WS_TARGET ? all : QS_WS_TARGET;
   return (one > cap ? one : cap) + 2048;
 }
@@ -441,7 +778,7 @@ bool q2_slide_ok(int64_t nrows, int64_t n, const float *Zt, int64_t ldz) {
   static int on = -1, min_rows = 0;
   if (on < 0) {
     on = qs_env("VIVIT_Q2_SLIDE", 1);
-    min_rows = qs_env("VIVIT_Q2_SLIDE_MIN_ROWS", 12288);
+    min_rows = qs_env("VIVIT_Q2_SLIDE_MIN_ROWS", 24576);
   }
   const bool vec = ((reinterpret_cast<uintptr_t>(Zt) & 15) == 0) && (ldz % 4 == 0) && (n % 4 == 0);
   return on != 0 && vec && n >= 192 && nrows >= min_rows && device_cu_count() > 0;
@@ -458,7 +795,10 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     if (!(attr_done & (1ull << (dev & 63)))) {
       if (!ensure_dynamic_lds(reinterpret_cast<const void *>(qs_apply_kernel<8>), QS_APPLY_LDS, attr_done) ||
           !ensure_dynamic_lds(reinterpret_cast<const void *>(qs_apply_kernel<12>), QS_APPLY_LDS, attr_done) ||
-          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs_prepare_kernel), QS_PREP_LDS, attr_done))
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs32_apply_kernel<4>), QS_APPLY_LDS, attr_done) ||
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs32_apply_kernel<8>), QS_APPLY_LDS, attr_done) ||
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs_prepare_kernel<false>), QS_PREP_LDS, attr_done) ||
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs_prepare_kernel<true>), QS_PREP_LDS, attr_done))
         return VIVIT_E_LAUNCH;
       attr_done |= 1ull << (dev & 63);
     }
@@ -467,15 +807,22 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
   const size_t img_bytes = ws_bytes - (size_t)(img - reinterpret_cast<unsigned char *>(ws));
   const int G0 = (int)((n - 2) / 64);
   const int Kend = G0 / 2 + 1;   // passes K with gmax(K) = G0 - 2K >= 0
-  // waves per workgroup: one slab per CU when the rows allow it (16 rows per wave), at most 12 waves (168 registers)
+  // wave shape: 32 rows per wave on the 32x32x16 MFMA (default), or 16 rows on the 16x16x32 MFMA (VIVIT_Q2_SLIDE_SHAPE=16)
+  static int shape = 0, force_nw = -2;
+  if (shape == 0) {
+    shape = qs_env("VIVIT_Q2_SLIDE_SHAPE", 16) == 32 ? 32 : 16;
+    force_nw = qs_env("VIVIT_Q2_SLIDE_WAVES", -1);
+  }
   const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
-  int nw = (int)cdiv(cdiv(nrows, cus), 16);
-  static int force_nw = -2;
-  if (force_nw == -2) force_nw = qs_env("VIVIT_Q2_SLIDE_WAVES", -1);
+  // waves per workgroup: 32-row form: eight (256-row slabs, two waves per SIMD), fewer when the rows do not fill the CUs;
+  // 16-row form: one slab per CU when the rows allow it, at most 12 waves (168 registers)
+  const int wmax = shape == 32 ? 8 : 12;
+  int nw = (int)cdiv(cdiv(nrows, cus), shape);
+  if (shape == 32 && nw < 8 && nrows >= (int64_t)cus * 128) nw = 8;
   if (force_nw > 0) nw = force_nw;
   if (nw < 1) nw = 1;
-  if (nw > 12) nw = 12;
-  const unsigned nslab = (unsigned)cdiv(nrows, 16 * nw);
+  if (nw > wmax) nw = wmax;
+  const unsigned nslab = (unsigned)cdiv(nrows, shape * nw);
   QsPrep pa;
   pa.R2 = R2; pa.ldr = ldr; pa.tau2 = tau2; pa.nk = sb2st_num_levels(n); pa.n = (int)n; pa.G0 = G0; pa.img = img;
   QsArgs aa;
@@ -484,9 +831,13 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     const int K1 = qs_chunk_passes(G0, K0, Kend, img_bytes);
     if (K1 == K0) return VIVIT_E_WORKSPACE;
     pa.K0 = K0;
-    qs_prepare_kernel<<<dim3((unsigned)(2 * (G0 - 2 * K0) + 1), (unsigned)(K1 - K0)), 256, QS_PREP_LDS, stream>>>(pa);
+    const dim3 pgrid((unsigned)(2 * (G0 - 2 * K0) + 2), (unsigned)(K1 - K0));
+    if (shape == 32) qs_prepare_kernel<true><<<pgrid, 256, QS_PREP_LDS, stream>>>(pa);
+    else qs_prepare_kernel<false><<<pgrid, 256, QS_PREP_LDS, stream>>>(pa);
     aa.K0 = K0; aa.K1 = K1;
-    if (nw <= 8) qs_apply_kernel<8><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
+    if (shape == 32 && nw <= 4) qs32_apply_kernel<4><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
+    else if (shape == 32) qs32_apply_kernel<8><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
+    else if (nw <= 8) qs_apply_kernel<8><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
     else qs_apply_kernel<12><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
     K0 = K1;
   }

@@ -398,14 +398,22 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
     """Per-stage roofline of the eigensolver from the library's stage marks (ms summed over the timed steps).
     Algorithmic work per stage: band reduction (4/3) n^3 flop on MFMA; bulge chasing: n^2/(2 nb)
     tasks that each read and write two nb x nb blocks; the two back-transformations 2 n^3 flop each on MFMA."""
-    names = {1: "prepare (scale scan + mirror)", 2: "sy2sb (full -> band)", 3: "sb2st (band -> tridiagonal, bulge chasing)",
+    names = {1: "prepare (scale scan + mirror)", 2: "sy2sb (full -> band): panel QR + panel-local products",
+             9: "sy2sb: streaming panel products P^T = V^T A22 (fp32 MFMA)",
+             10: "sy2sb: delayed rank-1024 trailing updates (bf16 pipe)",
+             3: "sb2st (band -> tridiagonal, bulge chasing)",
              4: "tridiagonal eigenproblem (divide & conquer | multisection)", 5: "Q2 back-transformation",
              6: "Q1 back-transformation", 7: "sort + transpose into the output", 8: "sytrd (one-stage tridiagonalisation)"}
+    # (csrc/q2slide.hip:q2_slide_ok: the sliding-window kernel takes over when this many eigenvector rows are transformed)
+    q2_bf16 = (bool(split) and n * row_frac >= int(os.environ.get("VIVIT_Q2_SLIDE_MIN_ROWS", "14336"))
+               and os.environ.get("VIVIT_Q2_SLIDE", "1") != "0" and n % 4 == 0)
     nb = 64
     n3 = float(n) ** 3
     work = {
         1: ("hbm", 4.0 * n * n * 1.5, "B"),
-        2: ("mfma", 4.0 / 3.0 * n3, "flop"),
+        2: (None, None, None),   # launch chains and 64-wide products: seconds only
+        9: ("mfma", 2.0 / 3.0 * n3, "flop"),
+        10: ("mfma", 2.0 / 3.0 * n3, "flop"),
         3: ("hbm", (n * n / (2.0 * nb)) * 4 * nb * nb * 4.0, "B"),
         4: (None, None, None),  # spectrum dependent (deflation): seconds only
         5: ("mfma", 2.0 * n3 * row_frac, "flop"),   # back-transformations: only this rank's eigenvector rows
@@ -414,17 +422,23 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
         8: ("hbm", 2.0 / 3.0 * n3, "B"),
     }
     out = []
-    for k in sorted(names):
+    for k in (1, 2, 9, 10, 3, 4, 5, 6, 7, 8):
         sec = stage_ms[k] / 1e3 / max(steps, 1)
         if sec <= 0:
             continue
         bound, amount, unit = work[k]
         row = {"stage": names[k], "seconds": sec, "bound": bound}
+        if bound is None:
+            out.append(row)
+            continue
         if bound == "mfma":
             ach = amount / sec / 1e12
-            # Q1's three products per super-block run on the bf16 pipe when the operand split is on (its roofline is then
-            # the bf16 peak / split); band reduction and Q2 are fp32 MFMA kernels
-            peak = MFMA_BF16_PEAK_TF / split if (k == 6 and split) else MFMA_F32_PEAK_TF
+            # each stage against the pipe it runs on: Q1's products, the band reduction's trailing updates and the
+            # sliding-window Q2 kernel form fp32 products from exact bf16 splits (roofline = bf16 peak / split); the band
+            # reduction's streaming panel product and the block-step Q2 kernels are fp32 MFMA kernels
+            on_bf16 = split and (k in (6, 10) or (k == 5 and q2_bf16))
+            peak = MFMA_BF16_PEAK_TF / split if on_bf16 else MFMA_F32_PEAK_TF
+            row["pipe"] = f"bf16 MFMA, {split} partial products per fp32 product" if on_bf16 else "fp32 MFMA"
             row.update({"flops": amount, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak})
         elif bound == "hbm":
             ach = amount / sec / 1e9

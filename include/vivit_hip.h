@@ -348,7 +348,9 @@ int vivit_profile_end(double *out);
  * boundaries, on the launch stream), summed over calls, in ms.  out_ms[k], k < num (host pointer):
  *   1 prescale + mirror, 2 full -> band (sy2sb), 3 band -> tridiagonal (sb2st), 4 tridiagonal eigenproblem
  *   (divide & conquer | Sturm multisection | inverse iteration), 5 back-transformation Q2, 6 back-transformation
- *   Q1 / Q, 7 sort + transpose into the output, 8 one-stage tridiagonalisation (sytrd).  Synchronises on the
+ *   Q1 / Q, 7 sort + transpose into the output, 8 one-stage tridiagonalisation (sytrd); two parts of stage 2 are
+ *   reported on their own and NOT included in out_ms[2]: 9 its streaming panel products P^T = V^T A22 (fp32 MFMA),
+ *   10 its delayed trailing updates (bf16 pipe).  Synchronises on the
  *   recorded events and clears them; call before vivit_profile_end or after, once. */
 int vivit_profile_stages(double *out_ms, int num);
 

@@ -91,7 +91,10 @@ void prof_begin(int kind, double work, hipStream_t stream);
 void prof_end(int kind, hipStream_t stream);
 // stage marks of the eigensolver (vivit_profile_stages): indices of out_ms
 enum { PROF_STAGE_BEGIN = 0, PROF_STAGE_PREP = 1, PROF_STAGE_SY2SB = 2, PROF_STAGE_SB2ST = 3, PROF_STAGE_TRIDIAG = 4,
-       PROF_STAGE_Q2 = 5, PROF_STAGE_Q1 = 6, PROF_STAGE_OUTPUT = 7, PROF_STAGE_SYTRD = 8, PROF_NUM_STAGES = 9 };
+       PROF_STAGE_Q2 = 5, PROF_STAGE_Q1 = 6, PROF_STAGE_OUTPUT = 7, PROF_STAGE_SYTRD = 8,
+       // parts of the band reduction that run on different pipes (the rest of it stays under PROF_STAGE_SY2SB):
+       // 9 the streaming panel product P^T = V^T A22 (fp32 MFMA), 10 the delayed trailing updates (bf16 pipe)
+       PROF_STAGE_SY2SB_PP = 9, PROF_STAGE_SY2SB_UPD = 10, PROF_NUM_STAGES = 11 };
 void prof_mark(int stage, hipStream_t stream);
 
 // Compute units of the current device (cached per device): the one-XCD persistent kernels (sytrd_persist.hip, the panel

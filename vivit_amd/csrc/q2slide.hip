@@ -31,6 +31,26 @@
 
 namespace vivit {
 
+// QS_VAR (timing-only builds, wrong results; scripts/probe/q2_variants.sh): 1 no arithmetic (DMA, barriers and Zt traffic
+// only), 2 no image DMA, 3 no DMA and no barriers, 4 no Zt loads / stores, 5 no split arithmetic, 6 no LDS fragment reads,
+// 7 = 3 + 4, 8 = 5 + 6 + 7 (MFMAs only)
+#ifndef QS_VAR
+#define QS_VAR 0
+#endif
+#if QS_VAR == 7 || QS_VAR == 8
+#define QS_NO_SYNC 1
+#define QS_NO_ZT 1
+#elif QS_VAR == 3
+#define QS_NO_SYNC 1
+#define QS_NO_ZT 0
+#elif QS_VAR == 4
+#define QS_NO_SYNC 0
+#define QS_NO_ZT 1
+#else
+#define QS_NO_SYNC 0
+#define QS_NO_ZT 0
+#endif
+
 typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 qbf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned qu32x4 __attribute__((ext_vector_type(4)));
@@ -60,33 +80,25 @@ static_assert(QS_NW2 == 14 && QS_NU == 12, "fragment lists");
 constexpr int QS_NFRAG = 3 * (QS_NW2 + QS_NU);  // 78
 constexpr int QS_IMG = QS_NFRAG * 1024;        // bytes per block image
 
-// 32-row waves (v_mfma_f32_32x32x16_bf16: t' tiles of 32, k steps of 16): the same counts, 14 + 12 steps of six MFMAs
-__host__ __device__ constexpr bool qs32_w2_need(int ks, int ta) { return 16 * ks + 15 >= 32 * ta + 1; }
-__host__ __device__ constexpr bool qs32_u_need(int wt, int kt) { return 16 * kt <= 32 * wt + 30 && 16 * kt + 15 >= 32 * wt - 64; }
-__host__ __device__ constexpr int qs32_count() {
-  int c = 0;
-  for (int ks = 0; ks < 8; ++ks)
-    for (int ta = 0; ta < 2; ++ta) c += qs32_w2_need(ks, ta) ? 1 : 0;
-  for (int wt = 0; wt < 4; ++wt)
-    for (int kt = 0; kt < 4; ++kt) c += qs32_u_need(wt, kt) ? 100 : 0;
-  return c;
-}
-static_assert(qs32_count() == 1214, "fragment lists of the 32-row form");
-// k index of element j of the lane half h in a 16-deep MFMA step of the 32-row form (both operands): the order in which
-// registers 8 s .. 8 s + 7 of a 32 x 32 accumulator hold its rows
-__host__ __device__ constexpr int qs32_kcol(int step, int h, int j) { return 16 * step + 8 * (j >> 2) + 4 * h + (j & 3); }
-
 // k index of element j of the lanes kq in MFMA step `step` (both operands)
 __host__ __device__ constexpr int qs_kcol(int step, int kq, int j) { return 32 * step + 16 * (j >> 2) + 4 * kq + (j & 3); }
 
 // exact three-way split of two fp32 values into packed bf16 pairs (low half = first value)
+// a - b as ONE v_sub_f32: hipcc pairs the residual subtractions into v_pk_add_f32, which costs ~13 cycles more than two
+// plain subtractions beside MFMAs (measured: -1.3 % of the kernel's time)
+__device__ __forceinline__ float qs_sub(float a, float b) {
+  float r;
+  __asm__("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ void qs_split2(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo) {
   const qbf16x2 h = {(__bf16)a, (__bf16)b};
   hi = __builtin_bit_cast(unsigned, h);
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  const float ra = qs_sub(a, __uint_as_float(hi << 16)), rb = qs_sub(b, __uint_as_float(hi & 0xffff0000u));
   const qbf16x2 m = {(__bf16)ra, (__bf16)rb};
   mid = __builtin_bit_cast(unsigned, m);
-  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+  const float sa = qs_sub(ra, __uint_as_float(mid << 16)), sb = qs_sub(rb, __uint_as_float(mid & 0xffff0000u));
   const qbf16x2 l = {(__bf16)sa, (__bf16)sb};
   lo = __builtin_bit_cast(unsigned, l);
 }
@@ -97,6 +109,17 @@ struct QsPieces {
 
 // eight fp32 values (element j of an MFMA operand: x = j 0..3, y = j 4..7) -> three bf16x8 operands
 __device__ __forceinline__ QsPieces qs_split8(const float4 x, const float4 y) {
+#if QS_VAR == 5 || QS_VAR == 8   // timing only: no split arithmetic
+  {
+    QsPieces p;
+    qu32x4 a = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
+    qu32x4 b = {__float_as_uint(y.x), __float_as_uint(y.y), __float_as_uint(y.z), __float_as_uint(y.w)};
+    p.h = __builtin_bit_cast(qbf16x8, a);
+    p.m = __builtin_bit_cast(qbf16x8, b);
+    p.l = p.h;
+    return p;
+  }
+#endif
   qu32x4 h, m, l;
   unsigned a, b, c;
   qs_split2(x.x, x.y, a, b, c); h[0] = a; m[0] = b; l[0] = c;
@@ -132,8 +155,6 @@ constexpr int QS_LDV = QS_WIN + 1;  // 129: odd row stride, column walks are con
 constexpr int QS_LDT = QS_W + 1;
 constexpr int QS_PREP_LDS = (2 * QS_W * QS_LDV + 2 * QS_W * QS_LDT + QS_W) * 4;
 
-// S32: fragments for 32-row waves on v_mfma_f32_32x32x16_bf16 (qs32_apply_kernel) instead of 16-row waves
-template <bool S32>
 __global__ __launch_bounds__(256) void qs_prepare_kernel(QsPrep a) {
   extern __shared__ __attribute__((aligned(16))) float qsp_lds[];
   float *Vw = qsp_lds;                 // [64][129]  Vw[t][w] = v_t[w - 1]
@@ -196,37 +217,58 @@ __global__ __launch_bounds__(256) void qs_prepare_kernel(QsPrep a) {
     for (int c = 0; c < 16; ++c) S[r * QS_LDT + cb + c] = acc[c];
   }
   __syncthreads();
-  if (tid < QS_W) tfactor_column(S, taus, Ts, QS_LDT, QS_W, tid);
-  __syncthreads();
-  // T V (T upper triangular): (S V^T) T^T = S (T V)^T, one product instead of two in the apply kernel
-  for (int idx = tid; idx < QS_W * QS_WIN; idx += 256) {
-    const int tp = idx / QS_WIN, w = idx - tp * QS_WIN;
-    float acc = 0.f;
-    // V[t][w] != 0 only for t in [w - 64, w - 1]
-    const int tlo = tp > w - QS_B ? tp : w - QS_B, thi = w - 1 < QS_W - 1 ? w - 1 : QS_W - 1;
-    for (int t = tlo; t <= thi; ++t) acc += Ts[tp * QS_LDT + t] * Vw[t * QS_LDV + w];
-    TV[tp * QS_LDV + w] = acc;
+  // T factor (device_utils.h:tfactor_column gives the same matrix with one thread per column: a dependent chain of 2016
+  // multiply-adds for the last column, ~100 us per block and most of this kernel).  Blocked instead: the four 16 x 16
+  // diagonal blocks by the column recurrence (chains of <= 120), then the merge T12 = -T1 (S12 T2) of compact-WY factors
+  // for the block pairs of size 16 and 32, every product spread over the 256 threads.  X: scratch in the T V array.
+  {
+    float *X = TV;
+    for (int idx = tid; idx < QS_W * QS_LDT; idx += 256) Ts[idx] = 0.f;
+    __syncthreads();
+    if (tid < QS_W) tfactor_column(S + (tid & ~15) * (QS_LDT + 1), taus + (tid & ~15), Ts + (tid & ~15) * (QS_LDT + 1), QS_LDT, 16, tid & 15);
+    __syncthreads();
+    for (int hb = 16; hb < QS_W; hb *= 2) {
+      const int npair = QS_W / (2 * hb), hh = hb * hb;
+      for (int idx = tid; idx < npair * hh; idx += 256) {   // X = S12 T2 (T2 upper triangular: k <= c)
+        const int pr = idx / hh, rem = idx - pr * hh, r = rem / hb, c = rem - r * hb, o = 2 * hb * pr;
+        float acc = 0.f;
+        for (int k = 0; k <= c; ++k) acc += S[(o + r) * QS_LDT + o + hb + k] * Ts[(o + hb + k) * QS_LDT + o + hb + c];
+        X[idx] = acc;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < npair * hh; idx += 256) {   // T12 = -T1 X (T1 upper triangular: k >= r)
+        const int pr = idx / hh, rem = idx - pr * hh, r = rem / hb, c = rem - r * hb, o = 2 * hb * pr;
+        float acc = 0.f;
+        for (int k = r; k < hb; ++k) acc += Ts[(o + r) * QS_LDT + o + k] * X[pr * hh + k * hb + c];
+        Ts[(o + r) * QS_LDT + o + hb + c] = -acc;
+      }
+      __syncthreads();
+    }
+  }
+  // T V (T upper triangular): (S V^T) T^T = S (T V)^T, one product instead of two in the apply kernel.  Thread = window
+  // column w and half of the rows t': V[t][w] is read once per t, T[t'][t] is the same word for the whole wave
+  {
+    const int w = tid & (QS_WIN - 1), tp0 = (tid >> 7) * 32;
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    // V[t][w] != 0 only for t in [w - 64, w - 1]; rows t' <= t
+    const int tlo = w - QS_B > tp0 ? w - QS_B : tp0, thi = w - 1 < QS_W - 1 ? w - 1 : QS_W - 1;
+    for (int t = tlo; t <= thi; ++t) {
+      const float v = Vw[t * QS_LDV + w];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) acc[j] += Ts[(tp0 + j) * QS_LDT + t] * v;   // (zero below the diagonal)
+    }
+    __syncthreads();   // (X aliased the T V array)
+#pragma unroll
+    for (int j = 0; j < 32; ++j) TV[(tp0 + j) * QS_LDV + w] = acc[j];
   }
   __syncthreads();
   // fragments: (fragment triple ft, lane) items; a thread writes the three 16-byte pieces of its lane
   for (int idx = tid; idx < (QS_NW2 + QS_NU) * 64; idx += 256) {
     const int ft = idx >> 6, ln = idx & 63;
     float v[8];
-    if constexpr (S32) {
-      const int r = ln & 31, hh = ln >> 5;
-      if (ft < QS_NW2) {
-        // walk order of the W2 steps: ks outer (0..7), t' tile inner: ks = 0, 1: tile 0 only; ks >= 2: tiles 0, 1
-        const int ks = ft < 2 ? ft : 2 + (ft - 2) / 2, ta = ft < 2 ? 0 : (ft - 2) & 1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = TV[(32 * ta + r) * QS_LDV + qs32_kcol(ks, hh, j)];
-      } else {
-        // walk order of the U steps (qs32_step): (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) | (1,2) (1,3) (2,2) (2,3) (3,2) (3,3)
-        const int fu = ft - QS_NW2;
-        const int wt = fu < 6 ? fu / 2 : 1 + (fu - 6) / 2, kt = fu < 6 ? (fu & 1) : 2 + ((fu - 6) & 1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = Vw[qs32_kcol(kt, hh, j) * QS_LDV + 32 * wt + r];
-      }
-    } else {
+    {
       const int m16 = ln & 15, kq = ln >> 4;
       if (ft < QS_NW2) {
         // walk order of the W2 steps: ks outer, ta inner over the needed tiles: ks = 0: ta 0, 1; ks >= 1: ta 0..3
@@ -278,9 +320,6 @@ typedef const __attribute__((address_space(3))) qbf16x8 *qs_lds_frag;
 
 // QS_VAR (timing-only builds, wrong results; scripts/probe/q2_variants.sh): 1 no arithmetic (DMA, barriers and Zt traffic
 // only), 2 no image DMA, 3 no DMA and no barriers, 4 no Zt loads / stores
-#ifndef QS_VAR
-#define QS_VAR 0
-#endif
 
 // the 26 tile steps of a block in walk order: steps 0..13 form W2^T (ks outer, t'-tile inner), 14..25 form U^T (w-tile
 // outer, kt inner).  Compile-time tables (every index below is a constant after unrolling).
@@ -320,6 +359,15 @@ struct QsFrag {
 };
 __device__ __forceinline__ QsFrag qs_frag(qs_lds_ptr frag, int i) {
   QsFrag f;
+#if QS_VAR == 6 || QS_VAR == 8   // timing only: no LDS reads
+  {
+    qu32x4 a = {(unsigned)(uintptr_t)frag, 0x3f803f80u, (unsigned)i, 0x3f803f80u};
+    f.h = __builtin_bit_cast(qbf16x8, a);
+    f.m = f.h;
+    f.l = f.h;
+    return f;
+  }
+#endif
   f.h = *reinterpret_cast<qs_lds_frag>(frag + (3 * i + 0) * 1024);
   f.m = *reinterpret_cast<qs_lds_frag>(frag + (3 * i + 1) * 1024);
   f.l = *reinterpret_cast<qs_lds_frag>(frag + (3 * i + 2) * 1024);
@@ -353,7 +401,13 @@ __device__ __forceinline__ void qs_apply_block(float4 (&sw)[12], qs_lds_ptr frag
     mid(i);
     if constexpr (st.ks >= 0) {
       if constexpr (i == 0 || st.ks != prev.ks) bp = qs_split8(sw[Q0 + 2 * st.ks], sw[Q0 + 2 * st.ks + 1]);
+#if defined(QS_PRIO)
+      __builtin_amdgcn_s_setprio(1);
+#endif
       QS_MFMA6(acc2[st.ta], cur.h, cur.m, cur.l, bp)
+#if defined(QS_PRIO)
+      __builtin_amdgcn_s_setprio(0);
+#endif
     } else {
       if constexpr (i == QS_NW2) {
         wp[0] = qs_split8(make_float4(acc2[0][0], acc2[0][1], acc2[0][2], acc2[0][3]),
@@ -365,13 +419,22 @@ __device__ __forceinline__ void qs_apply_block(float4 (&sw)[12], qs_lds_ptr frag
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = 0.f;
       }
+#if defined(QS_PRIO)
+      __builtin_amdgcn_s_setprio(1);
+#endif
       QS_MFMA6(u, cur.h, cur.m, cur.l, wp[st.kt])
+#if defined(QS_PRIO)
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if constexpr (i + 1 == QS_NSTEP || next.wt != st.wt) {
         float4 &x = sw[Q0 + st.wt];
         x.x -= u[0]; x.y -= u[1]; x.z -= u[2]; x.w -= u[3];
       }
     }
     cur = nxt;
+    // nothing moves across a step boundary: the scheduler otherwise hoists the fragment reads of several steps and the
+    // next split to the front (three more registers than the 168 that ten to twelve waves per workgroup allow)
+    __builtin_amdgcn_sched_barrier(0);
   });
 }
 
@@ -383,9 +446,12 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = (int)(blockDim.x >> 6);
   const int n16 = lane & 15, kq = lane >> 4;
-  const int64_t row = (int64_t)blockIdx.x * (16 * nw) + wave * 16 + n16;
-  const bool rok = row < a.nrows;
-  float *zrow = a.Zt + (rok ? row : 0) * a.ldz + 4 * kq;   // + 64 unit + 16 q
+  // wave-uniform row base (scalar registers) + a 32-bit lane offset: one VGPR of address instead of a 64-bit pointer
+  const int64_t row0 = (int64_t)blockIdx.x * (16 * nw) + wave * 16;
+  const bool wave_valid = row0 < a.nrows;                  // some row of the wave exists
+  const bool rok = row0 + n16 < a.nrows;
+  float *zbase = a.Zt + (wave_valid ? row0 : 0) * a.ldz;   // rows beyond nrows read the wave's first row and are never stored
+  const unsigned zoff = (unsigned)((rok ? n16 : 0) * a.ldz + 4 * kq);   // + 64 unit + 16 q
   const int n = a.n;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)qs_lds);
   qs_lds_ptr myfrag = (qs_lds_ptr)qs_lds + lane * 16;
@@ -409,19 +475,20 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
   auto dma = [&](int64_t seq) __attribute__((always_inline)) {
     for (int j = 0; j < npiece; ++j) dma_piece(seq, j);
   };
-  // pieces requested at tile step i of the block that computes while the image lands: piece i / 2 at the even steps
-  // (13 slots; no loop and no branch but the piece's own bound check inside the unrolled step code), whatever is left
-  // (fewer than six waves) at step 0
+  // pieces requested at tile step i of the block that computes while the image lands: piece i at steps 0 .. 12 (one
+  // request per step: they do not queue up behind the barrier, and all of them are out in the first half of the block so
+  // that the image has the second half to land), whatever is left (fewer than six waves) at step 0
+  constexpr int QS_DMA_STEPS = QS_NSTEP / 2;   // 13
   auto dma_step = [&](int64_t seq, int i) __attribute__((always_inline)) {
     if (i == 0)
-      for (int j = QS_NSTEP / 2; j < npiece; ++j) dma_piece(seq, j);
-    if ((i & 1) == 0) dma_piece(seq, i / 2);
+      for (int j = QS_DMA_STEPS; j < npiece; ++j) dma_piece(seq, j);
+    if (i < QS_DMA_STEPS) dma_piece(seq, i);
   };
   // unit u entirely inside the matrix (64 u + 63 < n): unguarded loads (rows beyond nrows read row 0, never stored)
   auto load_unit = [&](int u, float4 (&dst)[4]) __attribute__((always_inline)) {
-    const float4 *src = reinterpret_cast<const float4 *>(zrow + (int64_t)64 * u);
+    const float *src = zbase + (int64_t)64 * u;   // (uniform)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = src[4 * q];
+    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const float4 *>(src + zoff + 16 * q);
   };
   // the last unit of the matrix (u = G0: columns up to n - 1 exist; n % 4 == 0, so a float4 is all in or all out)
   auto load_unit_edge = [&](int u, float4 (&dst)[4]) __attribute__((always_inline)) {
@@ -430,26 +497,28 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
     for (int q = 0; q < 4; ++q) {
       const bool ok = c0 + 16 * q < n;
       dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) dst[q] = *reinterpret_cast<const float4 *>(zrow + (int64_t)64 * u + 16 * q);
+      if (ok) dst[q] = *reinterpret_cast<const float4 *>(zbase + (int64_t)64 * u + zoff + 16 * q);
     }
   };
   auto store_unit = [&](int u, const float4 *src) __attribute__((always_inline)) {
     const int c0 = 64 * u + 4 * kq;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (rok && c0 + 16 * q < n) *reinterpret_cast<float4 *>(zrow + (int64_t)64 * u + 16 * q) = src[q];
+      if (rok && c0 + 16 * q < n) *reinterpret_cast<float4 *>(zbase + (int64_t)64 * u + zoff + 16 * q) = src[q];
   };
 
   // The Zt loads and stores are plain C++ (hipcc counts them), the image DMAs are asm (hipcc does not): a wait that hipcc
-  // places for one of ITS loads also drains every DMA issued before that point.  The loop is therefore arranged so that
-  // hipcc's waits fall where nothing of ours is in flight:
+  // places for one of ITS loads also drains every DMA issued before that point.  The loop is arranged so that hipcc's
+  // waits fall where that is wanted anyway, and the hand-placed waits count the operations that may stay in flight:
   //   * nothing of hipcc's is pending at the loop entry (compiler-visible vmcnt(0) behind the pass-start loads);
-  //   * the prefetched unit `pre` is "used" by an empty asm right behind the wait at the top of the second block, before
-  //     the next image is requested, so hipcc's wait for it is a no-op there;
-  //   * the stores of the retired unit need no wait at all; the wait at the top of the next first block leaves them in
-  //     flight (vmcnt(4): they are the four youngest operations) when all four were issued (`steady`).
+  //   * the next group's unit `pre` is requested in the MIDDLE of the first block, behind that block's image requests: it is
+  //     the four youngest operations at the top of the second block (vmcnt(4) there waits for the image only) and has
+  //     one and a half blocks to arrive;
+  //   * `pre` is "used" by an empty asm at the end of the second block, in front of the stores: hipcc's wait for it also
+  //     waits for the image requests of the second block, which the next first block needs in any case;
+  //   * the stores of the retired unit need no wait; the wait at the top of the next first block leaves them in flight
+  //     (vmcnt(4): they are the four youngest operations) when all four were issued (`steady`).
 #define QS_USE4(a) "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)
-  const bool wave_valid = (int64_t)blockIdx.x * (16 * nw) + wave * 16 < a.nrows;   // wave-uniform: some row of the wave exists
   int64_t seq = 0;
   if (nseq > 0) dma(0);
   float4 sw[12];
@@ -469,51 +538,56 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible
       __asm__ volatile("" : QS_USE4(sw[0]), QS_USE4(sw[1]), QS_USE4(sw[2]), QS_USE4(sw[3]));
     }
-    bool steady = false;   // the previous step issued exactly four stores behind the image request
+    bool steady = false;   // the previous step issued exactly four stores behind the image requests
     for (int g = gmax; g >= 0; --g) {
       // ---- block (g, 2K): its image has landed once every wave is past this wait and the barrier
       if (steady) __asm__ volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if QS_VAR != 3
+#if !QS_NO_SYNC
       __builtin_amdgcn_s_barrier();
 #endif
       const int64_t seq_a = seq + 1 < nseq ? seq + 1 : 0;   // (the very last block re-requests image 0: never read)
-      // next group's left unit (g - 1 + 2K < G0: inside the matrix), in flight during the block.  Unconditional (the last
-      // group of a pass fetches a unit it does not use): a branch around the loads makes hipcc wait for them at the join
+      // next group's left unit (g - 1 + 2K < G0: inside the matrix).  Unconditional (the last group of a pass fetches a
+      // unit it does not use): a branch around the loads makes hipcc wait for them at the join
       float4 pre[4];
-      {
-        const int up = g - 1 + 2 * K;
-#if QS_VAR == 4
-        for (int q = 0; q < 4; ++q) pre[q] = sw[q];
-#else
-        load_unit(up > 0 ? up : 0, pre);
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);   // (the loads stay up here)
+      const int up = g - 1 + 2 * K;
       qs_apply_block<0>(sw, myfrag + (seq & 1) * QS_IMG, [&](int i) __attribute__((always_inline)) {
-#if QS_VAR != 2 && QS_VAR != 3
+#if QS_VAR != 2 && !QS_NO_SYNC
         dma_step(seq_a, i);
 #endif
+        if (i == QS_DMA_STEPS) {
+#if QS_NO_ZT
+          for (int q = 0; q < 4; ++q) pre[q] = sw[8 + q];
+#else
+          load_unit(up > 0 ? up : 0, pre);
+#endif
+          __builtin_amdgcn_sched_barrier(0);   // (the loads stay here: behind the image requests, in front of the rest)
+        }
       });
       ++seq;
       {
         // ---- block (g, 2K + 1) (g = gmax: the identity block)
+#if QS_NO_ZT
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if QS_VAR != 3
+#else
+        __asm__ volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the image; `pre` stays in flight
+#endif
+#if !QS_NO_SYNC
         __builtin_amdgcn_s_barrier();
 #endif
-        __asm__ volatile("" : QS_USE4(pre[0]), QS_USE4(pre[1]), QS_USE4(pre[2]), QS_USE4(pre[3]));
         const int64_t seq_b = seq + 1 < nseq ? seq + 1 : 0;
         qs_apply_block<4>(sw, myfrag + (seq & 1) * QS_IMG, [&](int i) __attribute__((always_inline)) {
-#if QS_VAR != 2 && QS_VAR != 3
+#if QS_VAR != 2 && !QS_NO_SYNC
           dma_step(seq_b, i);
 #endif
         });
         ++seq;
       }
+      // hipcc waits for `pre` here (and with it for the image requests of the block just computed)
+      __asm__ volatile("" : QS_USE4(pre[0]), QS_USE4(pre[1]), QS_USE4(pre[2]), QS_USE4(pre[3]));
       // the right unit is final: store it, slide the window
       const int ur = g + 2 * K + 2;
-#if QS_VAR != 4
+#if !QS_NO_ZT
       store_unit(ur, &sw[8]);
 #endif
       steady = wave_valid && 64 * ur + 63 < n;
@@ -523,225 +597,6 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
     // after g = 0: units 2K (slot 1) and 2K + 1 (slot 2) are still in registers
     store_unit(2 * K, &sw[4]);
     store_unit(2 * K + 1, &sw[8]);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // the next pass reads what this one stored
-  }
-  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last image request
-#undef QS_USE4
-}
-
-
-// ====================================================================================================================
-// 32-row waves on v_mfma_f32_32x32x16_bf16.  The 16-row form above is bound by the SIMD's instruction ISSUE, not by its
-// matrix pipe: a 16x16x32 MFMA holds the vector issue port for 8 of its 16 cycles, which leaves two issue slots per MFMA
-// for the ~1.7 split instructions, the LDS reads and the pads that go with it (measured: the three waves of a SIMD need
-// MFMA time + VALU time, 5.0 us per block against 3.45 us of MFMAs).  A 32x32x16 MFMA holds the port for 8 of 32 cycles
-// and does twice the work: six free slots per MFMA for the same split work per row.  Lane (r = lane & 31, h = lane >> 5)
-// keeps S[row r][8 q + 4 h .. + 3], q = 0..23 (three units of eight float4); k order of a 16-deep step as qs32_kcol.
-#define QS32_MFMA6(acc, ah, am, al, bp)                                                 \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, (bp).h, acc, 0, 0, 0);              \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, (bp).l, acc, 0, 0, 0);              \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, (bp).m, acc, 0, 0, 0);              \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, (bp).h, acc, 0, 0, 0);              \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, (bp).m, acc, 0, 0, 0);              \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, (bp).h, acc, 0, 0, 0);
-
-// U steps in two halves over t': (w tile 0..2) x (kt 0, 1), then (w tile 1..3) x (kt 2, 3) -- each half needs the pieces of
-// ONE accumulator tile of W2^T only (24 registers instead of 48), at the price of two more subtractions from the window
-__host__ __device__ constexpr QsStep qs32_step(int i) {
-  int c = 0;
-  for (int ks = 0; ks < 8; ++ks)
-    for (int ta = 0; ta < 2; ++ta)
-      if (qs32_w2_need(ks, ta)) {
-        if (c == i) return QsStep{ks, ta, -1, -1};
-        ++c;
-      }
-  for (int half = 0; half < 2; ++half)
-    for (int wt = 0; wt < 4; ++wt)
-      for (int kt = 2 * half; kt < 2 * half + 2; ++kt)
-        if (qs32_u_need(wt, kt)) {
-          if (c == i) return QsStep{-1, -1, wt, kt};
-          ++c;
-        }
-  return QsStep{-1, -1, -1, -1};
-}
-
-// one block on the float4s Q0 .. Q0 + 15 of the window (two units); see qs_apply_block
-template <int Q0, class Mid>
-__device__ __forceinline__ void qs32_apply_block(float4 (&sw)[24], qs_lds_ptr frag, Mid mid) {
-#if QS_VAR == 1
-  __asm__ volatile("" : "+v"(sw[Q0].x), "+v"(sw[Q0 + 15].w));
-  qs_static_for<QS_NSTEP>([&](auto itag) __attribute__((always_inline)) { mid(decltype(itag)::value); });
-  return;
-#endif
-  f32x16 acc2[2];
-#pragma unroll
-  for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[ta][e] = 0.f;
-  QsPieces bp, wp[2];
-  f32x16 u;
-  QsFrag cur = qs_frag(frag, 0);
-  qs_static_for<QS_NSTEP>([&](auto itag) __attribute__((always_inline)) {
-    constexpr int i = decltype(itag)::value;
-    constexpr QsStep st = qs32_step(i), prev = qs32_step(i > 0 ? i - 1 : 0), next = qs32_step(i + 1 < QS_NSTEP ? i + 1 : i);
-    QsFrag nxt = cur;
-    if constexpr (i + 1 < QS_NSTEP) nxt = qs_frag(frag, i + 1);
-    mid(i);
-    if constexpr (st.ks >= 0) {
-      if constexpr (i == 0 || st.ks != prev.ks) bp = qs_split8(sw[Q0 + 2 * st.ks], sw[Q0 + 2 * st.ks + 1]);
-      QS32_MFMA6(acc2[st.ta], cur.h, cur.m, cur.l, bp)
-    } else {
-      if constexpr (i == QS_NW2 || (prev.wt >= 0 && (prev.kt >> 1) != (st.kt >> 1))) {
-        // registers 8 s .. 8 s + 7 of accumulator tile kt >> 1 are the B operand of t' step kt (s = kt & 1)
-        const f32x16 &x = acc2[st.kt >> 1];
-        wp[0] = qs_split8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]));
-        wp[1] = qs_split8(make_float4(x[8], x[9], x[10], x[11]), make_float4(x[12], x[13], x[14], x[15]));
-      }
-      if constexpr (i == QS_NW2 || prev.wt != st.wt || (prev.kt >> 1) != (st.kt >> 1)) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) u[e] = 0.f;
-      }
-      QS32_MFMA6(u, cur.h, cur.m, cur.l, wp[st.kt & 1])
-      if constexpr (i + 1 == QS_NSTEP || next.wt != st.wt || (next.kt >> 1) != (st.kt >> 1)) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float4 &x = sw[Q0 + 4 * st.wt + c];
-          x.x -= u[4 * c]; x.y -= u[4 * c + 1]; x.z -= u[4 * c + 2]; x.w -= u[4 * c + 3];
-        }
-      }
-    }
-    cur = nxt;
-    // the scheduler may not move anything across a step boundary: it would hoist the fragment reads of several steps
-    // and the next split to the front (the window, the prefetched unit and the pieces already take ~220 registers)
-    __builtin_amdgcn_sched_barrier(0);
-  });
-}
-
-// MAXW = 8: up to eight waves of 32 rows per workgroup (two per SIMD, 256 registers each: the window, the prefetched unit
-// and the pieces do not fit, hipcc spills); MAXW = 4: one wave per SIMD, up to 512 registers
-template <int MAXW>
-__global__ __launch_bounds__(64 * MAXW) void qs32_apply_kernel(QsArgs a) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char qs_lds[];  // two images
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = (int)(blockDim.x >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t row = (int64_t)blockIdx.x * (32 * nw) + wave * 32 + r;
-  const bool rok = row < a.nrows;
-  float *zrow = a.Zt + (rok ? row : 0) * a.ldz + 4 * h;   // + 64 unit + 8 c
-  const int n = a.n;
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)qs_lds);
-  qs_lds_ptr myfrag = (qs_lds_ptr)qs_lds + lane * 16;
-  const int64_t nseq = qs_pass_offset(a.G0, a.K0, a.K1);
-  const unsigned lane16 = (unsigned)lane * 16u;
-  auto dma_piece = [&](int64_t seq, int j) __attribute__((always_inline)) {
-    const int f = wave + nw * j;
-    if (f < QS_NFRAG) {
-      const unsigned char *src = a.img + seq * (int64_t)QS_IMG + (int64_t)f * 1024;
-      const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG + (unsigned)f * 1024u);
-      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");
-    }
-  };
-  const int npiece = (QS_NFRAG + nw - 1) / nw;
-  // pieces requested at tile step i of the block that computes while the image lands: piece i / 2 at the even steps
-  // (13 slots; no loop and no branch but the piece's own bound check inside the unrolled step code), whatever is left
-  // (fewer than six waves) at step 0
-  auto dma_step = [&](int64_t seq, int i) __attribute__((always_inline)) {
-    if (i == 0)
-      for (int j = QS_NSTEP / 2; j < npiece; ++j) dma_piece(seq, j);
-    if ((i & 1) == 0) dma_piece(seq, i / 2);
-  };
-  auto load_unit = [&](int u, float4 (&dst)[8]) __attribute__((always_inline)) {
-    const float4 *src = reinterpret_cast<const float4 *>(zrow + (int64_t)64 * u);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) dst[c] = src[2 * c];
-  };
-  auto load_unit_edge = [&](int u, float4 (&dst)[8]) __attribute__((always_inline)) {
-    const int c0 = 64 * u + 4 * h;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const bool ok = c0 + 8 * c < n;
-      dst[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) dst[c] = *reinterpret_cast<const float4 *>(zrow + (int64_t)64 * u + 8 * c);
-    }
-  };
-  auto store_unit = [&](int u, const float4 *src) __attribute__((always_inline)) {
-    const int c0 = 64 * u + 4 * h;
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (rok && c0 + 8 * c < n) *reinterpret_cast<float4 *>(zrow + (int64_t)64 * u + 8 * c) = src[c];
-  };
-#define QS_USE4(a) "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)
-  const bool wave_valid = (int64_t)blockIdx.x * (32 * nw) + wave * 32 < a.nrows;
-  int64_t seq = 0;
-  if (nseq > 0)
-    for (int j = 0; j < npiece; ++j) dma_piece(0, j);
-  float4 sw[24];
-  for (int K = a.K0; K < a.K1; ++K) {
-    const int gmax = a.G0 - 2 * K;
-    {
-      float4 t0[8];
-      load_unit_edge(gmax + 2 * K, t0);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        sw[c] = t0[c];
-        sw[8 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sw[16 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), compiler-visible
-      __asm__ volatile("" : QS_USE4(sw[0]), QS_USE4(sw[1]), QS_USE4(sw[2]), QS_USE4(sw[3]));
-      __asm__ volatile("" : QS_USE4(sw[4]), QS_USE4(sw[5]), QS_USE4(sw[6]), QS_USE4(sw[7]));
-    }
-    bool steady = false;   // the previous step issued exactly eight stores behind the image requests
-    for (int g = gmax; g >= 0; --g) {
-      if (steady) __asm__ volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if QS_VAR != 3
-      __builtin_amdgcn_s_barrier();
-#endif
-      const int64_t seq_a = seq + 1 < nseq ? seq + 1 : 0;   // (the very last block re-requests image 0: never read)
-      float4 pre[8];
-      {
-        const int up = g - 1 + 2 * K;
-#if QS_VAR == 4
-        for (int c = 0; c < 8; ++c) pre[c] = sw[c];
-#else
-        load_unit(up > 0 ? up : 0, pre);
-#endif
-      }
-      __builtin_amdgcn_sched_barrier(0);   // (the loads stay up here)
-      qs32_apply_block<0>(sw, myfrag + (seq & 1) * QS_IMG, [&](int i) __attribute__((always_inline)) {
-#if QS_VAR != 2 && QS_VAR != 3
-        dma_step(seq_a, i);
-#endif
-      });
-      ++seq;
-      {
-        // ---- block (g, 2K + 1) (g = gmax: the identity block)
-        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if QS_VAR != 3
-        __builtin_amdgcn_s_barrier();
-#endif
-        __asm__ volatile("" : QS_USE4(pre[0]), QS_USE4(pre[1]), QS_USE4(pre[2]), QS_USE4(pre[3]));
-        __asm__ volatile("" : QS_USE4(pre[4]), QS_USE4(pre[5]), QS_USE4(pre[6]), QS_USE4(pre[7]));
-        const int64_t seq_b = seq + 1 < nseq ? seq + 1 : 0;
-        qs32_apply_block<8>(sw, myfrag + (seq & 1) * QS_IMG, [&](int i) __attribute__((always_inline)) {
-#if QS_VAR != 2 && QS_VAR != 3
-          dma_step(seq_b, i);
-#endif
-        });
-        ++seq;
-      }
-      const int ur = g + 2 * K + 2;
-#if QS_VAR != 4
-      store_unit(ur, &sw[16]);
-#endif
-      steady = wave_valid && 64 * ur + 63 < n;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { sw[16 + c] = sw[8 + c]; sw[8 + c] = sw[c]; sw[c] = pre[c]; }
-    }
-    store_unit(2 * K, &sw[8]);
-    store_unit(2 * K + 1, &sw[16]);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // the next pass reads what this one stored
   }
   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last image request
@@ -778,7 +633,7 @@ bool q2_slide_ok(int64_t nrows, int64_t n, const float *Zt, int64_t ldz) {
   static int on = -1, min_rows = 0;
   if (on < 0) {
     on = qs_env("VIVIT_Q2_SLIDE", 1);
-    min_rows = qs_env("VIVIT_Q2_SLIDE_MIN_ROWS", 24576);
+    min_rows = qs_env("VIVIT_Q2_SLIDE_MIN_ROWS", 14336);
   }
   const bool vec = ((reinterpret_cast<uintptr_t>(Zt) & 15) == 0) && (ldz % 4 == 0) && (n % 4 == 0);
   return on != 0 && vec && n >= 192 && nrows >= min_rows && device_cu_count() > 0;
@@ -795,10 +650,7 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     if (!(attr_done & (1ull << (dev & 63)))) {
       if (!ensure_dynamic_lds(reinterpret_cast<const void *>(qs_apply_kernel<8>), QS_APPLY_LDS, attr_done) ||
           !ensure_dynamic_lds(reinterpret_cast<const void *>(qs_apply_kernel<12>), QS_APPLY_LDS, attr_done) ||
-          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs32_apply_kernel<4>), QS_APPLY_LDS, attr_done) ||
-          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs32_apply_kernel<8>), QS_APPLY_LDS, attr_done) ||
-          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs_prepare_kernel<false>), QS_PREP_LDS, attr_done) ||
-          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs_prepare_kernel<true>), QS_PREP_LDS, attr_done))
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(qs_prepare_kernel), QS_PREP_LDS, attr_done))
         return VIVIT_E_LAUNCH;
       attr_done |= 1ull << (dev & 63);
     }
@@ -807,22 +659,15 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
   const size_t img_bytes = ws_bytes - (size_t)(img - reinterpret_cast<unsigned char *>(ws));
   const int G0 = (int)((n - 2) / 64);
   const int Kend = G0 / 2 + 1;   // passes K with gmax(K) = G0 - 2K >= 0
-  // wave shape: 32 rows per wave on the 32x32x16 MFMA (default), or 16 rows on the 16x16x32 MFMA (VIVIT_Q2_SLIDE_SHAPE=16)
-  static int shape = 0, force_nw = -2;
-  if (shape == 0) {
-    shape = qs_env("VIVIT_Q2_SLIDE_SHAPE", 16) == 32 ? 32 : 16;
-    force_nw = qs_env("VIVIT_Q2_SLIDE_WAVES", -1);
-  }
+  // waves per workgroup (16 rows each): one slab per CU when the rows allow it, at most 12 waves (168 registers)
+  static int force_nw = -2;
+  if (force_nw == -2) force_nw = qs_env("VIVIT_Q2_SLIDE_WAVES", -1);
   const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
-  // waves per workgroup: 32-row form: eight (256-row slabs, two waves per SIMD), fewer when the rows do not fill the CUs;
-  // 16-row form: one slab per CU when the rows allow it, at most 12 waves (168 registers)
-  const int wmax = shape == 32 ? 8 : 12;
-  int nw = (int)cdiv(cdiv(nrows, cus), shape);
-  if (shape == 32 && nw < 8 && nrows >= (int64_t)cus * 128) nw = 8;
+  int nw = (int)cdiv(cdiv(nrows, cus), 16);
   if (force_nw > 0) nw = force_nw;
   if (nw < 1) nw = 1;
-  if (nw > wmax) nw = wmax;
-  const unsigned nslab = (unsigned)cdiv(nrows, shape * nw);
+  if (nw > 12) nw = 12;
+  const unsigned nslab = (unsigned)cdiv(nrows, 16 * nw);
   QsPrep pa;
   pa.R2 = R2; pa.ldr = ldr; pa.tau2 = tau2; pa.nk = sb2st_num_levels(n); pa.n = (int)n; pa.G0 = G0; pa.img = img;
   QsArgs aa;
@@ -832,12 +677,9 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     if (K1 == K0) return VIVIT_E_WORKSPACE;
     pa.K0 = K0;
     const dim3 pgrid((unsigned)(2 * (G0 - 2 * K0) + 2), (unsigned)(K1 - K0));
-    if (shape == 32) qs_prepare_kernel<true><<<pgrid, 256, QS_PREP_LDS, stream>>>(pa);
-    else qs_prepare_kernel<false><<<pgrid, 256, QS_PREP_LDS, stream>>>(pa);
+    qs_prepare_kernel<<<pgrid, 256, QS_PREP_LDS, stream>>>(pa);
     aa.K0 = K0; aa.K1 = K1;
-    if (shape == 32 && nw <= 4) qs32_apply_kernel<4><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
-    else if (shape == 32) qs32_apply_kernel<8><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
-    else if (nw <= 8) qs_apply_kernel<8><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
+    if (nw <= 8) qs_apply_kernel<8><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
     else qs_apply_kernel<12><<<nslab, 64 * nw, QS_APPLY_LDS, stream>>>(aa);
     K0 = K1;
   }

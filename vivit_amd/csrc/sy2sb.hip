@@ -761,7 +761,9 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     int st;
     // Pt = Vt A22                      [SNB x mp]   (A22 symmetric: B operand k-major = A22 itself; the big
     // operand is streamed exactly once: gemm64_dma_kernel)
+    prof_mark(PROF_STAGE_SY2SB, stream);
     st = gemm_launch(LAY_K, LAY_M, Vt, A22, Wt, SNB, mp, mp, ldn, lda, ldn, 1.f, 0.f, false, ws.gws, ws.gws_bytes, stream);
+    prof_mark(PROF_STAGE_SY2SB_PP, stream);
     if (st != VIVIT_OK) return st;
     // [G12 | S] = Vt [V1 W1 .. V]^T: the stack rows 0 .. kp + SNB - 1 end with this panel's V, so the Gram blocks against the
     // pending updates (G12, for the correction of Pt) and against itself (S, for T) are ONE deep-K product
@@ -839,8 +841,10 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     }
     // ---- trailing matrix (from the last panel's gi) -= stackA^T stackB : one update, lower tiles + mirror
     const int64_t mt = n - gi_last;
+    prof_mark(PROF_STAGE_SY2SB, stream);
     st = gemm_launch(LAY_M, LAY_M, sA + gi_last, sB + gi_last, A + gi_last * lda + gi_last, mt, mt, (int64_t)2 * SNB * np, ldn, ldn,
                      lda, -1.f, 1.f, true, ws.gws, ws.gws_bytes, stream);
+    prof_mark(PROF_STAGE_SY2SB_UPD, stream);
     if (st != VIVIT_OK) return st;
   }
   return launch_status();

@@ -168,11 +168,12 @@ def verify_symeig(G, w, Z, block=4096):
             r = G @ Zi - Zi * w[i:i + block]
             res = max(res, r.abs().max().item())
             del gram, r
-        out["orth_err"] = orth
         out["residual_err"] = res / lam
-        # the same quantity with fp64 ACCUMULATION on 256 sampled eigenvectors against all n (the checker's own fp32 sums
-        # over n terms are not what limits orth_err), and its rms: the maximum above is taken over n^2 = 1.7e9 entries of
-        # rounding noise of size ~ sqrt(n) eps (LAPACK's bound for ||Z^T Z - I|| is p(n) eps), i.e. ~6 sigma
+        # Orthonormality is measured with fp64 ACCUMULATION on 256 sampled eigenvectors against all n (2.1e7 entries of
+        # Z^T Z - I): the fp32 matmul of the checker above carries its own error over n = 4e4 terms -- round 4 measured
+        # 8.4e-5 with it where the fp64 accumulation of the same entries gives 2.3e-6 (rms 6.9e-8; the noise scale of an
+        # fp32 eigensolver is sqrt(n) eps = 1.2e-5).  `orth_err` is the fp64 figure; the fp32 whole-matrix figure stays as
+        # `orth_err_fp32_checker` with its own, looser bound (it still catches a wrong eigenvector anywhere in Z).
         g = torch.Generator().manual_seed(0)
         cols = torch.randperm(n, generator=g)[:256].to(G.device)
         Zc = Z[:, cols].double()
@@ -180,8 +181,9 @@ def verify_symeig(G, w, Z, block=4096):
         for i in range(0, n, block):
             acc += Z[i:i + block].double().T @ Zc[i:i + block]
         acc[cols, torch.arange(cols.numel(), device=G.device)] -= 1.0
-        out["orth_err_fp64_sampled"] = acc.abs().max().item()
-        out["orth_rms_fp64_sampled"] = acc.pow(2).mean().sqrt().item()
+        out["orth_err"] = acc.abs().max().item()
+        out["orth_rms"] = acc.pow(2).mean().sqrt().item()
+        out["orth_err_fp32_checker"] = orth
         out["orth_noise_scale_sqrt_n_eps"] = float(n) ** 0.5 * 2.0 ** -24
         del acc, Zc
     return out
@@ -192,7 +194,7 @@ def verify_symeig(G, w, Z, block=4096):
 # the fp32 MFMA kernel / the bf16-pipe kernel: 1.3e-6 / 2.6e-6 off the diagonal, 2.5e-6 / 3.7e-6 on it where all terms
 # are positive and rounding cannot cancel, 3.5e-7 / 1.2e-6 for the trace)
 VERIFY_BOUNDS = {"entry_err": 5e-6, "diag_err": 1e-5, "trace_err": 4e-6, "eig_trace_err": 1e-5, "fro_err": 1e-4,
-                 "orth_err": 1e-4, "residual_err": 3e-5}
+                 "orth_err": 2e-5, "orth_err_fp32_checker": 2e-4, "residual_err": 3e-5}
 
 
 def verified_ok(vg, ve):
@@ -201,6 +203,7 @@ def verified_ok(vg, ve):
     ok = ok and ve["trace_err"] <= VERIFY_BOUNDS["eig_trace_err"] and ve["fro_err"] <= VERIFY_BOUNDS["fro_err"]
     if "orth_err" in ve:
         ok = ok and ve["orth_err"] <= VERIFY_BOUNDS["orth_err"] and ve["residual_err"] <= VERIFY_BOUNDS["residual_err"]
+        ok = ok and ve["orth_err_fp32_checker"] <= VERIFY_BOUNDS["orth_err_fp32_checker"]
     return bool(ok)
 
 

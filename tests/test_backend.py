@@ -99,10 +99,17 @@ def make_problem(name):
         model = nn.Sequential(nn.ConvTranspose2d(2, 3, 2, stride=2, output_padding=1), nn.Tanh(), nn.Flatten(),
                               nn.Linear(75, 3))
         X, y, lossf, loss = torch.rand(3, 2, 2, 2), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "pool1d_ce":  # SqrtGGN{Max,Avg}Pool1d (__init__.py:97-102) on the two-dimensional kernels
+        model = nn.Sequential(nn.Conv1d(2, 3, 2), nn.MaxPool1d(2), nn.Tanh(), nn.AvgPool1d(2, stride=1, padding=1), nn.Flatten(),
+                              nn.Linear(15, 3))
+        X, y, lossf, loss = torch.rand(3, 2, 9), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "zeropad_ce":  # SqrtGGNZeroPad2d (__init__.py:110-112): the transposed Jacobian is a crop
+        model = nn.Sequential(nn.ZeroPad2d((1, 0, 2, 1)), nn.Conv2d(2, 2, 3), nn.Sigmoid(), nn.Flatten(), nn.Linear(30, 3))
+        X, y, lossf, loss = torch.rand(3, 2, 4, 4), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
     return model, X, y, lossf, loss
 
 
-PROBLEMS = ["mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce", "branching_ce", "resblock_ce",
+PROBLEMS = ["pool1d_ce", "zeropad_ce", "mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce", "branching_ce", "resblock_ce",
             "conv1d_mse", "conv3d_ce", "convtranspose_ce"]
 
 

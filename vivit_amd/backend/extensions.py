@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from vivit_amd import _lib, kernels
-from vivit_amd.backend.custom_module import SumModule
+from vivit_amd.backend.custom_module import Pad, Slicing, SumModule
 from vivit_amd.utils.ggn import Vmp
 from vivit_amd.utils.gram import mVp, pairwise_dot
 
@@ -169,6 +169,10 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+def _single(v):
+    return v if isinstance(v, int) else tuple(v)[0]
+
+
 def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
     """The layer rules that have a HIP kernel (csrc/jacobians.hip): activations, Flatten / Identity / Dropout(eval),
     Max/AvgPool2d, Conv2d / Conv1d (groups = 1, zero padding), BatchNorm (eval).  ``None``: no kernel for this module
@@ -178,6 +182,35 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
         return kernels.act_jac_t(M, x, kind[0], getattr(module, kind[1]) if kind[1] else 0.0)
     if isinstance(module, (nn.Flatten, nn.Identity, nn.Dropout)):
         return M.reshape(M.shape[0], *x.shape)
+    # index modules: the transposed Jacobian of a zero / constant padding is a crop, that of a slicing a scatter into zeros
+    # (SqrtGGNPad / SqrtGGNZeroPad2d / SqrtGGNSlicing, __init__.py:110-117) -- no recomputed forward, no autograd
+    if isinstance(module, (Pad, nn.ZeroPad2d)):
+        pad = tuple(module.padding) if isinstance(module, nn.ZeroPad2d) else tuple(module.pad)
+        mode = "constant" if isinstance(module, nn.ZeroPad2d) else module.mode
+        if mode == "constant" and len(pad) % 2 == 0 and all(p_ >= 0 for p_ in pad) and len(pad) // 2 <= x.dim():
+            g = M
+            for i in range(len(pad) // 2):          # F.pad: the last dimension first
+                d = g.dim() - 1 - i
+                g = g.narrow(d, pad[2 * i], g.shape[d] - pad[2 * i] - pad[2 * i + 1])
+            return g.contiguous()
+    if isinstance(module, Slicing):
+        g = M.new_zeros((M.shape[0],) + tuple(x.shape))
+        info = module.slice_info if isinstance(module.slice_info, tuple) else (module.slice_info,)
+        g[(slice(None),) + tuple(info)] = M
+        return g
+    # one-dimensional pooling on the two-dimensional kernels (a row image), as the Conv1d rules do
+    if isinstance(module, nn.MaxPool1d) and x.dim() == 3:
+        if _single(module.dilation) == 1 and not module.ceil_mode and not module.return_indices:
+            ks = _single(module.kernel_size)
+            st = _single(module.stride if module.stride is not None else ks)
+            g = kernels.maxpool2d_jac_t(M.unsqueeze(3), x.unsqueeze(2), (1, ks), (1, st), (0, _single(module.padding)))
+            return g.squeeze(3)
+    if isinstance(module, nn.AvgPool1d) and x.dim() == 3:
+        if not module.ceil_mode and module.count_include_pad:
+            ks = _single(module.kernel_size)
+            st = _single(module.stride if module.stride is not None else ks)
+            g = kernels.avgpool2d_jac_t(M.unsqueeze(3), (1, x.shape[2]), (1, ks), (1, st), (0, _single(module.padding)))
+            return g.squeeze(3)
     if isinstance(module, nn.MaxPool2d) and x.dim() == 4:
         if _pair(module.dilation) == (1, 1) and not module.ceil_mode and not module.return_indices:
             ks = _pair(module.kernel_size)

@@ -21,7 +21,10 @@
 // 1 KB -- [lane][8 bf16] exactly as the MFMA wants them, in consumption order, three pieces each -- so a block's image is
 // 78 global -> LDS DMA instructions (no VALU, no registers) into one of two LDS buffers while the previous block
 // computes, and an A operand is ONE conflict-free ds_read_b128.  Structurally zero 16 x 32 tiles of the parallelogram V
-// and of the trapezoid T V are skipped: 26 tile steps x 6 = 156 MFMAs per block and wave.
+// and of the trapezoid T V are skipped: 26 tile steps x 6 = 156 MFMAs per block and wave.  Two loader waves per workgroup
+// request the images; the compute waves (up to ten, 16 rows each) never wait for a request of their own.  Slabs are
+// independent, so there is no synchronisation between workgroups at all: any number of them may be resident.
+// Measured at n = 40 960: 1.15 - 1.2 s against 1.66 s for q2apply.hip, matrix pipe busy 56 %.
 #include <cstdlib>
 #include <type_traits>
 
@@ -31,32 +34,20 @@
 
 namespace vivit {
 
-// QS_VAR (timing-only builds, wrong results; scripts/probe/q2_variants.sh): 1 no arithmetic (DMA, barriers and Zt traffic
-// only), 2 no image DMA, 3 no DMA and no barriers, 4 no Zt loads / stores, 5 no split arithmetic, 6 no LDS fragment reads,
-// 7 = 3 + 4, 8 = 5 + 6 + 7 (MFMAs only)
+// QS_VAR: timing-only builds (WRONG results; scripts/probe/q2_variants.sh builds them as separate libraries) that leave one
+// ingredient out -- 1 no arithmetic (images, barriers and Zt traffic only), 2 no image requests by the compute waves, 3 no
+// image requests and no barriers, 4 no Zt loads / stores, 5 no split arithmetic, 6 no LDS fragment reads, 7 = 3 + 4,
+// 8 = 5 + 6 + 7, 9 no Zt loads, 10 no Zt stores.  (Mind what hipcc removes with them: without the final store of a unit
+// the MFMAs that only feed it go as well.)
 #ifndef QS_VAR
 #define QS_VAR 0
 #endif
-#if QS_VAR == 9      // timing only: no Zt loads (stores stay)
-#define QS_NO_SYNC 0
-#define QS_NO_ZT 0
+#define QS_NO_SYNC (QS_VAR == 3 || QS_VAR == 7 || QS_VAR == 8)
+#define QS_NO_ZT (QS_VAR == 4 || QS_VAR == 7 || QS_VAR == 8)
+#if QS_VAR == 9
 #define QS_NO_ZLOAD 1
-#elif QS_VAR == 10   // timing only: no Zt stores (loads stay)
-#define QS_NO_SYNC 0
-#define QS_NO_ZT 0
+#elif QS_VAR == 10
 #define QS_NO_ZSTORE 1
-#elif QS_VAR == 7 || QS_VAR == 8
-#define QS_NO_SYNC 1
-#define QS_NO_ZT 1
-#elif QS_VAR == 3
-#define QS_NO_SYNC 1
-#define QS_NO_ZT 0
-#elif QS_VAR == 4
-#define QS_NO_SYNC 0
-#define QS_NO_ZT 1
-#else
-#define QS_NO_SYNC 0
-#define QS_NO_ZT 0
 #endif
 
 typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
@@ -327,8 +318,6 @@ struct QsArgs {
 typedef const __attribute__((address_space(3))) unsigned char *qs_lds_ptr;
 typedef const __attribute__((address_space(3))) qbf16x8 *qs_lds_frag;
 
-// QS_VAR (timing-only builds, wrong results; scripts/probe/q2_variants.sh): 1 no arithmetic (DMA, barriers and Zt traffic
-// only), 2 no image DMA, 3 no DMA and no barriers, 4 no Zt loads / stores
 
 // the 26 tile steps of a block in walk order: steps 0..13 form W2^T (ks outer, t'-tile inner), 14..25 form U^T (w-tile
 // outer, kt inner).  Compile-time tables (every index below is a constant after unrolling).

@@ -816,7 +816,7 @@ constexpr int GEMM256BX_LDS_BYTES = 3 * BX_STAGE;
 #define BX_PATCH_OFFSET (3 * BX_STAGE)
 constexpr int GEMM256BX_LDS_BYTES = 3 * BX_STAGE + 4 * 4096;
 #endif
-constexpr int GEMM256BX_LDS_BYTES_UNUSED = 0;  // three stages (144 KB) + a 32 x 32 flush patch per wave = 160 KB
+// (three stages of 48 KB + a 32 x 32 flush patch per wave = 160 KB)
 
 __device__ __forceinline__ void bx_split2(float a, float b, unsigned &hi, unsigned &mid, unsigned &lo) {
   const bf16x2 h = {(__bf16)a, (__bf16)b};

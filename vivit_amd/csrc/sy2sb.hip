@@ -814,7 +814,7 @@ int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_ou
     int np = 0;            // panels of this group done so far
     int64_t gi_last = 0;   // first row/column of the trailing matrix after the group's last panel
     for (; np < SGRP && j0 + SNB < n; ++np, j0 += SNB) {
-      const int64_t mp = n - j0 - SNB, gi = j0 + SNB;
+      const int64_t gi = j0 + SNB;
       const int64_t kp = (int64_t)2 * SNB * np;  // stack rows of the pending updates
       if (np > 0) {
         // pending updates on the block column that becomes this panel: rows gi - SNB .., columns gi - SNB .. gi - 1

@@ -402,7 +402,7 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
     Algorithmic work per stage: band reduction (4/3) n^3 flop on MFMA; bulge chasing: n^2/(2 nb)
     tasks that each read and write two nb x nb blocks; the two back-transformations 2 n^3 flop each on MFMA."""
     names = {1: "prepare (scale scan + mirror)", 2: "sy2sb (full -> band): panel QR + panel-local products",
-             9: "sy2sb: streaming panel products P^T = V^T A22 (fp32 MFMA)",
+             9: "sy2sb: streaming panel products P^T = V^T A22",
              10: "sy2sb: delayed rank-1024 trailing updates (bf16 pipe)",
              3: "sb2st (band -> tridiagonal, bulge chasing)",
              4: "tridiagonal eigenproblem (divide & conquer | multisection)", 5: "Q2 back-transformation",
@@ -410,12 +410,15 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
     # (csrc/q2slide.hip:q2_slide_ok: the sliding-window kernel takes over when this many eigenvector rows are transformed)
     q2_bf16 = (bool(split) and n * row_frac >= int(os.environ.get("VIVIT_Q2_SLIDE_MIN_ROWS", "14336"))
                and os.environ.get("VIVIT_Q2_SLIDE", "1") != "0" and n % 4 == 0)
+    # (csrc/gemm_f32.hip:gemm64_bx_enabled: the 64-row streaming product on the bf16 pipe, then bound by the HBM stream)
+    g64_bf16 = bool(split) and os.environ.get("VIVIT_GEMM64_BX", "1") != "0"
     nb = 64
     n3 = float(n) ** 3
     work = {
         1: ("hbm", 4.0 * n * n * 1.5, "B"),
         2: (None, None, None),   # launch chains and 64-wide products: seconds only
-        9: ("mfma", 2.0 / 3.0 * n3, "flop"),
+        # every panel reads its trailing matrix once: 4 B x sum_p m_p^2 = n^3 / 48 bytes, 2 x 64 flop per element
+        9: ("hbm", n3 / 48.0, "B") if g64_bf16 else ("mfma", 2.0 / 3.0 * n3, "flop"),
         10: ("mfma", 2.0 / 3.0 * n3, "flop"),
         3: ("hbm", (n * n / (2.0 * nb)) * 4 * nb * nb * 4.0, "B"),
         4: (None, None, None),  # spectrum dependent (deflation): seconds only
@@ -438,7 +441,7 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
             ach = amount / sec / 1e12
             # each stage against the pipe it runs on: Q1's products, the band reduction's trailing updates and the
             # sliding-window Q2 kernel form fp32 products from exact bf16 splits (roofline = bf16 peak / split); the band
-            # reduction's streaming panel product and the block-step Q2 kernels are fp32 MFMA kernels
+            # reduction's streaming panel product (VIVIT_GEMM64_BX=0) and the block-step Q2 kernels are fp32 MFMA kernels
             on_bf16 = split and (k in (6, 10) or (k == 5 and q2_bf16))
             peak = MFMA_BF16_PEAK_TF / split if on_bf16 else MFMA_F32_PEAK_TF
             row["pipe"] = f"bf16 MFMA, {split} partial products per fp32 product" if on_bf16 else "fp32 MFMA"
@@ -446,6 +449,10 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
         elif bound == "hbm":
             ach = amount / sec / 1e9
             row.update({"bytes": amount, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
+            if k == 9:   # the same seconds against the matrix pipe it runs on
+                tf = 2.0 / 3.0 * n3 / sec / 1e12
+                row.update({"pipe": f"bf16 MFMA, {split} partial products per fp32 product", "flops": 2.0 / 3.0 * n3,
+                            "mfma_tflops": tf, "mfma_frac": tf / (MFMA_BF16_PEAK_TF / split)})
         out.append(row)
     return out
 

@@ -19,7 +19,9 @@ def _rel(a, b):
     [(1, 1, 1), (5, 7, 3), (128, 128, 16), (130, 250, 37), (64, 300, 1000), (257, 129, 515), (10, 10, 5000), (300, 300, 70000),
      (64, 1024, 4096), (33, 515, 129), (64, 2051, 20000), (17, 260, 64),
      # 64-row streaming kernel (gemm64_dma_kernel): N, K >= 2048, K % 16 == 0; ragged N, M < 64, deep K (splits)
-     (64, 2048, 2048), (36, 2100, 6400), (4, 4096, 40000), (64, 2304, 33 * 1024)],
+     (64, 2048, 2048), (36, 2100, 6400), (4, 4096, 40000), (64, 2304, 33 * 1024),
+     # its bf16-pipe form (gemm64_bx_kernel): an odd number of K tiles per split, a chain boundary (2048 k) plus one tile
+     (64, 2048, 2064), (60, 2560, 3 * 2048 + 16)],
 )
 def test_gemm_variants(m, n, k):
     from vivit_amd import kernels

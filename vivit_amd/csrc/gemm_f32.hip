@@ -1492,6 +1492,9 @@ __global__ __launch_bounds__(256, 1) void gemm64_dma_kernel(GemmArgs p) {
 
   float fa[2][2][4], fb[2][2][4];  // [half parity][tile][k pair]
   auto frags = [&](int st, int q, int par) __attribute__((always_inline)) {
+#if defined(G64_VAR) && G64_VAR >= 2   // timing-only: no LDS reads either (the DMA stream and the barriers alone)
+    return;
+#endif
     const float *sa = smem3 + st * G64_STG, *sb = sa + G64_TA;
 #pragma unroll
     for (int i = 0; i < 2; ++i) frag_half<ALAY, 64>(sa, i * 32 + r, q, h, fa[par][i]);
@@ -1499,6 +1502,12 @@ __global__ __launch_bounds__(256, 1) void gemm64_dma_kernel(GemmArgs p) {
     for (int j = 0; j < 2; ++j) frag_half<BLAY, 256>(sb, wave * 64 + j * 32 + r, q, h, fb[par][j]);
   };
   auto mfma_half = [&](int par) __attribute__((always_inline)) {
+#if defined(G64_VAR) && G64_VAR >= 1   // timing-only builds (scripts/probe/variants.sh): no products, fragments kept alive
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) __asm__ volatile("" ::"v"(fa[par][i][tt]), "v"(fb[par][i][tt]));
+#else
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -1506,6 +1515,7 @@ __global__ __launch_bounds__(256, 1) void gemm64_dma_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][i][tt], fb[par][j][tt], acc[i][j], 0, 0, 0);
+#endif
   };
 
   // DMA sources: wave w moves block w of the A tile and blocks w, w+4, w+8, w+12 of the B tile
@@ -1569,6 +1579,222 @@ __global__ __launch_bounds__(256, 1) void gemm64_dma_kernel(GemmArgs p) {
     flush_to_c(first_flush);
     first_flush = false;
   }
+}
+
+// ---- The same 64-row streaming product on the bf16 pipe (round 4).
+// The fp32 kernel above is bound by its own MFMAs (32 of 64 cycles per K tile and wave: 2.1 ms for 64 x 40960 x 40960
+// where the DMA stream alone takes 1.1 ms, scripts/probe/panel_product.py with the G64_VAR builds).  Here every product is
+// six v_mfma_f32_32x32x16_bf16 on exact three-way bf16 splits (24 MFMAs of 32 cycles per K tile and wave):
+//   * the small operand A (64 x K, read by every workgroup) is split ONCE by g64_split_a_kernel into the fragment
+//     order of the MFMA -- per K tile [row tile 2][piece 3][lane 64][8 bf16] = 6 KB -- and streamed by DMA like B;
+//   * the big operand B (K x N or N x K, fp32, read exactly once from HBM) is split in registers by the wave that
+//     multiplies it: 16 values per lane and K tile (~100 VALU instructions), issued between the MFMAs of the PREVIOUS
+//     tile (pieces are double-buffered in registers; one wave per SIMD owns the SIMD's 512 registers).
+// Splitting both operands in registers was measured too: ~200 VALU instructions per tile do not fit the MFMA gaps
+// (1.88 ms).  Element j of a lane's eight values of a K tile is k = 8 (j >> 2) + 4 h + (j & 3) for both operands (the order
+// frag_half delivers B in), which is all a 16-deep MFMA needs.  One DMA stream runs over the whole K range of the
+// workgroup; accumulation chains are closed in registers every 2048 k (the MFMA's truncating accumulator: see
+// bx_chain_tiles) and C or the split-K slab is written once.
+constexpr int G64X_NST = 7;
+constexpr int G64X_TA = 6 * 1024 / 4;                 // floats: the A pieces of one K tile (6 KB)
+constexpr int G64X_STG = G64X_TA + G64_TB;            // 22 KB per stage
+constexpr int GEMM64X_LDS_BYTES = G64X_NST * G64X_STG * 4;  // 154 KB
+constexpr int G64X_CHAIN = 2048 / BK;
+
+// this lane's K index inside a K tile for element j of its MFMA fragment
+__device__ __forceinline__ int g64x_k(int h, int j) { return 8 * (j >> 2) + 4 * h + (j & 3); }
+
+template <int ALAY>
+__global__ __launch_bounds__(128) void g64_split_a_kernel(const float *__restrict__ A, int64_t lda, int64_t M, uint4 *__restrict__ out) {
+  const int64_t kt = blockIdx.x;
+  const int i = threadIdx.x >> 6, l = threadIdx.x & 63, h = l >> 5;
+  const int64_t row = 32 * i + (l & 31);
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t k = kt * BK + g64x_k(h, j);
+    f[j] = row < M ? (ALAY == LAY_K ? A[row * lda + k] : A[k * lda + row]) : 0.f;
+  }
+  unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) bx_split2(f[2 * u], f[2 * u + 1], hh[u], mm[u], ll[u]);
+  uint4 *o = out + (kt * 6 + i * 3) * 64 + l;
+  o[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+  o[64] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+  o[128] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+}
+
+template <int BLAY>
+__global__ __launch_bounds__(256, 1) void gemm64_bx_kernel(GemmArgs p, const uint4 *__restrict__ apieces) {
+  extern __shared__ __attribute__((aligned(16))) float smem3[];
+  const int tj = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t col0 = (int64_t)tj * 256;
+  const int64_t kbeg = (int64_t)blockIdx.y * p.kchunk;
+  const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
+  const int nt = (int)((kend - kbeg) / BK);  // K and kchunk are multiples of 16 (host)
+
+  f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f, tot[i][j][e] = 0.f;
+
+  // DMA sources: wave w moves bytes [1536 w, 1536 w + 1536) of the A pieces (one full and one half-wave request) and
+  // blocks w, w+4, w+8, w+12 of the B tile
+  gcptr srcA = (gcptr)(reinterpret_cast<const char *>(apieces) + (kbeg / BK) * 6144 + wave * 1536 + lane * 16);
+  gcptr srcB[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    srcB[u] = dma_src<BLAY, 256>(p.B, p.ldb, col0, p.N, wave + 4 * u, lane) + (BLAY == LAY_K ? kbeg : kbeg * p.ldb);
+  const int64_t stepB = (BLAY == LAY_K) ? BK : (int64_t)BK * p.ldb;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem3;
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * 1536)),
+                 ldsB = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(G64X_TA * 4 + wave * 1024));
+  auto issue = [&](int st) __attribute__((always_inline)) {   // 6 requests per wave
+    const unsigned so = (unsigned)(st * G64X_STG * 4);
+    dma16(srcA, ldsA + so);
+    if (lane < 32) dma16(srcA + 256, ldsA + so + 1024);   // (+256 floats = 1 KB; counted by vmcnt whatever the exec mask)
+    srcA += 6144 / 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      dma16(srcB[u], ldsB + so + (unsigned)(4 * u * 1024));
+      srcB[u] += stepB;
+    }
+  };
+
+  struct P3 { bf16x8 h, m, l; };
+  P3 pa[2][2], pb[2][2];   // [tile parity][row / column tile]
+  float raw[2][8];         // the next K tile's B fragments as read from LDS (columns 0-31, 32-63 of the wave's 64)
+  auto read_next = [&](int st, int par) __attribute__((always_inline)) {
+    const float *sa = smem3 + st * G64X_STG, *sb = sa + G64X_TA;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16x8 *q = reinterpret_cast<const bf16x8 *>(sa) + (i * 3) * 64 + lane;
+      pa[par][i].h = q[0];
+      pa[par][i].m = q[64];
+      pa[par][i].l = q[128];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      frag_half<BLAY, 256>(sb, wave * 64 + j * 32 + r, 0, h, *reinterpret_cast<float(*)[4]>(&raw[j][0]));
+      frag_half<BLAY, 256>(sb, wave * 64 + j * 32 + r, 1, h, *reinterpret_cast<float(*)[4]>(&raw[j][4]));
+    }
+  };
+  auto split_raw = [&](int par) __attribute__((always_inline)) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      unsigned hh[4], mm[4], ll[4];
+#if defined(G64_VAR) && G64_VAR == 4   // timing-only: the products without the split
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hh[u] = __float_as_uint(raw[j][u]), mm[u] = __float_as_uint(raw[j][4 + u]), ll[u] = hh[u] ^ mm[u];
+#else
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bx_split2(raw[j][2 * u], raw[j][2 * u + 1], hh[u], mm[u], ll[u]);
+#endif
+      pb[par][j].h = __builtin_bit_cast(bf16x8, (u32x4){hh[0], hh[1], hh[2], hh[3]});
+      pb[par][j].m = __builtin_bit_cast(bf16x8, (u32x4){mm[0], mm[1], mm[2], mm[3]});
+      pb[par][j].l = __builtin_bit_cast(bf16x8, (u32x4){ll[0], ll[1], ll[2], ll[3]});
+    }
+  };
+  auto mfma_bx = [&](int par) __attribute__((always_inline)) {
+    // six partial products per output tile, smallest first; the four tiles' chains interleaved
+#define G64_BX4(PA, PB)                                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =             \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[par][i].PA, pb[par][j].PB, acc[i][j], 0, 0, 0);
+#if defined(G64_VAR) && G64_VAR == 3   // timing-only: the split without the products
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) __asm__ volatile("" ::"v"(pa[par][i].h), "v"(pa[par][i].m), "v"(pa[par][i].l),
+                                                                   "v"(pb[par][i].h), "v"(pb[par][i].m), "v"(pb[par][i].l));
+#else
+    G64_BX4(l, h) G64_BX4(h, l) G64_BX4(m, m) G64_BX4(m, h) G64_BX4(h, m) G64_BX4(h, h)
+#endif
+#undef G64_BX4
+  };
+
+  int issued = 0, ist = 0;   // tiles requested so far; the stage the next request goes to
+  for (; issued < nt && issued < G64X_NST - 1; ++issued, ++ist) issue(ist);
+  if (issued == G64X_NST - 1) __asm__ volatile("s_waitcnt vmcnt(30)" ::: "memory");  // (NST-2) * 6: tile 0 landed
+  else __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  read_next(0, 0);
+  split_raw(0);
+  int t = 0, st1 = 1;
+  // tile t: its pieces are in registers (parity par); tile t+1 is read from LDS and split while tile t's 24 MFMAs run
+  auto step = [&](int par) __attribute__((always_inline)) {
+    if (issued < nt) {
+      // own part of tile t+1 landed: tiles t+2 .. t+NST-2 (NST-3 of them) may still be in flight
+      __asm__ volatile("s_waitcnt vmcnt(24)" ::: "memory");
+#if !(defined(G64_VAR) && G64_VAR == 5)   // timing-only 5: no requests after the first NST-1 tiles
+      issue(ist);  // tile t+NST-1 into the stage tile t-1 has left (its LDS reads ended before the previous barrier)
+#endif
+      ++issued;
+      ist = ist + 1 == G64X_NST ? 0 : ist + 1;
+    } else {
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();           // every wave's part of tile t+1 is in LDS
+    read_next(st1, par ^ 1);   // (after the last tile: a stale stage, the values are not used)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_bx(par);
+    split_raw(par ^ 1);
+    // (an empty use, so that the split stays in this block: the compiler sinks it into the next step's otherwise)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __asm__ volatile("" : "+v"(pb[par ^ 1][j].h), "+v"(pb[par ^ 1][j].m), "+v"(pb[par ^ 1][j].l));
+    // the split's ~100 VALU instructions between the MFMAs: 4 MFMAs first (the LDS reads are on their way), then 5 : 1
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+    for (int u = 0; u < 20; ++u) {
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ++t;
+    st1 = st1 + 1 == G64X_NST ? 0 : st1 + 1;
+  };
+  static_assert(G64X_CHAIN % 2 == 0, "chains hold whole pairs of tiles (the register parity of the pieces)");
+  while (t < nt) {
+    const int len = nt - t < G64X_CHAIN ? nt - t : G64X_CHAIN;   // this chain; only the last one can be odd
+    for (int c = 0; c < len / 2; ++c) {
+      step(0);
+      step(1);
+    }
+    if (len & 1) step(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)   // close the chain in registers
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          tot[i][j][e] += acc[i][j][e];
+          acc[i][j][e] = 0.f;
+        }
+  }
+
+  const bool partial = p.ksplit > 1;
+  gptr Cout = (gptr)(partial ? p.slab + (int64_t)blockIdx.y * p.M * p.N : p.C);
+  const int64_t ldc = partial ? p.N : p.ldc;
+  const float alpha = partial ? 1.f : p.alpha, beta = partial ? 0.f : p.beta;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = col0 + wave * 64 + j * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < p.M && col < p.N) {
+          gptr c = Cout + row * ldc + col;
+          float v = alpha * tot[i][j][e];
+          if (beta != 0.f) v += beta * *c;
+          *c = v;
+        }
+      }
+    }
 }
 
 // C = alpha * sum_z slab[z] + beta * C  (fixed summation order); SYRK slabs hold the lower
@@ -1790,7 +2016,7 @@ static void choose_split(int64_t M, int64_t N, int64_t K, bool syrk, int &ksplit
   }
 }
 
-static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out);
+static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out, size_t *slab_out = nullptr);
 static bool gemm256_plan(int64_t M, int64_t N, int64_t K, bool syrk, int *ksplit_out, int64_t *kchunk_out, int max_split = 32);
 
 static int gemm_split_mode();
@@ -2255,7 +2481,18 @@ static bool use_gemm64(int alay, int blay, const float *A, const float *B, int64
   return vec && M <= 64 && N >= 2048 && K >= 2048 && (K % BK) == 0;
 }
 
-static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out) {
+// products of the 64-row streaming kernel on the bf16 pipe (exact three-way splits) unless the fp32 pipe is asked for
+// (VIVIT_GEMM_SPLIT=0 or VIVIT_GEMM64_BX=0)
+static bool gemm64_bx_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("VIVIT_GEMM64_BX");
+    on = (e ? atoi(e) != 0 : true) && gemm_split_mode() != 0;
+  }
+  return on != 0;
+}
+
+static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *ksplit_out, int64_t *kchunk_out, size_t *slab_out) {
   const int64_t tiles = cdiv(N, 256), ktiles = K / BK;
   // one workgroup per CU: pick the split count (>= 2 rounds of work, every split >= 64 K tiles) whose last
   // round of 256 workgroups is fullest
@@ -2272,7 +2509,10 @@ static size_t gemm64_workspace_bytes(int64_t M, int64_t N, int64_t K, int *kspli
   const int ksplit = (int)cdiv(K, kchunk);
   if (ksplit_out) *ksplit_out = ksplit;
   if (kchunk_out) *kchunk_out = kchunk;
-  return ksplit > 1 ? (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) : 0;
+  const size_t slab = ksplit > 1 ? (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) : 0;
+  if (slab_out) *slab_out = slab;
+  // + the bf16 pieces of the 64-row operand (gemm64_bx_kernel): 6 KB per K tile, after the slab
+  return gemm64_bx_enabled() ? align_up(slab, 256) + (size_t)ktiles * 6144 : slab;
 }
 
 static int gemm64_launch(int alay, int blay, GemmArgs p, void *workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -2285,23 +2525,41 @@ static int gemm64_launch(int alay, int blay, GemmArgs p, void *workspace, size_t
                             reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_K, LAY_M>),
                             reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_M, LAY_K>),
                             reinterpret_cast<const void *>(gemm64_dma_kernel<LAY_M, LAY_M>)};
-      for (const void *f : fns)
-        if (!ensure_dynamic_lds(f, GEMM64_LDS_BYTES, attr_done)) return VIVIT_E_LAUNCH;
+      for (int f = 0; f < 4; ++f)
+        if (!ensure_dynamic_lds(fns[f], GEMM64_LDS_BYTES, attr_done)) return VIVIT_E_LAUNCH;
+      if (!ensure_dynamic_lds(reinterpret_cast<const void *>(gemm64_bx_kernel<LAY_K>), GEMM64X_LDS_BYTES, attr_done) ||
+          !ensure_dynamic_lds(reinterpret_cast<const void *>(gemm64_bx_kernel<LAY_M>), GEMM64X_LDS_BYTES, attr_done))
+        return VIVIT_E_LAUNCH;
       attr_done |= 1ull << (dev & 63);
     }
   }
-  const size_t need = gemm64_workspace_bytes(p.M, p.N, p.K, &p.ksplit, &p.kchunk);
+  size_t slab_bytes = 0;
+  const size_t need = gemm64_workspace_bytes(p.M, p.N, p.K, &p.ksplit, &p.kchunk, &slab_bytes);
   p.slab = nullptr;
   if (p.ksplit > 1) {
-    if (!workspace || workspace_bytes < need) return VIVIT_E_WORKSPACE;
+    if (!workspace || workspace_bytes < slab_bytes) return VIVIT_E_WORKSPACE;
     p.slab = static_cast<float *>(workspace);
   }
+  // the bf16-pipe form needs room for the pieces of A behind the slab; without it the fp32 form runs
+  uint4 *apieces = nullptr;
+  if (gemm64_bx_enabled() && workspace && workspace_bytes >= need)
+    apieces = reinterpret_cast<uint4 *>(static_cast<char *>(workspace) + align_up(slab_bytes, 256));
   p.tiles_m = 1;
   p.tiles_n = (int)cdiv(p.N, 256);
   p.syrk = 0;
   p.desc = nullptr;
   dim3 grid((unsigned)p.tiles_n, (unsigned)p.ksplit, 1);
-  if (alay == LAY_K && blay == LAY_K)
+  if (apieces) {   // products on the bf16 pipe: split the 64-row operand once, then stream
+    if (alay == LAY_K)
+      g64_split_a_kernel<LAY_K><<<(unsigned)(p.K / BK), 128, 0, stream>>>(p.A, p.lda, p.M, apieces);
+    else
+      g64_split_a_kernel<LAY_M><<<(unsigned)(p.K / BK), 128, 0, stream>>>(p.A, p.lda, p.M, apieces);
+    if (blay == LAY_K)
+      gemm64_bx_kernel<LAY_K><<<grid, 256, GEMM64X_LDS_BYTES, stream>>>(p, apieces);
+    else
+      gemm64_bx_kernel<LAY_M><<<grid, 256, GEMM64X_LDS_BYTES, stream>>>(p, apieces);
+  }
+  else if (alay == LAY_K && blay == LAY_K)
     gemm64_dma_kernel<LAY_K, LAY_K><<<grid, 256, GEMM64_LDS_BYTES, stream>>>(p);
   else if (alay == LAY_K && blay == LAY_M)
     gemm64_dma_kernel<LAY_K, LAY_M><<<grid, 256, GEMM64_LDS_BYTES, stream>>>(p);

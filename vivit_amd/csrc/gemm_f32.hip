@@ -1693,6 +1693,8 @@ __global__ __launch_bounds__(256, 1) void gemm64_bx_kernel(GemmArgs p, const uin
 #pragma unroll
       for (int u = 0; u < 4; ++u) hh[u] = __float_as_uint(raw[j][u]), mm[u] = __float_as_uint(raw[j][4 + u]), ll[u] = hh[u] ^ mm[u];
 #else
+      // (13 instructions per pair as hipcc compiles it; a 9-instruction form -- packed subtractions in inline asm, the
+      // packed conversion hidden from the optimiser -- ran 7 % SLOWER on the same box: hazard s_nops around the asm)
 #pragma unroll
       for (int u = 0; u < 4; ++u) bx_split2(raw[j][2 * u], raw[j][2 * u + 1], hh[u], mm[u], ll[u]);
 #endif

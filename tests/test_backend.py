@@ -106,10 +106,14 @@ def make_problem(name):
     elif name == "zeropad_ce":  # SqrtGGNZeroPad2d (__init__.py:110-112): the transposed Jacobian is a crop
         model = nn.Sequential(nn.ZeroPad2d((1, 0, 2, 1)), nn.Conv2d(2, 2, 3), nn.Sigmoid(), nn.Flatten(), nn.Linear(30, 3))
         X, y, lossf, loss = torch.rand(3, 2, 4, 4), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "grouped_ce":  # grouped Conv2d / ConvTranspose2d / Conv1d weight rules on the HIP kernel, one launch per group
+        model = nn.Sequential(nn.Conv2d(4, 4, 2, groups=2), nn.ReLU(), nn.ConvTranspose2d(4, 2, 2, stride=2, groups=2), nn.Tanh(),
+                              nn.Flatten(2), nn.Conv1d(2, 4, 3, stride=2, groups=2), nn.Flatten(), nn.Linear(28, 3))
+        X, y, lossf, loss = torch.rand(3, 4, 3, 3), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
     return model, X, y, lossf, loss
 
 
-PROBLEMS = ["pool1d_ce", "zeropad_ce", "mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce", "branching_ce", "resblock_ce",
+PROBLEMS = ["grouped_ce", "pool1d_ce", "zeropad_ce", "mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce", "branching_ce", "resblock_ce",
             "conv1d_mse", "conv3d_ce", "convtranspose_ce"]
 
 
@@ -140,6 +144,31 @@ def test_sqrt_ggn_and_batch_grad_factors(problem, subsampling, device):
     for p, v, g in zip(model.parameters(), V_ref, g_ref):
         close(p.sqrt_ggn_exact, v, rtol=1e-4, atol=1e-6)
         close(p.grad_batch, g, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem", ["grouped_ce", "linear_extra_mse", "convtranspose_ce", "conv1d_mse", "cnn_ce"])
+def test_weight_rules_run_on_the_hip_kernels(problem, monkeypatch):
+    """The weight rules of Linear with extra input dimensions, of grouped and of transposed 1-D / 2-D convolutions are
+    launches of the HIP kernels: the torch.func.vmap / einsum rules must not be reached on the GPU."""
+    from vivit_amd.backend import extensions as ext
+
+    def forbidden(*a, **k):
+        raise AssertionError("fell back to the torch rule")
+
+    set_kernel_backend(None)
+    dev = torch.device("cuda:0")
+    model, X, y, lossf, loss = make_problem(problem)
+    ref_model = make_problem(problem)[0]
+    S = oracle.loss_hessian_sqrt_exact(ref_model(X).detach(), loss)
+    V_ref = oracle.sqrt_ggn_factors(ref_model, X, S, None)
+    model, X, y = model.to(dev), X.to(dev), y.to(dev)
+    monkeypatch.setattr(ext, "_conv_weight_factor", forbidden)
+    monkeypatch.setattr(torch, "einsum", forbidden)
+    run_backward(model, X, y, lossf, [SqrtGGNExact()])
+    monkeypatch.undo()
+    for p, v in zip(model.parameters(), V_ref):
+        close(p.sqrt_ggn_exact, v, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("problem", PROBLEMS)

@@ -60,6 +60,10 @@ class LinearFactor:
 
     def materialise(self) -> Tensor:
         """The explicit tensor (small problems / mixed representations only)."""
+        if self.s.is_cuda and self.s.dtype == torch.float32:   # the HIP store-stream kernel of the weight rule
+            if self.s.dim() == 2:
+                return kernels.linear_weight_mjp(self.s.unsqueeze(0), self.z)[0]
+            return kernels.linear_weight_mjp(self.s, self.z)
         if self.s.dim() == 2:
             return torch.einsum("no,ni->noi", self.s, self.z)
         return torch.einsum("cno,ni->cnoi", self.s, self.z)
@@ -99,21 +103,20 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
             return M if M.dim() == 3 else M.flatten(2, -2).sum(2)
         if M.dim() == 3:
             return kernels.linear_weight_mjp(M, x)           # "vno,ni->vnoi" (HIP store-stream kernel)
-        return torch.einsum("vnao,nai->vnoi", M.flatten(2, -2), x.flatten(1, -2))
+        Ma, xa = M.flatten(2, -2), x.flatten(1, -2)          # [V, N, A, O], [N, A, I]  (linear.py:52-81: extra dims are summed)
+        if M.is_cuda and M.dtype == torch.float32:
+            # a 1 x 1 convolution over the A positions: the HIP weight rule of the convolution, "vnoa,nia->vnoi"
+            out = kernels.conv2d_weight_mjp(Ma.transpose(2, 3).unsqueeze(3).contiguous(), xa.transpose(1, 2).unsqueeze(2).contiguous(),
+                                            (1, 1), (1, 1), (0, 0), (1, 1))
+            return out.reshape(out.shape[:4])
+        return torch.einsum("vnao,nai->vnoi", Ma, xa)
     if isinstance(module, _CONVS):
         if name == "bias":
             return _spatial_sum(M, 3)
-        if (isinstance(module, (nn.Conv2d, nn.Conv1d)) and module.groups == 1 and isinstance(module.padding, tuple)
-                and module.padding_mode == "zeros"):
-            # unfold + "vnol,nkl->vnok" in one HIP kernel (patch values gathered on the fly, no im2col buffer);
-            # a Conv1d is the Conv2d with one row
-            one_d = isinstance(module, nn.Conv1d)
+        if (M.is_cuda and M.dtype == torch.float32 and isinstance(module, (nn.Conv2d, nn.Conv1d, nn.ConvTranspose2d, nn.ConvTranspose1d))
+                and isinstance(module.padding, tuple) and module.padding_mode == "zeros"):
             try:
-                if one_d:
-                    out = kernels.conv2d_weight_mjp(M.unsqueeze(3), x.unsqueeze(2), (1, module.kernel_size[0]), (1, module.stride[0]),
-                                                    (0, module.padding[0]), (1, module.dilation[0]))
-                    return out.squeeze(4)
-                return kernels.conv2d_weight_mjp(M, x, module.kernel_size, module.stride, module.padding, module.dilation)
+                return _hip_conv_weight_factor(module, M, x)
             except _lib.VivitHipError as exc:  # shapes outside the kernel's launch limits: the torch rule below
                 if exc.status != _lib.VIVIT_E_UNSUPPORTED:
                     raise
@@ -137,6 +140,43 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
 
 _CONV_FN = {nn.Conv1d: F.conv1d, nn.Conv2d: F.conv2d, nn.Conv3d: F.conv3d, nn.ConvTranspose1d: F.conv_transpose1d,
             nn.ConvTranspose2d: F.conv_transpose2d, nn.ConvTranspose3d: F.conv_transpose3d}
+
+
+def _hip_conv_weight_factor(module, M: Tensor, x: Tensor) -> Tensor:
+    """Weight rule of Conv1d/2d and ConvTranspose1d/2d (any ``groups``, zero padding) on ONE HIP kernel
+    (csrc/jacobians.hip: unfold + "vnol,nkl->vnok", patch values gathered on the fly, no im2col buffer).
+
+    * a 1-D convolution is the 2-D one with a single row;
+    * ``groups > 1``: one launch per group on the group's channel slices (the weight's leading axis is the groups'
+      output channels one after the other -- convnd.py:9-30 through BackPACK's grouped unfold);
+    * a transposed convolution y = conv_transpose(x, W) is the adjoint of a convolution with the same stride / padding /
+      dilation, so dL/dW[ci, co, k] = sum_q x[ci, q] M[co, q s - p + k d] is the SAME contraction with the roles swapped:
+      ``M`` is the image the patches are gathered from, ``x`` the coefficient (convtransposend.py:9-30).  The kernel
+      gathers from the operand without a slice axis, so the slice axis of ``M`` is folded into the batch and ``x`` is
+      repeated over it."""
+    one_d = isinstance(module, (nn.Conv1d, nn.ConvTranspose1d))
+    transposed = isinstance(module, (nn.ConvTranspose1d, nn.ConvTranspose2d))
+    if one_d:
+        M, x = M.unsqueeze(3), x.unsqueeze(2)
+        ks, st, pd, dl = (1, module.kernel_size[0]), (1, module.stride[0]), (0, module.padding[0]), (1, module.dilation[0])
+    else:
+        ks, st, pd, dl = module.kernel_size, module.stride, module.padding, module.dilation
+    V, N, G = M.shape[0], M.shape[1], module.groups
+    if transposed:
+        coef = x.unsqueeze(0).expand(V, *x.shape).reshape(1, V * N, *x.shape[1:])     # [1, V N, Cin, Hq, Wq]
+        image = M.reshape(V * N, *M.shape[2:])                                         # [V N, Cout, H', W']
+    else:
+        coef, image = M, x
+    Cc, Ci = coef.shape[2] // G, image.shape[1] // G
+    parts = []
+    for g in range(G):
+        c = coef if G == 1 else coef[:, :, g * Cc:(g + 1) * Cc]
+        im = image if G == 1 else image[:, g * Ci:(g + 1) * Ci]
+        parts.append(kernels.conv2d_weight_mjp(c.contiguous(), im.contiguous(), ks, st, pd, dl))
+    out = parts[0] if G == 1 else torch.cat(parts, 2)     # [.., .., coefficient channels, image channels / G, kh, kw]
+    if transposed:
+        out = out.view(V, N, *out.shape[2:])
+    return out.squeeze(4) if one_d else out
 
 
 def _conv_weight_factor(module, M: Tensor, x: Tensor) -> Tensor:
@@ -220,15 +260,24 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
             ks = _pair(module.kernel_size)
             return kernels.avgpool2d_jac_t(M, x.shape[2:], ks, _pair(module.stride if module.stride is not None else ks),
                                            _pair(module.padding))
-    if (isinstance(module, nn.Conv2d) and module.groups == 1 and isinstance(module.padding, tuple)
-            and module.padding_mode == "zeros" and module.out_channels * module.kernel_size[0] * module.kernel_size[1] <= 1024):
-        return kernels.conv2d_jac_t(M, module.weight.detach(), x.shape[2:], module.stride, module.padding, module.dilation)
-    if (isinstance(module, nn.Conv1d) and module.groups == 1 and isinstance(module.padding, tuple)
-            and module.padding_mode == "zeros" and module.out_channels * module.kernel_size[0] <= 1024):
-        # a Conv1d is the Conv2d with one row: same kernel
-        g = kernels.conv2d_jac_t(M.unsqueeze(3), module.weight.detach().unsqueeze(2), (1, x.shape[2]), (1, module.stride[0]),
-                                 (0, module.padding[0]), (1, module.dilation[0]))
-        return g.squeeze(3)
+    if (isinstance(module, (nn.Conv2d, nn.Conv1d)) and isinstance(module.padding, tuple) and module.padding_mode == "zeros"
+            and module.out_channels // module.groups * math.prod(module.kernel_size) <= 1024):
+        # a Conv1d is the Conv2d with one row: same kernel; groups > 1: one launch per group on its channel slices
+        one_d = isinstance(module, nn.Conv1d)
+        W = module.weight.detach()
+        if one_d:
+            M, W, hw = M.unsqueeze(3), W.unsqueeze(2), (1, x.shape[2])
+            st, pd, dl = (1, module.stride[0]), (0, module.padding[0]), (1, module.dilation[0])
+        else:
+            hw, st, pd, dl = x.shape[2:], module.stride, module.padding, module.dilation
+        G = module.groups
+        Co = module.out_channels // G
+        if G == 1:
+            g = kernels.conv2d_jac_t(M, W, hw, st, pd, dl)
+        else:
+            g = torch.cat([kernels.conv2d_jac_t(M[:, :, i * Co:(i + 1) * Co].contiguous(), W[i * Co:(i + 1) * Co].contiguous(), hw, st, pd, dl)
+                           for i in range(G)], 2)
+        return g.squeeze(3) if one_d else g
     if isinstance(module, _BATCHNORM) and x.dim() >= 2:
         scale = torch.rsqrt(module.running_var + module.eps)
         if module.weight is not None:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 measurement pass on the GPU box (final code): the bench line, kernel-trace stats of the same command without the
-# extras, PMC passes (separate runs: FETCH_SIZE / WRITE_SIZE / matrix-pipe busy) for the Gram SYRK and for the
-# sliding-window Q2 kernel.  Outputs under gpurun_out/r04; copy what is to be kept into profiles/.
+# extras, PMC passes (separate runs: FETCH_SIZE / WRITE_SIZE / matrix-pipe busy) for the Gram SYRK, the
+# sliding-window Q2 kernel and the band reduction's streaming panel product.  Outputs under gpurun_out/r04; copy what is to be kept into profiles/.
 set -o pipefail
 export TMPDIR=/tmp
 R=$PWD
@@ -24,6 +24,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-include-regex "qs_apply" --kernel-trace -d $O/pmc_q2_mfma -o p --output-format csv -- python3 $R/scripts/probe/q2_time1.py 40960 1 > $O/pmc_q2_mfma.log 2>&1 || { tail -5 $O/pmc_q2_mfma.log; exit 1; }
 echo "q2 pmc done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-include-regex "gemm64_bx|g64_split" --kernel-trace -d $O/pmc_g64_$c -o p --output-format csv -- python3 $R/scripts/probe/panel_product1.py 40960 > $O/pmc_g64_$c.log 2>&1 || { tail -5 $O/pmc_g64_$c.log; exit 1; }
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-include-regex "gemm64_bx" --kernel-trace -d $O/pmc_g64_mfma -o p --output-format csv -- python3 $R/scripts/probe/panel_product1.py 40960 > $O/pmc_g64_mfma.log 2>&1 || { tail -5 $O/pmc_g64_mfma.log; exit 1; }
+echo "panel product pmc done"
 cd $R
 find $O -name "*_kernel_trace.csv" -size +2M -delete   # gpurun copies at most 64 MiB back
 find $O -name "*.csv" | head -40

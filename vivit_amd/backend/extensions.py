@@ -494,7 +494,7 @@ def _linear_weight_closures(s: Tensor, z: Tensor):
         return kernels.class_expand(s, U)
 
     def factor():  # the explicit V_t[c,n,o,i] = s[c,n,o] z[n,i]; only asked for when O*I is small
-        return torch.einsum("cno,ni->cnoi", s, z)
+        return LinearFactor(s, z).materialise()
 
     return {"V_mat_prod": V_mat_prod, "V_t_mat_prod": V_t_mat_prod, "gram_mat": gram_mat, "factor": factor,
             "shape_cn": (C, N), "dp_add": lambda acc: acc.add_linear(s, z)}

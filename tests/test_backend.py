@@ -149,8 +149,9 @@ def test_sqrt_ggn_and_batch_grad_factors(problem, subsampling, device):
 @pytest.mark.gpu
 @pytest.mark.parametrize("problem", ["grouped_ce", "linear_extra_mse", "convtranspose_ce", "conv1d_mse", "cnn_ce"])
 def test_weight_rules_run_on_the_hip_kernels(problem, monkeypatch):
-    """The weight rules of Linear with extra input dimensions, of grouped and of transposed 1-D / 2-D convolutions are
-    launches of the HIP kernels: the torch.func.vmap / einsum rules must not be reached on the GPU."""
+    """The weight rules of Linear with extra input dimensions, of grouped and of transposed 1-D / 2-D convolutions and the
+    input rules of these modules are launches of the HIP kernels: the torch.func.vmap / einsum / autograd rules must not
+    be reached on the GPU."""
     from vivit_amd.backend import extensions as ext
 
     def forbidden(*a, **k):
@@ -165,10 +166,34 @@ def test_weight_rules_run_on_the_hip_kernels(problem, monkeypatch):
     model, X, y = model.to(dev), X.to(dev), y.to(dev)
     monkeypatch.setattr(ext, "_conv_weight_factor", forbidden)
     monkeypatch.setattr(torch, "einsum", forbidden)
+    monkeypatch.setattr(torch.autograd, "grad", forbidden)   # the generic input rule (recomputed forward + batched vjp)
     run_backward(model, X, y, lossf, [SqrtGGNExact()])
     monkeypatch.undo()
     for p, v in zip(model.parameters(), V_ref):
         close(p.sqrt_ggn_exact, v, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,k,s,p,d,op,g,h", [(2, 3, 2, 2, 0, 1, 1, 1, 2), (4, 2, 2, 2, 0, 1, 0, 2, 3), (3, 2, 3, 1, 1, 1, 0, 1, 5),
+                                                     (4, 6, 3, 2, 1, 2, 1, 2, 4), (3, 5, (2, 3), (3, 1), (1, 2), 1, (2, 0), 1, 4)])
+def test_convtranspose_input_rule_on_the_convolution_kernel(cin, cout, k, s, p, d, op, g, h):
+    """ConvTranspose1d/2d input rule = stride-1 input rule of the convolution with reversed taps, sampled at the stride
+    (convtransposend.py:9-30), against autograd."""
+    from vivit_amd.backend import extensions as ext
+
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    for cls, shape in ((nn.ConvTranspose2d, (3, cin, h, h + 1)), (nn.ConvTranspose1d, (3, cin, h + 2))):
+        one = cls is nn.ConvTranspose1d
+        pick = (lambda v: v if isinstance(v, int) else v[1]) if one else (lambda v: v)
+        m = cls(cin, cout, pick(k), stride=pick(s), padding=pick(p), dilation=pick(d), output_padding=pick(op), groups=g).to(dev)
+        x = torch.rand(*shape, device=dev, requires_grad=True)
+        y = m(x)
+        M = torch.rand(4, *y.shape, device=dev)
+        (ref,) = torch.autograd.grad(y, x, M, is_grads_batched=True)
+        got = ext._hip_convtranspose_jac_t(m, M, x.detach())
+        assert got is not None and got.shape == ref.shape
+        close(got, ref, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("problem", PROBLEMS)

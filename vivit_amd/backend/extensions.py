@@ -215,8 +215,9 @@ def _single(v):
 
 def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
     """The layer rules that have a HIP kernel (csrc/jacobians.hip): activations, Flatten / Identity / Dropout(eval),
-    Max/AvgPool2d, Conv2d / Conv1d (groups = 1, zero padding), BatchNorm (eval).  ``None``: no kernel for this module
-    (Conv3d, transposed and grouped convolutions, custom index modules) -- the generic autograd rule takes over."""
+    Max/AvgPool1d/2d, Conv1d / Conv2d and ConvTranspose1d / 2d (any groups, zero padding), Pad / ZeroPad2d / Slicing,
+    BatchNorm (eval).  ``None``: no kernel for this module (Conv3d, ConvTranspose3d, 3-D pooling, custom modules) -- the
+    generic autograd rule takes over."""
     kind = _ACTIVATIONS.get(type(module))
     if kind is not None:
         return kernels.act_jac_t(M, x, kind[0], getattr(module, kind[1]) if kind[1] else 0.0)
@@ -278,12 +279,54 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
             g = torch.cat([kernels.conv2d_jac_t(M[:, :, i * Co:(i + 1) * Co].contiguous(), W[i * Co:(i + 1) * Co].contiguous(), hw, st, pd, dl)
                            for i in range(G)], 2)
         return g.squeeze(3) if one_d else g
+    if (isinstance(module, (nn.ConvTranspose2d, nn.ConvTranspose1d)) and isinstance(module.padding, tuple)
+            and getattr(module, "padding_mode", "zeros") == "zeros"):
+        g = _hip_convtranspose_jac_t(module, M, x)
+        if g is not None:
+            return g
     if isinstance(module, _BATCHNORM) and x.dim() >= 2:
         scale = torch.rsqrt(module.running_var + module.eps)
         if module.weight is not None:
             scale = scale * module.weight.detach()
         return kernels.channel_scale(M if M.dim() > 3 else M.unsqueeze(-1), scale).view(M.shape)
     return None
+
+
+def _hip_convtranspose_jac_t(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
+    """Input rule of ConvTranspose1d/2d (convtransposend.py:9-30) on the HIP kernel of the convolution's input rule.
+
+    The transposed Jacobian of y = conv_transpose(x, W) is a forward convolution of ``M`` with ``W``:
+    ``g[ci, q] = sum_{co, k} W[ci, co, k] M[co, q s - p + k d]``.  With the kernel index reversed (k' = K - 1 - k) this is
+    the stride-1 input rule ``sum_{o, k'} W'[o, ci, k'] M[o, y + p' - k' d]`` of a convolution with weight
+    ``W'[co, ci, k'] = W[ci, co, K - 1 - k']`` and padding ``p' = (K - 1) d - p``, evaluated at ``y = q s`` -- the kernel
+    computes every y and the stride picks every s-th (s^2 of the work is discarded for s > 1; transposed convolutions are
+    rare on this path).  ``None`` when p' would be negative or the kernel's channel limit is exceeded."""
+    one_d = isinstance(module, nn.ConvTranspose1d)
+    W = module.weight.detach()
+    if one_d:
+        M, W = M.unsqueeze(3), W.unsqueeze(2)
+        ks, st, pd, dl = (1, module.kernel_size[0]), (1, module.stride[0]), (0, module.padding[0]), (1, module.dilation[0])
+        hq = (1, x.shape[2])
+    else:
+        ks, st, pd, dl = module.kernel_size, module.stride, module.padding, module.dilation
+        hq = tuple(x.shape[2:])
+    pad2 = tuple((k - 1) * d - p for k, d, p in zip(ks, dl, pd))
+    G = module.groups
+    Co, Ci = module.out_channels // G, module.in_channels // G
+    if min(pad2) < 0 or Co * ks[0] * ks[1] > 1024:
+        return None
+    # input size of the stride-1 rule whose output size is M's:  H' = full + 2 p' - d (K - 1)  <=>  full = H' + 2 p - d (K - 1)
+    full = tuple(h + 2 * p - d * (k - 1) for h, p, d, k in zip(M.shape[3:], pd, dl, ks))
+    if any(f < (q - 1) * s + 1 for f, q, s in zip(full, hq, st)):
+        return None
+    parts = []
+    for g in range(G):
+        Wg = W[g * Ci:(g + 1) * Ci].transpose(0, 1).flip(2, 3).contiguous()            # [Co, Ci, kh, kw], reversed taps
+        Mg = M if G == 1 else M[:, :, g * Co:(g + 1) * Co].contiguous()
+        parts.append(kernels.conv2d_jac_t(Mg, Wg, full, (1, 1), pad2, dl))
+    out = parts[0] if G == 1 else torch.cat(parts, 2)
+    out = out[..., ::st[0], ::st[1]][..., :hq[0], :hq[1]].contiguous()
+    return out.squeeze(3) if one_d else out
 
 
 def _jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Tensor:

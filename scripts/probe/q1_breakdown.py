@@ -4,7 +4,7 @@ gaps between consecutive kernels."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last_q2 = max(i for i, r in enumerate(rows) if "q2_apply" in r["Kernel_Name"])
+last_q2 = max(i for i, r in enumerate(rows) if "q2_apply" in r["Kernel_Name"] or "qs_apply" in r["Kernel_Name"])
 tail = rows[last_q2 + 1:]
 by = collections.defaultdict(lambda: [0, 0])
 gap = 0

@@ -3,6 +3,8 @@
 // reference at vivit/extensions/secondorder/vivit/base.py:84-92; Linear: einsum("vno,ni->vnoi"), Conv2d: unfold +
 // einsum("vnol,nkl->vnok")).  Both are bound by writing V (4 n P bytes): the Linear kernel is a pure store stream, the
 // Conv2d kernel gathers the input patch values on the fly (no im2col buffer) from the L1/L2-resident sample.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace vivit {
@@ -90,6 +92,198 @@ __global__ __launch_bounds__(256) void conv2d_weight_mjp_kernel(const float *__r
   }
 }
 
+// ---- the same rule on the fp32 matrix pipe (round 4) -----------------------------------------------------------------------
+// Per (v, n) row the rule is a small GEMM  V[o][k] = sum_l M[o][l] P[l][k]  with the patch matrix P[l][k = (c, kh, kw)] =
+// x[c][oh sh - ph + kh dh][ow sw - pw + kw dw]: 16..64 x 27..576 x 64..1024 in ResNet-32.  One workgroup per row (and group
+// of 64 output channels) stages the sample's input planes WITH their zero border ([Cin][H + 2 ph][W + 2 pw]: the gather
+// needs no bounds test) and the row's M transposed ([l][o], stride 16 RT + 1) in LDS; a wave owns 16-wide column tiles of
+// V and runs v_mfma_f32_16x16x4_f32 over l: the A value of a lane is M[o = 16 rt + lane % 16][l = l0 + lane / 16], the B
+// value the gathered x for (k = 16 ct + lane % 16, l = l0 + lane / 16), whose LDS address advances incrementally with l
+// (ow += 4 with one wrap, hence OW >= 4).  One gather feeds RT = Cout / 16 MFMAs.  (The scalar kernel above: 8 FMAs per
+// global + two LDS loads, 13 TFLOP/s, 10.5 of the 57 ms of config 4's factor back-propagation.)
+constexpr int CWM_OC = 64;        // output channels per workgroup (RT <= 4 row tiles)
+constexpr int CWM_THREADS = 1024;  // 16 waves: four per SIMD hide the LDS latency of the gather
+constexpr int CWM_U = 8;           // steps (of four positions) whose LDS reads are in flight together
+typedef float cwm_f32x4 __attribute__((ext_vector_type(4)));
+
+// Work items of a workgroup: (column tile ct, split sp of the position range); S > 1 only when there are fewer column
+// tiles than waves -- the partial tiles then go through the LDS region of M (dead after the products) and are summed in
+// a fixed order.
+template <int RT>
+__global__ __launch_bounds__(CWM_THREADS) void conv2d_weight_mjp_mfma_kernel(const float *__restrict__ M, const float *__restrict__ x,
+                                                                             float *__restrict__ V, int64_t N, Conv2dGeom g, int S) {
+  extern __shared__ __attribute__((aligned(16))) float cwm_smem[];
+  const int Hp = g.H + 2 * g.ph, Wp = g.W + 2 * g.pw, plane = Hp * Wp;
+  const int L = g.OH * g.OW, L4 = L & ~3, Lp = (L + 3) & ~3;
+  const int K = g.Cin * g.KH * g.KW, KK = g.KH * g.KW;
+  const int o0 = blockIdx.y * CWM_OC;
+  const int OC = (g.Cout - o0) < CWM_OC ? (g.Cout - o0) : CWM_OC;
+  constexpr int OCs = 16 * RT + 1;
+  float *sX = cwm_smem;                                  // [Cin][Hp][Wp], zero border
+  float *sM = cwm_smem + ((g.Cin * plane + 3) & ~3);     // [Lp][OCs]; afterwards: the partial tiles [S][16 RT][K]
+  const int64_t row = blockIdx.x, n = row % N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT = blockDim.x, NW = NT >> 6;
+  {
+    // staging in batches: CWM_SB loads of a thread in flight before their LDS stores (a load-store pair per trip costs a
+    // global round trip each: 34 of them per wave were 70 % of the kernel)
+    constexpr int CWM_SB = 12;
+    const float *xn = x + n * (int64_t)g.Cin * g.H * g.W;
+    const int totx = g.Cin * plane;
+    for (int base = 0; base < totx; base += NT * CWM_SB) {
+      float v[CWM_SB];
+#pragma unroll
+      for (int u = 0; u < CWM_SB; ++u) {
+        const int idx = base + u * NT + tid;
+        const int ic = idx < totx ? idx : 0;
+        const int rr = ic / Wp, wq = ic - rr * Wp;
+        const int c = rr / Hp, ih = rr - c * Hp - g.ph, iw = wq - g.pw;
+        const bool in = idx < totx && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W;
+        v[u] = in ? xn[((int64_t)c * g.H + ih) * g.W + iw] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < CWM_SB; ++u) {
+        const int idx = base + u * NT + tid;
+        if (idx < totx) sX[idx] = v[u];
+      }
+    }
+    const float *Mrow = M + (row * g.Cout + o0) * (int64_t)L;
+    const int totm = 16 * RT * Lp;
+    for (int base = 0; base < totm; base += NT * CWM_SB) {
+      float v[CWM_SB];
+#pragma unroll
+      for (int u = 0; u < CWM_SB; ++u) {
+        const int idx = base + u * NT + tid;
+        const int ic = idx < totm ? idx : 0;
+        const int o = ic / Lp, l = ic - o * Lp;                 // coalesced along the positions of a channel
+        v[u] = (idx < totm && o < OC && l < L) ? Mrow[(int64_t)o * L + l] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < CWM_SB; ++u) {
+        const int idx = base + u * NT + tid;
+        if (idx < totm) {
+          const int o = idx / Lp, l = idx - o * Lp;
+          sM[l * OCs + o] = v[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int j = lane & 15, kq = lane >> 4;
+  const int nct = (K + 15) / 16;
+  const int wrap = g.sh * Wp - g.OW * g.sw;
+  const int nsteps = L4 / 4;   // whole steps; the last split also takes the 1..3 positions behind them
+  cwm_f32x4 acc[RT];
+  for (int item = wave; item < nct * S; item += NW) {
+    const int ct = item / S, sp = item - ct * S;
+    const int s0 = (int)((int64_t)sp * nsteps / S), s1 = (int)((int64_t)(sp + 1) * nsteps / S);
+    const int kp = ct * 16 + j;
+    const bool kvalid = kp < K;
+    const int kpc = kvalid ? kp : 0;
+    const int c = kpc / KK, r = kpc - c * KK, kh = r / g.KW, kw = r - kh * g.KW;
+    const int lstart = 4 * s0 + kq;
+    int oh = lstart / g.OW, ow = lstart - oh * g.OW;
+    int pos = c * plane + (oh * g.sh + kh * g.dh) * Wp + ow * g.sw + kw * g.dw;
+    const float *aM = sM + lstart * OCs + j;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (cwm_f32x4){0.f, 0.f, 0.f, 0.f};
+    auto advance = [&]() __attribute__((always_inline)) {   // l += 4 (OW >= 4: at most one wrap)
+      ow += 4;
+      pos += 4 * g.sw;
+      const bool wr = ow >= g.OW;
+      ow = wr ? ow - g.OW : ow;
+      pos = wr ? pos + wrap : pos;
+    };
+    int st = s0;
+    for (; st + CWM_U <= s1; st += CWM_U) {
+      float b[CWM_U], a[CWM_U][RT];
+#pragma unroll
+      for (int u = 0; u < CWM_U; ++u) {
+        b[u] = sX[pos];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[u][rt] = aM[u * 4 * OCs + 16 * rt];
+        advance();
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (hipcc sinks the reads to their MFMAs otherwise: one exposed LDS latency per pair)
+#pragma unroll
+      for (int u = 0; u < CWM_U; ++u)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][rt], b[u], acc[rt], 0, 0, 0);
+      aM += CWM_U * 4 * OCs;
+    }
+    for (; st < s1; ++st) {
+      const float b = sX[pos];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aM[16 * rt], b, acc[rt], 0, 0, 0);
+      aM += 4 * OCs;
+      advance();
+    }
+    if (sp == S - 1 && L4 < L) {   // the last 1..3 positions: lanes beyond L contribute nothing (their M rows are zero; no stray read)
+      const float b = (L4 + kq < L) ? sX[pos] : 0.f;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aM[16 * rt], b, acc[rt], 0, 0, 0);
+    }
+    if (S == 1) {
+      if (kvalid) {
+        float *vp = V + (row * g.Cout + o0) * (int64_t)K + kp;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int o = 16 * rt + 4 * kq + e;
+            if (o < OC) vp[(int64_t)o * K] = acc[rt][e];
+          }
+      }
+    } else {
+      // (S > 1 implies a single trip of this loop per wave: nct S <= NW -- the partials may overwrite M only after everybody's products)
+      __syncthreads();
+      if (kvalid) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sM[((int64_t)sp * 16 * RT + 16 * rt + 4 * kq + e) * K + kp] = acc[rt][e];
+      }
+    }
+  }
+  if (S > 1) {
+    if (wave >= nct * S) __syncthreads();   // waves without an item: the barrier of the others
+    __syncthreads();
+    float *vp = V + (row * g.Cout + o0) * (int64_t)K;
+    for (int idx = tid; idx < OC * K; idx += NT) {
+      float v = sM[idx];
+      for (int q = 1; q < S; ++q) v += sM[(int64_t)q * 16 * RT * K + idx];
+      vp[idx] = v;
+    }
+  }
+}
+
+// LDS bytes of the matrix-pipe kernel for a geometry (0: it does not apply) and the number of position splits
+static size_t conv2d_weight_mjp_mfma_lds(const Conv2dGeom &g, int *splits, int *threads) {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("VIVIT_CONV_MFMA");
+    on = e ? atoi(e) : 1;
+  }
+  *splits = 1;
+  *threads = 256;
+  if (!on || g.OW < 4) return 0;
+  const int64_t plane = (int64_t)(g.H + 2 * g.ph) * (g.W + 2 * g.pw);
+  const int64_t L = (int64_t)g.OH * g.OW, K = (int64_t)g.Cin * g.KH * g.KW;
+  const int rt = (int)((((g.Cout < CWM_OC ? g.Cout : CWM_OC) + 15) / 16));
+  const int64_t mfloats = ((L + 3) & ~3LL) * (16 * rt + 1);
+  const int64_t floats = ((g.Cin * plane + 3) & ~3LL) + mfloats;
+  if (floats * 4 > 156 * 1024 || L * K < 4096) return 0;   // (tiny problems: the scalar kernel's launch is cheaper)
+  // fewer column tiles than waves: split the positions (at most one item per wave, partial tiles inside M's region,
+  // every split at least CWM_U steps)
+  // one workgroup per CU (LDS-bound): 16 waves; two to three: 8; more: 4
+  *threads = floats * 4 > 80 * 1024 ? 1024 : (floats * 4 > 40 * 1024 ? 512 : 256);
+  const int64_t nct = (K + 15) / 16, nw = *threads / 64;
+  int S = (int)(nw / nct);
+  while (S > 1 && (S * 16 * rt * K > mfloats || (L / 4) / S < CWM_U)) --S;
+  *splits = S < 1 ? 1 : S;
+  return (size_t)floats * 4;
+}
+
 } // namespace vivit
 
 using namespace vivit;
@@ -134,10 +328,35 @@ int vivit_conv2d_weight_mjp_f32(const float *M, const float *x, float *V, int64_
   const int64_t per = (1 << 20) / N > 0 ? (1 << 20) / N : 1;
   const int64_t step = N * per;
   if (step > 0x7fffffffLL) return VIVIT_E_UNSUPPORTED;
+  int splits = 1, threads = 256;
+  const size_t lds = conv2d_weight_mjp_mfma_lds(g, &splits, &threads);
+  if (lds > 0) {
+    static unsigned long long attr_done = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
+    if (!(attr_done & (1ull << (dev & 63)))) {
+      const void *fns[4] = {reinterpret_cast<const void *>(conv2d_weight_mjp_mfma_kernel<1>), reinterpret_cast<const void *>(conv2d_weight_mjp_mfma_kernel<2>),
+                            reinterpret_cast<const void *>(conv2d_weight_mjp_mfma_kernel<3>), reinterpret_cast<const void *>(conv2d_weight_mjp_mfma_kernel<4>)};
+      for (const void *f : fns)
+        if (!ensure_dynamic_lds(f, 156 * 1024, attr_done)) return VIVIT_E_LAUNCH;
+      attr_done |= 1ull << (dev & 63);
+    }
+  }
   for (int64_t r0 = 0; r0 < rows; r0 += step) {
     const int64_t rc = (rows - r0) < step ? rows - r0 : step;
-    const dim3 grid((unsigned)rc, (unsigned)cdiv(Cin * KH * KW, 256), (unsigned)cdiv(Cout, CV_OT));
-    conv2d_weight_mjp_kernel<<<grid, 256, 0, st>>>(M + r0 * Cout * OH * OW, x, V + r0 * outs, N, g);
+    const float *Mc = M + r0 * Cout * OH * OW;
+    float *Vc = V + r0 * outs;
+    if (lds > 0) {
+      const dim3 grid((unsigned)rc, (unsigned)cdiv(Cout, CWM_OC));
+      const int rt = (int)cdiv(Cout < CWM_OC ? Cout : CWM_OC, 16);
+      if (rt == 1) conv2d_weight_mjp_mfma_kernel<1><<<grid, threads, lds, st>>>(Mc, x, Vc, N, g, splits);
+      else if (rt == 2) conv2d_weight_mjp_mfma_kernel<2><<<grid, threads, lds, st>>>(Mc, x, Vc, N, g, splits);
+      else if (rt == 3) conv2d_weight_mjp_mfma_kernel<3><<<grid, threads, lds, st>>>(Mc, x, Vc, N, g, splits);
+      else conv2d_weight_mjp_mfma_kernel<4><<<grid, threads, lds, st>>>(Mc, x, Vc, N, g, splits);
+    } else {
+      const dim3 grid((unsigned)rc, (unsigned)cdiv(Cin * KH * KW, 256), (unsigned)cdiv(Cout, CV_OT));
+      conv2d_weight_mjp_kernel<<<grid, 256, 0, st>>>(Mc, x, Vc, N, g);
+    }
   }
   return launch_status();
 }

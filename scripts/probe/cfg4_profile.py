@@ -35,4 +35,4 @@ for w in (False, True):
         for _ in range(3):
             run(w)
     print("==== with factor extension" if w else "==== plain backward")
-    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=18, max_name_column_width=70))
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))

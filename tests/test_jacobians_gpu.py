@@ -64,7 +64,14 @@ def test_pooling_rules(shape, k, s, p):
                                                  (16, 32, (32, 32), 3, 2, 1, 1),     # ResNet-32 down-sampling block
                                                  (64, 64, (8, 8), 3, 1, 1, 1),       # ResNet-32 last stage
                                                  (5, 7, (9, 11), (2, 3), (2, 1), (1, 2), (2, 1)),   # ragged everything
-                                                 (19, 3, (6, 6), 3, 1, 0, 1)])       # more than one group of 16 input channels
+                                                 (19, 3, (6, 6), 3, 1, 0, 1),        # more than one group of 16 input channels
+                                                 # filter slices beyond the scalar input rule's LDS budget (Cout KH KW > 1024): the
+                                                 # matrix-pipe input rule -- one chunk with split contraction, ragged channels and
+                                                 # positions, stride 2 (inserted zeros), chunks of output channels
+                                                 (40, 128, (8, 8), 3, 1, 1, 1),
+                                                 (37, 150, (7, 9), 3, 2, 1, 1),
+                                                 (16, 520, (20, 20), 3, 1, 1, 1),
+                                                 (8, 72, (12, 12), 5, 1, 2, 1)])
 def test_conv2d_rules(cin, cout, hw, k, s, p, d):
     from vivit_amd import kernels
 

@@ -261,8 +261,8 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
             ks = _pair(module.kernel_size)
             return kernels.avgpool2d_jac_t(M, x.shape[2:], ks, _pair(module.stride if module.stride is not None else ks),
                                            _pair(module.padding))
-    if (isinstance(module, (nn.Conv2d, nn.Conv1d)) and isinstance(module.padding, tuple) and module.padding_mode == "zeros"
-            and module.out_channels // module.groups * math.prod(module.kernel_size) <= 1024):
+    if isinstance(module, (nn.Conv2d, nn.Conv1d)) and isinstance(module.padding, tuple) and module.padding_mode == "zeros":
+        # (a shape neither kernel takes comes back as VIVIT_E_UNSUPPORTED: the caller falls through to the generic rule)
         # a Conv1d is the Conv2d with one row: same kernel; groups > 1: one launch per group on its channel slices
         one_d = isinstance(module, nn.Conv1d)
         W = module.weight.detach()

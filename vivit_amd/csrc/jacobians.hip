@@ -6,6 +6,8 @@
 // biases and BatchNorm.  Everything here is bandwidth-bound elementwise / gather work (coalesced along the innermost
 // spatial dimension, one pass over M), except the Conv2d rule which is a direct transposed convolution with the
 // filter slice in LDS and 16 input channels per thread in registers.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace vivit {
@@ -113,7 +115,7 @@ struct ConvGeom {
   int Cin, H, W, Cout, KH, KW, OH, OW, sh, sw, ph, pw, dh, dw;
 };
 __global__ __launch_bounds__(256) void conv2d_jac_t_kernel(const float *__restrict__ M, const float *__restrict__ Wt,
-                                                           float *__restrict__ out, ConvGeom g) {
+                                                           float *__restrict__ out, ConvGeom g, int64_t rows) {
   extern __shared__ float sW[];  // [Cout][KH*KW][CIT]
   const int KK = g.KH * g.KW;
   const int ci0 = blockIdx.y * CIT;
@@ -124,10 +126,20 @@ __global__ __launch_bounds__(256) void conv2d_jac_t_kernel(const float *__restri
   }
   __syncthreads();
   const int HW = g.H * g.W, L = g.OH * g.OW;
-  const int tiles = (HW + 255) / 256;
-  const int64_t r = blockIdx.x / tiles;
-  const int hw = (int)(blockIdx.x % tiles) * 256 + threadIdx.x;
-  if (hw >= HW) return;
+  // planes of at most 128 positions: 256 / HW rows share a workgroup (an 8 x 8 plane used a quarter of the lanes)
+  int64_t r;
+  int hw;
+  if (HW <= 128) {
+    const int rpw = 256 / HW, rl = threadIdx.x / HW;
+    r = (int64_t)blockIdx.x * rpw + rl;
+    hw = threadIdx.x - rl * HW;
+    if (rl >= rpw || r >= rows) return;
+  } else {
+    const int tiles = (HW + 255) / 256;
+    r = blockIdx.x / tiles;
+    hw = (int)(blockIdx.x % tiles) * 256 + threadIdx.x;
+    if (hw >= HW) return;
+  }
   const int h = hw / g.W, w = hw - h * g.W;
   float acc[CIT];
 #pragma unroll
@@ -160,6 +172,219 @@ __global__ __launch_bounds__(256) void conv2d_jac_t_kernel(const float *__restri
 #pragma unroll
   for (int c = 0; c < CIT; ++c)
     if (c < nci) op[(int64_t)c * HW] = acc[c];
+}
+
+// ---- the same rule on the fp32 matrix pipe (round 4) -----------------------------------------------------------------------
+// Per row r = (v, n) the rule is a GEMM  out[ci][hw] = sum_q W'[ci][q] G[q][hw],  q = (co, a, b),  W'[ci][q] = Wt[co][ci][a][b],
+// G[q][hw] = M[co][(h + ph - a dh) / sh][(w + pw - b dw) / sw] (zero unless the divisions are exact and in range):
+// 16..64 x 64..1024 x 144..576 in ResNet-32.  One workgroup per row and group of 32 input channels stages
+//   * M "up-sampled": sMu[co][u][t] with M[co][oh][ow] at u = oh sh + Bh, t = ow sw + Bw and zeros elsewhere (Bh = (KH-1) dh - ph
+//     rows of border), so that G[q][hw] = sMu[tab[q] + h Wu + w] for EVERY q and hw -- no test, no division in the loop;
+//   * the weights transposed, sW[q][ci] (stride 16 RT + 1), and tab[q] = co plane + (ph - a dh + Bh) Wu + (pw - b dw + Bw);
+// output channels in chunks of CC when the whole of it does not fit (later chunks add into out).  A wave owns 16-wide
+// column tiles of out (16 positions hw) and runs v_mfma_f32_16x16x4_f32 over q; one gathered value feeds RT MFMAs.  With
+// fewer column tiles than waves the q range is split S ways and the partial tiles are summed through LDS in a fixed order.
+// (Stride-s layers multiply the inserted zeros: s^2 of the MFMAs are idle work; two of ResNet-32's thirty layers.)
+constexpr int CJM_IC = 32;   // input channels per workgroup (RT <= 2 row tiles)
+constexpr int CJM_U = 8;     // steps (of four q) whose LDS reads are in flight together
+typedef float cjm_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int RT>
+__global__ __launch_bounds__(1024) void conv2d_jac_t_mfma_kernel(const float *__restrict__ M, const float *__restrict__ Wt,
+                                                                 float *__restrict__ out, ConvGeom g, int CC, int S) {
+  extern __shared__ __attribute__((aligned(16))) float cjm_smem[];
+  const int KK = g.KH * g.KW;
+  const int Bh = (g.KH - 1) * g.dh > g.ph ? (g.KH - 1) * g.dh - g.ph : 0, Bw = (g.KW - 1) * g.dw > g.pw ? (g.KW - 1) * g.dw - g.pw : 0;
+  const int Hu = g.H + g.ph + Bh, Wu = g.W + g.pw + Bw, plane = Hu * Wu;
+  const int HW = g.H * g.W, L = g.OH * g.OW;
+  const int ci0 = blockIdx.y * CJM_IC;
+  const int IC = (g.Cin - ci0) < CJM_IC ? (g.Cin - ci0) : CJM_IC;
+  constexpr int WS = 16 * RT + 1;
+  const int Qmax = (CC * KK + 3) & ~3;
+  float *sMu = cjm_smem;                                  // [CC][Hu][Wu]
+  float *sW = cjm_smem + ((CC * plane + 3) & ~3);          // [Qmax][WS]; afterwards: the partial tiles [items][16 RT][16]
+  int *sT = reinterpret_cast<int *>(sW + Qmax * WS);       // [Qmax]
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT = blockDim.x, NW = NT >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  const int nct = (HW + 15) / 16;
+  const float *Mr = M + row * (int64_t)g.Cout * L;
+  float *outr = out + (row * g.Cin + ci0) * (int64_t)HW;
+  constexpr int SB = 12;   // staging loads of a thread in flight together
+  for (int cc0 = 0; cc0 < g.Cout; cc0 += CC) {
+    const int ccn = (g.Cout - cc0) < CC ? (g.Cout - cc0) : CC;
+    const int Qc = ccn * KK, Qp = (Qc + 3) & ~3;
+    if (cc0 > 0) __syncthreads();   // the previous chunk's reads (and partial sums) are done
+    {
+      const int totm = ccn * plane;
+      for (int base = 0; base < totm; base += NT * SB) {
+        float v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int idx = base + u * NT + tid;
+          const int ic = idx < totm ? idx : 0;
+          const int co = ic / plane, rem = ic - co * plane;
+          const int uh = rem / Wu - Bh, uw = rem % Wu - Bw;
+          const int oh = uh / g.sh, ow = uw / g.sw;
+          const bool in = idx < totm && uh >= 0 && uw >= 0 && oh * g.sh == uh && ow * g.sw == uw && oh < g.OH && ow < g.OW;
+          v[u] = in ? Mr[(int64_t)(cc0 + co) * L + oh * g.OW + ow] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int idx = base + u * NT + tid;
+          if (idx < totm) sMu[idx] = v[u];
+        }
+      }
+      // weights: global order (co, ci, k) -> sW[(co KK + k)][ci]
+      const int totw = ccn * IC * KK;
+      for (int base = 0; base < totw; base += NT * SB) {
+        float v[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int idx = base + u * NT + tid;
+          const int ic = idx < totw ? idx : 0;
+          const int co = ic / (IC * KK), rem = ic - co * (IC * KK);
+          v[u] = Wt[((int64_t)(cc0 + co) * g.Cin + ci0) * KK + rem];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int idx = base + u * NT + tid;
+          if (idx < totw) {
+            const int co = idx / (IC * KK), rem = idx - co * (IC * KK);
+            const int i = rem / KK, k = rem - i * KK;
+            sW[(co * KK + k) * WS + i] = v[u];
+          }
+        }
+      }
+      // zero rows of the weights (channels beyond IC, q beyond Qc) and the offset table
+      for (int idx = tid; idx < Qp * 16 * RT; idx += NT) {
+        const int q = idx / (16 * RT), i = idx - q * 16 * RT;
+        if (q >= Qc || i >= IC) sW[q * WS + i] = 0.f;
+      }
+      for (int q = tid; q < Qp; q += NT) {
+        int t = 0;
+        if (q < Qc) {
+          const int co = q / KK, k = q - co * KK, a = k / g.KW, b = k - a * g.KW;
+          t = co * plane + (g.ph - a * g.dh + Bh) * Wu + (g.pw - b * g.dw + Bw);
+        }
+        sT[q] = t;
+      }
+    }
+    __syncthreads();
+    const int nsteps = Qp / 4;
+    const int nitems = nct * S;
+    for (int it0 = 0; it0 < nitems; it0 += NW) {   // (all waves make the same trips: barriers inside when S > 1)
+      const int item = it0 + wave;
+      const bool has = item < nitems;
+      const int ct = has ? item / S : 0, sp = has ? item - ct * S : 0;
+      const int s0 = (int)((int64_t)sp * nsteps / S), s1 = has ? (int)((int64_t)(sp + 1) * nsteps / S) : s0;
+      const int hw = ct * 16 + j;
+      const bool hvalid = has && hw < HW;
+      const int hwc = hw < HW ? hw : HW - 1;
+      const int h = hwc / g.W, w = hwc - h * g.W;
+      const float *gb = sMu + h * Wu + w;
+      const float *aW = sW + (4 * s0 + kq) * WS + j;
+      const int *tq = sT + 4 * s0 + kq;
+      cjm_f32x4 acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = (cjm_f32x4){0.f, 0.f, 0.f, 0.f};
+      int st = s0;
+      for (; st + CJM_U <= s1; st += CJM_U) {
+        int t[CJM_U];
+        float b[CJM_U], a[CJM_U][RT];
+#pragma unroll
+        for (int u = 0; u < CJM_U; ++u) t[u] = tq[4 * u];
+#pragma unroll
+        for (int u = 0; u < CJM_U; ++u)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) a[u][rt] = aW[u * 4 * WS + 16 * rt];
+#pragma unroll
+        for (int u = 0; u < CJM_U; ++u) b[u] = gb[t[u]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CJM_U; ++u)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][rt], b[u], acc[rt], 0, 0, 0);
+        aW += CJM_U * 4 * WS;
+        tq += CJM_U * 4;
+      }
+      for (; st < s1; ++st) {
+        const float b = gb[tq[0]];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aW[16 * rt], b, acc[rt], 0, 0, 0);
+        aW += 4 * WS;
+        tq += 4;
+      }
+      if (S == 1) {
+        if (hvalid) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ci = 16 * rt + 4 * kq + e;
+              if (ci < IC) {
+                float *op = outr + (int64_t)ci * HW + hw;
+                *op = cc0 == 0 ? acc[rt][e] : *op + acc[rt][e];
+              }
+            }
+        }
+      } else {
+        // partial tiles through the weights' region (S > 1 is only planned when all items fit one trip and the region)
+        __syncthreads();
+        if (has) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sW[(item * 16 * RT + 16 * rt + 4 * kq + e) * 16 + j] = acc[rt][e];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nct * 16 * RT * 16; idx += NT) {
+          const int ct2 = idx / (16 * RT * 16), rem = idx - ct2 * (16 * RT * 16);
+          const int ci = rem >> 4, hw2 = ct2 * 16 + (rem & 15);
+          if (ci < IC && hw2 < HW) {
+            float v = sW[(ct2 * S) * 16 * RT * 16 + rem];
+            for (int q = 1; q < S; ++q) v += sW[(ct2 * S + q) * 16 * RT * 16 + rem];
+            float *op = outr + (int64_t)ci * HW + hw2;
+            *op = cc0 == 0 ? v : *op + v;
+          }
+        }
+      }
+    }
+  }
+}
+
+struct ConvJtPlan {
+  size_t lds;
+  int CC, S, threads, RT;
+};
+// the matrix-pipe kernel's plan for a geometry (lds = 0: it does not apply)
+static ConvJtPlan conv2d_jac_t_mfma_plan(const ConvGeom &g) {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("VIVIT_CONV_MFMA");
+    on = e ? atoi(e) : 1;
+  }
+  ConvJtPlan p{0, 0, 1, 256, 1};
+  if (!on) return p;
+  const int64_t KK = (int64_t)g.KH * g.KW;
+  const int64_t Bh = (g.KH - 1) * g.dh > g.ph ? (g.KH - 1) * g.dh - g.ph : 0, Bw = (g.KW - 1) * g.dw > g.pw ? (g.KW - 1) * g.dw - g.pw : 0;
+  const int64_t plane = (g.H + g.ph + Bh) * (g.W + g.pw + Bw), HW = (int64_t)g.H * g.W;
+  if (HW * g.Cout * KK < 4096) return p;   // (tiny problems: the scalar kernel's launch is cheaper)
+  p.RT = (g.Cin < CJM_IC ? g.Cin : CJM_IC) > 16 ? 2 : 1;
+  const int64_t WS = 16 * p.RT + 1;
+  auto floats = [&](int64_t cc) { const int64_t qp = (cc * KK + 3) & ~3LL; return ((cc * plane + 3) & ~3LL) + qp * WS + qp; };
+  int64_t cc = g.Cout;
+  while (cc > 1 && floats(cc) * 4 > 150 * 1024) cc = (cc + 1) / 2;
+  if (floats(cc) * 4 > 150 * 1024) return p;
+  p.CC = (int)cc;
+  p.lds = (size_t)floats(cc) * 4;
+  p.threads = p.lds > 80 * 1024 ? 1024 : (p.lds > 40 * 1024 ? 512 : 256);
+  const int64_t nct = (HW + 15) / 16, nw = p.threads / 64, qp = (cc * KK + 3) & ~3LL;
+  int S = (int)(nw / nct);
+  while (S > 1 && (nct * S * 16 * p.RT * 16 > qp * WS || (qp / 4) / S < CJM_U)) --S;
+  p.S = S < 1 ? 1 : S;
+  return p;
 }
 
 // ---- reductions of the parameter rules --------------------------------------------------------------------------------
@@ -294,10 +519,36 @@ int vivit_conv2d_jac_t_f32(const float *M, const float *weight, float *out, int6
   if (!M || !weight || !out) return VIVIT_E_BADARG;
   const size_t lds = (size_t)Cout * KH * KW * CIT * sizeof(float);
   const int64_t tiles = cdiv(H * W, 256);
-  if (lds > 64 * 1024 || rows * tiles > 0x7fffffffLL || cdiv(Cin, CIT) > 65535) return VIVIT_E_UNSUPPORTED;
   ConvGeom g{(int)Cin, (int)H, (int)W, (int)Cout, (int)KH, (int)KW, (int)OH, (int)OW, (int)sh, (int)sw, (int)ph, (int)pw, (int)dh, (int)dw};
-  conv2d_jac_t_kernel<<<dim3((unsigned)(rows * tiles), (unsigned)cdiv(Cin, CIT)), 256, lds, static_cast<hipStream_t>(stream)>>>(M, weight,
-                                                                                                                                  out, g);
+  // the geometry must be that of a convolution (as the weight rule checks): every output position reads inside the padded input
+  const bool conv_geom = (OH - 1) * sh + (KH - 1) * dh - ph < H + ph && (OW - 1) * sw + (KW - 1) * dw - pw < W + pw;
+  // The scalar kernel (40-47 TFLOP/s on ResNet-32's layers) takes every shape whose filter slice fits its LDS budget; the
+  // matrix-pipe kernel takes the rest (Cout KH KW > 1024: measured 107 against 122 us on 32 -> 32 @ 16 x 16, but 165 against
+  // 119 us on 16 -> 16 @ 32 x 32 and half the speed on stride-2 layers, whose inserted zeros it multiplies).
+  const bool scalar_ok = lds <= 64 * 1024 && rows * tiles <= 0x7fffffffLL && cdiv(Cin, CIT) <= 65535;
+  if (!scalar_ok && conv_geom && rows <= 0x7fffffffLL && cdiv(Cin, CJM_IC) <= 65535 && H * W <= (1 << 24) && Cout * KH * KW <= (1 << 24)) {
+    const ConvJtPlan pl = conv2d_jac_t_mfma_plan(g);
+    if (pl.lds > 0) {
+      static unsigned long long attr_done = 0;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) return VIVIT_E_LAUNCH;
+      if (!(attr_done & (1ull << (dev & 63)))) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(conv2d_jac_t_mfma_kernel<1>), 152 * 1024, attr_done) ||
+            !ensure_dynamic_lds(reinterpret_cast<const void *>(conv2d_jac_t_mfma_kernel<2>), 152 * 1024, attr_done))
+          return VIVIT_E_LAUNCH;
+        attr_done |= 1ull << (dev & 63);
+      }
+      const dim3 grid((unsigned)rows, (unsigned)cdiv(Cin, CJM_IC));
+      if (pl.RT == 1)
+        conv2d_jac_t_mfma_kernel<1><<<grid, pl.threads, pl.lds, static_cast<hipStream_t>(stream)>>>(M, weight, out, g, pl.CC, pl.S);
+      else
+        conv2d_jac_t_mfma_kernel<2><<<grid, pl.threads, pl.lds, static_cast<hipStream_t>(stream)>>>(M, weight, out, g, pl.CC, pl.S);
+      return launch_status();
+    }
+  }
+  if (!scalar_ok) return VIVIT_E_UNSUPPORTED;
+  const int64_t gx = H * W <= 128 ? cdiv(rows, 256 / (H * W)) : rows * tiles;
+  conv2d_jac_t_kernel<<<dim3((unsigned)gx, (unsigned)cdiv(Cin, CIT)), 256, lds, static_cast<hipStream_t>(stream)>>>(M, weight, out, g, rows);
   return launch_status();
 }
 

@@ -96,6 +96,19 @@ def _spatial_sum(t: Tensor, keep: int) -> Tensor:
     return t.flatten(start_dim=keep).sum(keep)
 
 
+def _spatial_sum3(M: Tensor) -> Tensor:
+    """``_spatial_sum(M, 3)`` remembered ON the factor tensor: BatchNorm's bias rule and its weight rule both need it (one pass
+    over M instead of two; the memo lives and dies with the tensor object)."""
+    memo = getattr(M, "_vivit_ssum3", None)
+    if memo is None:
+        memo = _spatial_sum(M, 3)
+        try:
+            M._vivit_ssum3 = memo
+        except AttributeError:   # (tensor subclasses without a __dict__)
+            pass
+    return memo
+
+
 def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
     """``param_mjp(..., sum_batch=False)``: ``M`` [V, N, *out] -> [V, N, *param.shape]."""
     if isinstance(module, nn.Linear):
@@ -125,13 +138,14 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
         if module.training:
             raise NotImplementedError("BatchNorm must be in eval mode (as in the reference tests)")
         if name == "bias":
-            return _spatial_sum(M, 3)
+            return _spatial_sum3(M)
         rstd = torch.rsqrt(module.running_var + module.eps)
         if M.is_cuda:
-            # sum_l M xhat = (sum_l M x - mean_c sum_l M) rstd_c: two row reductions on HIP, the rest is [V, N, C]-sized
+            # sum_l M xhat = (sum_l M x - mean_c sum_l M) rstd_c: two row reductions on HIP (the second shared with the bias
+            # rule), the rest is [V, N, C]-sized
             L = x[0, 0].numel()
             Mx = kernels.row_dot(M.reshape(-1, L), x.reshape(-1, L), rows_x=x.shape[0] * x.shape[1]).view(M.shape[:3])
-            return (Mx - module.running_mean * _spatial_sum(M, 3)) * rstd
+            return torch.addcmul(Mx * rstd, _spatial_sum3(M), -(module.running_mean * rstd))
         shape = [1, -1] + [1] * (x.dim() - 2)
         xhat = (x - module.running_mean.view(shape)) * rstd.view(shape)
         return _spatial_sum(M * xhat.unsqueeze(0), 3)

@@ -143,8 +143,10 @@ int vivit_class_expand_f32(const float *s, const float *U, float *R, int64_t F, 
  *     (einsum "vno,ni->vnoi"; what linear.py:41-42 keeps factorised, materialised for SqrtGGN{Exact,MC} / BatchGrad)
  *   vivit_conv2d_weight_mjp_f32: V[r, o, c, kh, kw] = sum_{oh,ow} M[r, o, oh, ow] * x[r % N, c, oh*sh-ph+kh*dh, ow*sw-pw+kw*dw]
  *     M: [rows, Cout, OH, OW], x: [N, Cin, H, W], V: [rows, Cout*Cin*KH*KW]; rows = C*N (class-major), groups = 1,
- *     zero padding (unfold + einsum "vnol,nkl->vnok" without the im2col buffer).
- * Both are bound by the 4*rows*P bytes they write.
+ *     zero padding (unfold + einsum "vnol,nkl->vnok" without the im2col buffer).  Per row a GEMM on the fp32 matrix pipe
+ *     when the sample's zero-bordered planes and the row of M fit the LDS (and OW >= 4), else a scalar kernel; the two
+ *     differ in summation order only (VIVIT_CONV_MFMA=0 selects the scalar kernels).
+ * The Linear rule is bound by the 4*rows*P bytes it writes.
  * ------------------------------------------------------------------------------------------- */
 int vivit_linear_weight_mjp_f32(const float *s, const float *z, float *V, int64_t C, int64_t N, int64_t O, int64_t I,
                                 void *stream);
@@ -178,7 +180,9 @@ int vivit_avgpool2d_jac_t_f32(const float *M, float *out, int64_t rows_planes, i
                               int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, void *stream);
 /* Conv2d (groups = 1, zero padding): out[r, ci, h, w] = sum_{co, a, b} M[r, co, oh, ow] weight[co, ci, a, b] with
  * oh sh - ph + a dh = h, ow sw - pw + b dw = w  (the transposed convolution; base.py:19 with Conv2DDerivatives,
- * convnd.py:17-22).  rows = V * N. */
+ * convnd.py:17-22).  rows = V * N.  Filter slices of up to Cout*KH*KW = 1024 run on a scalar kernel (16 input channels per
+ * thread, the slice in LDS), larger ones as a per-row GEMM on the fp32 matrix pipe (output channels in chunks that fit the
+ * LDS next to the zero-inserted planes of M); VIVIT_E_UNSUPPORTED when neither applies. */
 int vivit_conv2d_jac_t_f32(const float *M, const float *weight, float *out, int64_t rows, int64_t Cin, int64_t H, int64_t W,
                            int64_t Cout, int64_t KH, int64_t KW, int64_t OH, int64_t OW, int64_t sh, int64_t sw, int64_t ph,
                            int64_t pw, int64_t dh, int64_t dw, void *stream);

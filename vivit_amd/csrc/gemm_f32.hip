@@ -2160,13 +2160,24 @@ static int bx_flush_internal() { static int ft = -1; if (ft < 0) ft = bx_env_til
 static int bx_flush_splitk() { static int ft = -1; if (ft < 0) ft = bx_env_tiles("VIVIT_BX_FLUSH_SPLITK", 1024); return ft; }
 
 // columns of an operand split at a time (workspace: 6 bytes per element of the chunk and operand)
-static int64_t bx_chunk_cols(int64_t K) {
-  static int64_t kc = -1;
-  if (kc < 0) { const char *e = getenv("VIVIT_GEMM_SPLIT_KC"); kc = e ? atoll(e) : 65536; kc = kc / 16 * 16; if (kc < 16) kc = 16; }
+// Public products (the Gram SYRKs of the caller) take ONE accumulation chain per launch (round 4): 4096 columns instead of
+// 65 536 made the headline Gram build 3-4 % faster on four boxes (2.78-2.80 -> 2.67-2.71 s; 32 768: - 1.5 %, 16 384: - 2.5 %,
+// 6144 = a chain and a half: worse than either neighbour, 2048: + 5 %) -- no flush in the middle of a launch, and the
+// workgroups of an XCD start every chain together again (they drift apart by whole tiles otherwise, which is what the
+// re-fetch traffic of section 4.1b pays for).  The eigensolver's internal products keep 65 536 (their step was 12 ms
+// slower with the short chunks).  VIVIT_GEMM_SPLIT_KC sets both.
+static int64_t bx_chunk_cols(int64_t K, bool pub) {
+  static int64_t kc_env = -2;
+  if (kc_env == -2) {
+    const char *e = getenv("VIVIT_GEMM_SPLIT_KC");
+    kc_env = e ? atoll(e) / 16 * 16 : -1;
+    if (e && kc_env < 16) kc_env = 16;
+  }
+  const int64_t kc = kc_env > 0 ? kc_env : (pub ? (int64_t)bx_flush_tiles() * BK : 65536);
   return K < kc ? K : kc;
 }
 static size_t bx_piece_bytes(int64_t M, int64_t N, int64_t K, bool same) {
-  const int64_t kc = bx_chunk_cols(K);
+  const int64_t kc = bx_chunk_cols(K, false);   // (the larger of the two: the query does not know the caller)
   const int64_t ra = cdiv(M, 32) * 32, rb = cdiv(N, 32) * 32;
   return (size_t)6 * (size_t)kc * (size_t)(same ? ra : ra + rb);
 }
@@ -2182,7 +2193,7 @@ static size_t bx_sync_ints(int64_t M, int64_t N) {   // upper bound of 8 x (numb
   return (size_t)8 * (size_t)(tm * tn / 256 + tm + tn + 2);
 }
 static size_t bx_workspace_bytes(int64_t M, int64_t N, int64_t K, bool same) {
-  const size_t nch = (size_t)cdiv(K, bx_chunk_cols(K));
+  const size_t nch = (size_t)cdiv(K, bx_chunk_cols(K, true));   // (the larger of the two counts)
   return bx_piece_bytes(M, N, K, same) + 256 + 4 * nch + 256 + (bx_sync_enabled() ? 4 * nch * bx_sync_ints(M, N) + 256 : 0);
 }
 
@@ -2261,7 +2272,7 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
     // fp32 product on the bf16 pipe: K in chunks of BX_KC columns, per chunk the operand pieces (bx_split_kernel)
     // and one pure-bf16 launch that accumulates into C (beta = 1 from the second chunk on)
     const bool same = p.A == p.B && p.lda == p.ldb && p.M == p.N && alay == blay;
-    const int64_t kc_max = bx_chunk_cols(p.K);
+    const int64_t kc_max = bx_chunk_cols(p.K, bx_public_product());
     const int64_t nrbA = cdiv(p.M, 32), nrbB = cdiv(p.N, 32);
     unsigned short *PA = static_cast<unsigned short *>(workspace);
     const int64_t strideA = nrbA * 32 * kc_max, strideB = nrbB * 32 * kc_max;

@@ -43,14 +43,18 @@ SYRK_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * 3695931059.375 + 2766
 # launches of gemm256_bx_kernel<6> + 7 of bx_split_kernel, summed; the in-loop chain flushes add the Gram matrix's own
 # read-modify-write traffic: 6.16 TB fetched / 0.61 TB written; with 512-k chains on the diagonal tiles it was 7.74 / 0.66,
 # round 2 on 8192-k chains: 5.97 / 0.27)
-SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.975917e9 + 3.2229e7) + (5.02774e8 + 9.6339e7)) * 1024.0}
+# Round 4 (profiles/r04_pmc/pmc_syrk_*, final code: one 4096-column chain per launch, 98 launches of each kernel): 4.76 TB
+# fetched / 0.83 TB written -- the workgroups of an XCD start every chain together and share their operand panels again.
+SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.2943e9 + 3.2241e7) + (7.1264e8 + 9.6339e7)) * 1024.0}
 # clock the chip holds under that kernel, measured OUTSIDE this process (the product library carries no stamps):
 # in-kernel s_memtime / s_memrealtime stamps of a diagnostic build (scripts/probe/bx_clock.py + libstamp.so, median over
 # the 12 880 workgroups of the last chunk launch after 6 s of back-to-back SYRKs on the bench's own factors;
 # profiles/r03_pmc/v3_bx_clock_real.txt) and GRBM_GUI_ACTIVE / 8 / duration of the PMC pass on N(0,1) data
+# (round 4, profiles/r04_pmc/pmc_syrk_mfma_*: GRBM_GUI_ACTIVE 4.1806e10 / 8 over 2.986 s of gemm256_bx_kernel on N(0,1) data,
+# SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs; the in-kernel stamps are round 3's)
 SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors": 1.862, "in_kernel_stamps_randn": 1.725,
-                                                  "pmc_grbm_gui_active_randn": 1.771, "nominal": 2.4,
-                                                  "mfma_pipe_busy_pmc": 0.728}}
+                                                  "pmc_grbm_gui_active_randn": 1.750, "nominal": 2.4,
+                                                  "mfma_pipe_busy_pmc": 0.742}}
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
 MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 MFMA peak (256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz; same guide)
 
@@ -784,11 +788,11 @@ def main():
                     "issued_bf16_tflops": achieved * split,
                     "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
                     "traffic": SYRK_BX_TRAFFIC_BYTES_PMC.get((args.workload, world)) if split == 6 else None,
-                    "traffic_note": "bytes of the first-layer weight's SYRK (98.6 % of the Gram flops: split pass + 7 chunk launches), "
-                                    "separate rocprofv3 --pmc passes (profiles/r03_pmc), FETCH_SIZE includes Infinity-Cache hits",
+                    "traffic_note": "bytes of the first-layer weight's SYRK (98.6 % of the Gram flops: 98 split + 98 product launches of "
+                                    "4096 columns), separate rocprofv3 --pmc passes (profiles/r04_pmc), FETCH_SIZE includes Infinity-Cache hits",
                     "clock_ghz": SYRK_BX_CLOCK_GHZ.get((args.workload, world)) if split == 6 else None,
-                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.73) x (clock / 2.4 GHz); "
-                                  "measured with a diagnostic build and a PMC pass, not in this run (profiles/r03_pmc)",
+                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.74) x (clock / 2.4 GHz); "
+                                  "measured with a diagnostic build (profiles/r03_pmc) and a PMC pass (profiles/r04_pmc), not in this run",
                 }
             roofline.update({
                 "launches_sampled": int(syrk_cnt), "avg_launch_ms": syrk_ms / max(syrk_cnt, 1),

@@ -43,7 +43,7 @@ def case_syrk256_k65552():
 
 
 def case_syrk256_k401408():
-    # the headline contraction length: seven 65 536-column chunks, 98 chain flushes per tile
+    # the headline contraction length: 98 launches of one 4096-column chain each, every one added into C by atomics
     return sha(kernels.gram_syrk(factor(5120, 401408, 2)))
 
 
@@ -80,6 +80,28 @@ def case_symeig_reduce_select():
     idx = torch.tensor([0, 17, 4000, 4090, 4099], device=DEV, dtype=torch.int32)
     Zt = plan.select(idx)
     return sha(plan.evals, Zt)
+
+
+def case_panel_product_bx():
+    # the band reduction's 64-row streaming product on the bf16 pipe: split-K slab (fixed-order reduce), an odd number of K
+    # tiles per split, chains closed in registers
+    A, B = factor(64, 6160, 8), factor(6160, 2560, 9)
+    return sha(kernels.gemm_nn(A, B))
+
+
+def case_conv_rules():
+    # convolution weight rule on the matrix pipe (split position range with the fixed-order LDS reduction: 16 -> 16 @ 32 x 32)
+    # and the input rules (scalar kernel; the matrix-pipe kernel with a split contraction for 160 output channels)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(6, 16, 32, 32, generator=g, device=DEV)
+    M = torch.randn(2, 6, 16, 32, 32, generator=g, device=DEV)
+    w = torch.randn(16, 16, 3, 3, generator=g, device=DEV)
+    a = kernels.conv2d_weight_mjp(M, x, (3, 3), (1, 1), (1, 1), (1, 1))
+    b = kernels.conv2d_jac_t(M, w, (32, 32), (1, 1), (1, 1), (1, 1))
+    M2 = torch.randn(2, 6, 160, 8, 8, generator=g, device=DEV)
+    w2 = torch.randn(160, 24, 3, 3, generator=g, device=DEV)
+    c = kernels.conv2d_jac_t(M2, w2, (8, 8), (1, 1), (1, 1), (1, 1))
+    return sha(a, b, c)
 
 
 CASES = {k[5:]: v for k, v in globals().items() if k.startswith("case_")}

@@ -2176,8 +2176,11 @@ static int64_t bx_chunk_cols(int64_t K, bool pub) {
   const int64_t kc = kc_env > 0 ? kc_env : (pub ? (int64_t)bx_flush_tiles() * BK : 65536);
   return K < kc ? K : kc;
 }
+static bool bx_public_product();
 static size_t bx_piece_bytes(int64_t M, int64_t N, int64_t K, bool same) {
-  const int64_t kc = bx_chunk_cols(K, false);   // (the larger of the two: the query does not know the caller)
+  // (the public workspace queries run inside a BxStrictScope like the public launches: 1 GB of pieces instead of 16 GB at
+  // n = 40 960; the eigensolver's own queries and launches see the long chunk)
+  const int64_t kc = bx_chunk_cols(K, bx_public_product());
   const int64_t ra = cdiv(M, 32) * 32, rb = cdiv(N, 32) * 32;
   return (size_t)6 * (size_t)kc * (size_t)(same ? ra : ra + rb);
 }
@@ -2826,7 +2829,10 @@ int vivit_gemm_split_mode(void) { return gemm_split_mode(); }
 static size_t syrk_diag_bytes(int64_t n) { return align_up(sizeof(float) * (size_t)n, 256) + 256; }
 constexpr int64_t SYRK_DIAG_MIN_K = 1024;   // below: the product's own diagonal (chains never end; nothing to fix)
 
-size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p) { return gemm_workspace_bytes(n, n, p, true) + syrk_diag_bytes(n); }
+size_t vivit_gram_syrk_f32_workspace_bytes(int64_t n, int64_t p) {
+  BxStrictScope strict;   // sized for the public launch (one accumulation chain per chunk of the operand pieces)
+  return gemm_workspace_bytes(n, n, p, true) + syrk_diag_bytes(n);
+}
 
 int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float *G, int64_t ldg, float alpha,
                         float beta, void *workspace, size_t workspace_bytes, void *stream) {
@@ -2849,6 +2855,7 @@ int vivit_gram_syrk_f32(const float *A, int64_t n, int64_t p, int64_t lda, float
 }
 
 size_t vivit_gemm_f32_workspace_bytes(int64_t m, int64_t n, int64_t k) {
+  BxStrictScope strict;   // sized for the public launch
   size_t b = gemm_workspace_bytes(m, n, k, false);
   if (skinny_applicable(m, n, k)) {
     const size_t sb = skinny_workspace_bytes(m, k, n);

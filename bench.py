@@ -153,9 +153,15 @@ def verify_gram(facs, G, num=128, seed=0, row_index=None):
 
 
 def verify_symeig(G, w, Z, block=4096):
-    """Size-independent properties of an eigendecomposition ``G = Z diag(w) Z^T`` (checker: torch matmuls on the
-    device): ascending order, trace and Frobenius identities, orthonormality and the eigen-residual over ALL
-    eigenvectors (the properties of test/linalg/test_eigh.py:123-144 of the reference)."""
+    """Size-independent properties of an eigendecomposition ``G = Z diag(w) Z^T`` (checker: torch fp64 matmuls on the
+    device, in slabs): ascending order, trace and Frobenius identities, and -- over ALL eigenvectors, every product
+    accumulated in fp64 -- the per-eigenpair 2-NORM residual ``max_i ||G z_i - w_i z_i||_2`` and the orthonormality
+    ``max |Z^T Z - I|`` (the properties of test/linalg/test_eigh.py:123-144 of the reference).
+
+    Why the 2-norm: for symmetric ``G`` and a unit vector ``z``, ``||G z - w z||_2 <= eps`` PROVES that an exact
+    eigenvalue of ``G`` lies within ``eps`` of ``w``.  ``residual_2norm_fp64 <= 1e-5 lambda_max`` is therefore BASELINE's
+    "eigenvalues within 1e-5 rel-err" (scoped by lambda_max as test/linalg/test_eigvalsh.py:55-60 scopes its rtol/atol),
+    for every one of the n eigenpairs; an entry-wise maximum would only bound that norm up to a factor sqrt(n)."""
     n = G.shape[0]
     lam = w[-1].item()
     out = {"ascending": bool((w[1:] >= w[:-1]).all()), "lambda_max": lam}
@@ -163,33 +169,36 @@ def verify_symeig(G, w, Z, block=4096):
     fro2 = sum((G[i:i + block].double() ** 2).sum().item() for i in range(0, n, block))
     out["fro_err"] = abs((w.double() ** 2).sum().item() - fro2) / fro2
     if Z is not None:
-        orth, res = 0.0, 0.0
+        wd = w.double()
+        res2 = res_inf = orth = 0.0
+        orth_sq, norm_dev = 0.0, 0.0
         for i in range(0, n, block):
-            Zi = Z[:, i:i + block]
-            gram = Z.T @ Zi
-            gram[i:i + Zi.shape[1]] -= torch.eye(Zi.shape[1], device=G.device)
-            orth = max(orth, gram.abs().max().item())
-            r = G @ Zi - Zi * w[i:i + block]
-            res = max(res, r.abs().max().item())
-            del gram, r
-        out["residual_err"] = res / lam
-        # Orthonormality is measured with fp64 ACCUMULATION on 256 sampled eigenvectors against all n (2.1e7 entries of
-        # Z^T Z - I): the fp32 matmul of the checker above carries its own error over n = 4e4 terms -- round 4 measured
-        # 8.4e-5 with it where the fp64 accumulation of the same entries gives 2.3e-6 (rms 6.9e-8; the noise scale of an
-        # fp32 eigensolver is sqrt(n) eps = 1.2e-5).  `orth_err` is the fp64 figure; the fp32 whole-matrix figure stays as
-        # `orth_err_fp32_checker` with its own, looser bound (it still catches a wrong eigenvector anywhere in Z).
-        g = torch.Generator().manual_seed(0)
-        cols = torch.randperm(n, generator=g)[:256].to(G.device)
-        Zc = Z[:, cols].double()
-        acc = torch.zeros((n, cols.numel()), dtype=torch.float64, device=G.device)
-        for i in range(0, n, block):
-            acc += Z[i:i + block].double().T @ Zc[i:i + block]
-        acc[cols, torch.arange(cols.numel(), device=G.device)] -= 1.0
-        out["orth_err"] = acc.abs().max().item()
-        out["orth_rms"] = acc.pow(2).mean().sqrt().item()
-        out["orth_err_fp32_checker"] = orth
+            Zi = Z[:, i:i + block].double()                      # [n, b] column slab of the eigenvectors, promoted once
+            b = Zi.shape[1]
+            R = torch.empty((n, b), dtype=torch.float64, device=G.device)
+            for r in range(0, n, block):                         # G promoted to fp64 slab by slab
+                R[r:r + block] = G[r:r + block].double() @ Zi
+            R -= Zi * wd[i:i + b]
+            cn = Zi.norm(dim=0)
+            norm_dev = max(norm_dev, (cn - 1).abs().max().item())
+            res2 = max(res2, (R.norm(dim=0) / cn).max().item())
+            res_inf = max(res_inf, R.abs().max().item())
+            del R
+            for r in range(i, n, block):                         # Z^T Z - I, upper block triangle (it is symmetric)
+                S = Z[:, r:r + block].double().T @ Zi
+                if r == i:
+                    S.diagonal().sub_(1.0)
+                orth = max(orth, S.abs().max().item())
+                orth_sq += (1.0 if r == i else 2.0) * S.pow(2).sum().item()
+                del S
+            del Zi
+        out["residual_2norm_fp64"] = res2 / lam
+        out["residual_err"] = res_inf / lam
+        out["orth_err"] = orth
+        out["orth_rms"] = (orth_sq / float(n) ** 2) ** 0.5
+        out["norm_err"] = norm_dev
         out["orth_noise_scale_sqrt_n_eps"] = float(n) ** 0.5 * 2.0 ** -24
-        del acc, Zc
+        out["checker"] = "fp64 accumulation over all n eigenvectors (G and Z promoted slab by slab)"
     return out
 
 
@@ -197,8 +206,10 @@ def verify_symeig(G, w, Z, block=4096):
 # entries: fp32 contraction of length 4e5 with two accumulation levels, relative to sqrt(G_ii G_jj) (measured with
 # the fp32 MFMA kernel / the bf16-pipe kernel: 1.3e-6 / 2.6e-6 off the diagonal, 2.5e-6 / 3.7e-6 on it where all terms
 # are positive and rounding cannot cancel, 3.5e-7 / 1.2e-6 for the trace)
+# residual_2norm_fp64: BASELINE's 1e-5 eigenvalue tolerance, literally (see verify_symeig); residual_err is the entry-wise
+# maximum of the same fp64 residual (<= the 2-norm); orth_err: all of Z^T Z - I in fp64 (round 4 sampled 256 columns)
 VERIFY_BOUNDS = {"entry_err": 5e-6, "diag_err": 1e-5, "trace_err": 4e-6, "eig_trace_err": 1e-5, "fro_err": 1e-4,
-                 "orth_err": 2e-5, "orth_err_fp32_checker": 2e-4, "residual_err": 3e-5}
+                 "orth_err": 2e-5, "residual_err": 1e-5, "residual_2norm_fp64": 1e-5}
 
 
 def verified_ok(vg, ve):
@@ -207,7 +218,7 @@ def verified_ok(vg, ve):
     ok = ok and ve["trace_err"] <= VERIFY_BOUNDS["eig_trace_err"] and ve["fro_err"] <= VERIFY_BOUNDS["fro_err"]
     if "orth_err" in ve:
         ok = ok and ve["orth_err"] <= VERIFY_BOUNDS["orth_err"] and ve["residual_err"] <= VERIFY_BOUNDS["residual_err"]
-        ok = ok and ve["orth_err_fp32_checker"] <= VERIFY_BOUNDS["orth_err_fp32_checker"]
+        ok = ok and ve["residual_2norm_fp64"] <= VERIFY_BOUNDS["residual_2norm_fp64"]
     return bool(ok)
 
 
@@ -394,11 +405,44 @@ def _spawn_ranks(nranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+        # (own process group per child: the watchdog below can end a rank together with anything it started)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True))
+    return _watch_ranks(procs)
+
+
+def _watch_ranks(procs, poll_s=0.5, grace_s=20.0):
+    """Watchdog of the self-spawned ranks: poll ALL children; as soon as one exits non-zero (out of memory, RCCL
+    initialisation, an assertion) the others -- who would sit in a collective until the driver's timeout -- are
+    terminated (SIGTERM to their process groups, SIGKILL after ``grace_s``) and the launcher exits non-zero.  Only the
+    fresh children are ever signalled, by the PIDs this launcher created."""
+    import signal
+
+    def end(p, sig):
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                pass
+
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad and failed is None:
+            failed = bad[0]
+            print(f"[bench] rank {failed[0]} exited with code {failed[1]}: terminating the other ranks", file=sys.stderr, flush=True)
+            for p in procs:
+                end(p, signal.SIGTERM)
+            deadline = time.monotonic() + grace_s
+        if all(c is not None for c in codes):
+            break
+        if failed is not None and time.monotonic() > deadline:
+            for p in procs:
+                end(p, signal.SIGKILL)
+        time.sleep(poll_s)
+    if failed is not None:
+        return abs(failed[1]) or 1
+    return 0
 
 
 def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
@@ -633,12 +677,14 @@ def main():
             _progress("verify: eigendecomposition of the rebuilt Gram matrix done, checking its properties")
         ve = verify_symeig(Gv, wv, Zv)
         if rank == 0:
-            _progress(f"verify: residual {ve.get('residual_err', float('nan')):.2e}, orthonormality {ve.get('orth_err', float('nan')):.2e}")
+            _progress(f"verify: fp64 2-norm residual {ve.get('residual_2norm_fp64', float('nan')):.2e} lambda_max, "
+                      f"orthonormality {ve.get('orth_err', float('nan')):.2e}")
         ve["trace_err_eig"] = ve.pop("trace_err")
         verified = {"ok": verified_ok(vg, dict(ve, trace_err=ve["trace_err_eig"])), "gram": vg, "symeig": ve,
                     "bounds": VERIFY_BOUNDS,
                     "how": "sampled Gram entries (all tile classes) vs fp64 dot products, exact symmetry, trace; ascending "
-                           "order, trace/Frobenius identities, orthonormality and eigen-residual over all eigenvectors"}
+                           "order, trace/Frobenius identities; over ALL eigenvectors with fp64 accumulation: per-eigenpair 2-norm "
+                           "residual max_i ||G z_i - w_i z_i||_2 / lambda_max (bounds every eigenvalue's error) and max |Z^T Z - I|"}
         del Gv, wv, Zv
 
     secondary_lines = None

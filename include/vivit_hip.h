@@ -16,8 +16,9 @@
  *     caller through (workspace, workspace_bytes) sized by the matching *_workspace_bytes query;
  *   - return value: 0 = ok; <0 = bad argument (VIVIT_E_*); a numerical failure of the
  *     eigensolver is reported asynchronously through the device-side `info` word
- *     (0 = converged, k>0 = k off-diagonal elements did not converge), which the host maps to
- *     the reference's RuntimeError (vivit/utils/eig.py:37-40,103-106);
+ *     (0 = converged, k>0 = k off-diagonal elements did not converge; n = non-finite input), which the host maps
+ *     to the reference's RuntimeError (vivit/utils/eig.py:37-40,103-106).  VIVIT_INFO_PERSIST_TIMEOUT (< 0) is a
+ *     failure of a different kind -- see "Persistent kernels" below;
  *   - results are deterministic (bit-identical from call to call and from process to process on the same device
  *     type; tests/test_determinism_gpu.py): every reduction has a fixed order.  The one kernel that uses float
  *     atomics, the bf16-pipe 256 x 256 tile product, adds the partial sum of each 4096-k accumulation chain into C
@@ -41,9 +42,35 @@ extern "C" {
 #define VIVIT_E_LAUNCH (-3)     /* hipLaunch reported an error (hipGetLastError != success) */
 #define VIVIT_E_UNSUPPORTED (-4)
 
+/* ---------------------------------------------------------------------------------------------
+ * Persistent kernels.  Three stages of the eigensolver run as ONE launch whose workgroups exchange data through the
+ * L2 and therefore must all be resident at once: the tridiagonalisation for n <= 2048 (sytrd_persist.hip), the panel QR
+ * of the band reduction (sy2sb.hip) and the bulge chase (sb2st.hip).  Whether they are is decided once per launch by an
+ * atomic arrival gate BEFORE anything is written; a launch that does not become resident within 2 s (another process or
+ * a long-running kernel of another stream holds its compute units) aborts untouched and ONE retry queued behind it
+ * runs.  If that fails too -- or an exchange stalls later -- the stage gives up, the solve's `info` word becomes
+ * VIVIT_INFO_PERSIST_TIMEOUT (its results are garbage) and the library stays usable.  This status is distinct from the
+ * numerical ones: the input may be perfectly fine.  The host wrapper (vivit_amd/kernels.py) raises
+ * PersistentKernelTimeout and, when it still holds the input, repeats the solve ONCE with vivit_persistent_kernels(0),
+ * i.e. on the launch chains (VIVIT_SYTRD_PERSIST / VIVIT_QR_PERSIST / VIVIT_SB2ST_PERSIST = 0 select them for good).
+ * ------------------------------------------------------------------------------------------- */
+#define VIVIT_INFO_PERSIST_TIMEOUT (-1000)
+/* 1 / 0: allow / forbid the persistent kernels for the following calls of this process (overrides the environment
+ * variables); -1: back to the environment's choice.  Returns the previous setting (-1, 0 or 1).  Host-side state only. */
+int vivit_persistent_kernels(int on);
+/* For callers of the STAGE-level entry points (vivit_sytrd_f32, vivit_sy2sb_f32, vivit_sy2sb_panel_qr_f32,
+ * vivit_sb2st_f32), which have no info word: *info (device) = VIVIT_INFO_PERSIST_TIMEOUT if a persistent kernel gave up
+ * since the failure word was last taken, and clears the word; *info is left alone otherwise.  The vivit_symeig*_f32 entry
+ * points do this themselves.  (A stage that gave up also poisons its output with NaN, so nothing fails silently.) */
+int vivit_take_persist_timeout(int32_t *info, void *stream);
+
 /* Library/ABI version (major*1000 + minor) and the gfx target it was compiled for. */
-int vivit_hip_abi_version(void);   /* 1006 in this release; _lib.py refuses any other library */
+int vivit_hip_abi_version(void);   /* 1007 in this release; _lib.py refuses any other library */
 const char *vivit_hip_target(void);
+/* Provenance: the content hash (32 hex digits, vivit_amd/_build.py:source_hash) of the csrc/ tree + this header the library
+ * was compiled from ("unknown" for a build that did not go through _build.py).  _lib.load() compares it with the sources
+ * beside the package and refuses a stale binary. */
+const char *vivit_hip_source_hash(void);
 const char *vivit_hip_status_string(int status);
 
 /* ---------------------------------------------------------------------------------------------

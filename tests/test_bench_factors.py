@@ -46,3 +46,24 @@ def test_bench_factors_batch_shard_rows():
     for f, p in zip(full, part):
         expect = f.view(C, batch, -1)[:, lo:hi].reshape(C * (hi - lo), -1)
         torch.testing.assert_close(p, expect, rtol=1e-5, atol=1e-8)  # (S @ W2 is blocked differently on a slice)
+
+
+def test_rank_watchdog_ends_the_survivors_when_one_rank_dies():
+    """bench._watch_ranks (the bare `--gpus N` launcher): a rank that exits non-zero must not leave the others blocked in a
+    collective until the driver's timeout -- they are terminated and the launcher reports the failure."""
+    import subprocess
+    import sys
+    import time
+
+    sleeper = "import time; time.sleep(600)"
+    procs = [subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(3)"], start_new_session=True),
+             subprocess.Popen([sys.executable, "-c", sleeper], start_new_session=True),
+             subprocess.Popen([sys.executable, "-c", sleeper], start_new_session=True)]
+    t0 = time.monotonic()
+    rc = bench._watch_ranks(procs, poll_s=0.1, grace_s=5.0)
+    assert rc == 3
+    assert time.monotonic() - t0 < 30
+    assert all(p.poll() is not None for p in procs)
+    # all ranks fine -> 0
+    ok = [subprocess.Popen([sys.executable, "-c", "pass"], start_new_session=True) for _ in range(2)]
+    assert bench._watch_ranks(ok, poll_s=0.1) == 0

@@ -1,46 +1,47 @@
-"""BASELINE-size (n = 40 960) run of Gram build + symeig, checked through size-independent properties
-(the oracle cannot run at this size in seconds): ascending order, trace and Frobenius identities,
-orthonormality, the eigen-residual, agreement of the two solver flavours.  torch matmuls on the device are
-used only as the checker."""
+"""BASELINE-size runs of Gram build + symeig (n up to 40 960), checked through size-independent properties -- the oracle
+cannot run at these sizes in seconds: ascending order, trace and Frobenius identities, agreement of the two solver flavours,
+and, over ALL eigenvectors with fp64 accumulation (``bench.verify_symeig``), the per-eigenpair 2-NORM residual
+``max_i ||G z_i - w_i z_i||_2 <= 1e-5 lambda_max`` -- which proves every eigenvalue within BASELINE's 1e-5 of an exact one
+(scope of test/linalg/test_eigvalsh.py:55-60 of the reference) -- and ``max |Z^T Z - I|``.
+
+Sizes: the Gram sizes of BASELINE configs 2 / 3 / 5 (40 960 / 20 480 / 32 768) with GGN-like, numerically rank-deficient
+spectra, and ODD sizes (n % 4 != 0 takes the block-step Q2 kernels -- the sliding-window kernel needs 16-byte rows --, n not
+a multiple of the 64-wide panels / 256-wide tiles: ragged last panels, tiles and slabs everywhere; round 4 covered them with
+a probe script only)."""
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+import bench
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
 
 
-@pytest.mark.parametrize("n,p", [(8192, 4096), (40960, 6144)])
+@pytest.mark.parametrize("n,p", [(8192, 4096), (12289, 3000), (16100, 20000), (20001, 5000), (20480, 10164), (32768, 8192),
+                                 (40960, 6144)])
 def test_gram_symeig_properties_fullsize(n, p):
     from vivit_amd import kernels
 
     dev = torch.device("cuda:0")
     free, _ = torch.cuda.mem_get_info()
-    if free < 6 * n * n * 4 + n * p * 4 + (8 << 30):
+    if free < 7 * n * n * 4 + n * p * 4 + (10 << 30):
         pytest.skip("not enough free HBM for the full-size property test")
     g = torch.Generator(device=dev).manual_seed(n)
-    # decaying column scales: a GGN-like spectrum with a numerically rank-deficient tail (rank <= p < n)
-    V = torch.randn(n, p, device=dev, generator=g) * (0.999 ** torch.arange(p, device=dev))
+    # decaying column scales: a GGN-like spectrum with a numerically rank-deficient tail (rank <= p when p < n)
+    V = torch.randn(n, p, device=dev, generator=g) * (0.999 ** torch.arange(p, device=dev)).clamp_min(1e-3)
     G = kernels.gram_syrk(V)
     del V
     assert torch.equal(G, G.T)
     w_only, _ = kernels.symeig(G, eigenvectors=False)
     w, Z = kernels.symeig(G, eigenvectors=True)
-    lam_max = w[-1].item()
-    assert lam_max > 0
-    assert bool((w[1:] >= w[:-1]).all()), "eigenvalues must be ascending"
-    assert (w - w_only).abs().max().item() <= 1e-5 * lam_max          # D&C vs bisection
-    assert abs(w.double().sum().item() - G.diagonal().double().sum().item()) <= 1e-5 * n ** 0.5 * lam_max
-    fro2 = (G.double() ** 2).sum().item() if n <= 8192 else sum((G[i : i + 4096].double() ** 2).sum().item() for i in range(0, n, 4096))
-    assert abs((w.double() ** 2).sum().item() - fro2) <= 1e-4 * fro2
-    # orthonormality and residual, in row blocks of Z^T to bound the checker's memory
-    worst_orth, worst_res = 0.0, 0.0
-    B = 4096
-    for i in range(0, n, B):
-        Zi = Z[:, i : i + B]                                  # eigenvectors i .. i+B
-        gram = Z.T @ Zi                                       # [n, B]
-        gram[i : i + Zi.shape[1]] -= torch.eye(Zi.shape[1], device=dev)
-        worst_orth = max(worst_orth, gram.abs().max().item())
-        res = G @ Zi - Zi * w[i : i + B]
-        worst_res = max(worst_res, res.abs().max().item())
-        del gram, res
-    assert worst_orth <= 1e-4, worst_orth
-    assert worst_res <= 3e-5 * lam_max, worst_res / lam_max
+    ve = bench.verify_symeig(G, w, Z)
+    print(n, p, ve)
+    lam_max = ve["lambda_max"]
+    assert lam_max > 0 and ve["ascending"]
+    assert (w - w_only).abs().max().item() <= 1e-5 * lam_max          # D&C vs Sturm multisection
+    assert ve["trace_err"] <= bench.VERIFY_BOUNDS["eig_trace_err"], ve
+    assert ve["fro_err"] <= bench.VERIFY_BOUNDS["fro_err"], ve
+    assert ve["orth_err"] <= bench.VERIFY_BOUNDS["orth_err"], ve
+    assert ve["norm_err"] <= 1e-5, ve
+    assert ve["residual_2norm_fp64"] <= 1e-5, ve                      # BASELINE's eigenvalue tolerance, literally
+    if p < n:   # beyond the rank: rounding noise only
+        assert w[: n - p].abs().max().item() <= 1e-5 * lam_max

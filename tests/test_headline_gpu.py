@@ -43,8 +43,10 @@ def test_headline_gram_and_symeig(workload):
     assert (w - w_only).abs().max().item() <= 1e-5 * ve["lambda_max"]   # D&C against Sturm multisection
     assert ve["trace_err"] <= bench.VERIFY_BOUNDS["eig_trace_err"], ve
     assert ve["fro_err"] <= bench.VERIFY_BOUNDS["fro_err"], ve
-    assert ve["orth_err"] <= bench.VERIFY_BOUNDS["orth_err"], ve                       # fp64 accumulation, 256 sampled eigenvectors
-    assert ve["orth_err_fp32_checker"] <= bench.VERIFY_BOUNDS["orth_err_fp32_checker"], ve   # all of Z^T Z, fp32 matmul
+    assert ve["orth_err"] <= bench.VERIFY_BOUNDS["orth_err"], ve                       # all of Z^T Z - I, fp64 accumulation
     assert ve["residual_err"] <= bench.VERIFY_BOUNDS["residual_err"], ve
+    # BASELINE's tolerance, literally: max_i ||G z_i - w_i z_i||_2 <= 1e-5 lambda_max in fp64 => every eigenvalue has an exact
+    # eigenvalue of G within 1e-5 lambda_max (the scope of test/linalg/test_eigvalsh.py:55-60)
+    assert ve["residual_2norm_fp64"] <= bench.VERIFY_BOUNDS["residual_2norm_fp64"] == 1e-5, ve
     # the GGN of a C-class cross-entropy model has rank <= N (C - 1): the bottom N eigenvalues are rounding noise
     assert w[:batch].abs().max().item() <= 1e-5 * ve["lambda_max"]

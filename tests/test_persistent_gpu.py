@@ -36,7 +36,10 @@ def _child(tmp, tag, **env):
 def runs(tmp_path_factory):
     tmp = tmp_path_factory.mktemp("persist")
     return {"on": _child(tmp, "on", VIVIT_SB2ST_PERSIST="1", VIVIT_SYTRD_PERSIST="1", VIVIT_QR_PERSIST="1"),
-            "off": _child(tmp, "off", VIVIT_SB2ST_PERSIST="0", VIVIT_SYTRD_PERSIST="0", VIVIT_QR_PERSIST="0")}
+            "off": _child(tmp, "off", VIVIT_SB2ST_PERSIST="0", VIVIT_SYTRD_PERSIST="0", VIVIT_QR_PERSIST="0"),
+            # the first attempt of every arrival gate gives up at once: the retry queued behind it does the work
+            "retry": _child(tmp, "retry", VIVIT_SB2ST_PERSIST="1", VIVIT_SYTRD_PERSIST="1", VIVIT_QR_PERSIST="1",
+                            VIVIT_PERSIST_FAULT="1")}
 
 
 def test_sb2st_persistent_is_bit_identical_to_the_launch_chain(runs):
@@ -83,3 +86,29 @@ def test_panel_qr_persistent_band(runs, n):
     assert float((res["on"]["AB"] - res["off"]["AB"]).abs().max()) <= 1e-4 * scale
     assert float((res["on"]["tau1"] - res["off"]["tau1"]).abs().max()) <= 2e-3
     assert not torch.equal(res["on"]["AB"], res["off"]["AB"])   # (the knob did select another kernel)
+
+
+def test_aborted_first_attempt_is_retried_on_the_device(runs):
+    """VIVIT_PERSIST_FAULT=1: attempt 0 of every persistent kernel aborts at its arrival gate (nothing written), the second
+    launch queued behind it runs: every output is BIT-identical to the undisturbed run."""
+    assert runs["retry"]["sb2st"] == runs["on"]["sb2st"]
+    assert runs["retry"]["sytrd"] == runs["on"]["sytrd"]
+    for n in runs["on"]["sy2sb"]:
+        a, b = torch.load(runs["on"]["sy2sb"][n]), torch.load(runs["retry"]["sy2sb"][n])
+        assert torch.equal(a["AB"], b["AB"]) and torch.equal(a["tau1"], b["tau1"]), n
+
+
+def test_timeout_has_its_own_status_and_the_host_retries_on_the_launch_chains(tmp_path):
+    """VIVIT_PERSIST_FAULT=3: both attempts give up -> info = VIVIT_INFO_PERSIST_TIMEOUT (include/vivit_hip.h), not the
+    non-finite-input status; a solve that still has its input repeats itself on the launch chains (reference semantics
+    kept: the eigenvalues ``Tensor.symeig`` returns, vivit/utils/eig.py:35-46)."""
+    out = tmp_path / "fault.json"
+    subprocess.run([sys.executable, os.path.join(HERE, "persist_fault_child.py"), str(out)],
+                   env=dict(os.environ, VIVIT_PERSIST_FAULT="3"), check=True, timeout=600)
+    res = json.loads(out.read_text())
+    for n, row in res.items():
+        assert row["retry_warned"] and row["input_intact"], (n, row)
+        assert row["retry_eval_err"] <= 1e-5 and row["retry_residual"] <= 1e-5, (n, row)
+        assert row["raised"] == "PersistentKernelTimeout" and row["is_runtime_error"] and not row["message_says_converge"], (n, row)
+        assert row["backup_retry_warned"] and row["backup_eval_err"] <= 1e-5, (n, row)
+        assert row["after_eval_err"] <= 1e-5, (n, row)

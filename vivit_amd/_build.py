@@ -1,4 +1,12 @@
-"""Build libvivit_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()."""
+"""Build libvivit_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build().
+
+Provenance: the library exports ``vivit_hip_source_hash()`` = ``source_hash()`` of the tree it was compiled from
+(every file of csrc/ + include/vivit_hip.h, by CONTENT); ``_lib.load()`` refuses a library whose hash differs from
+the sources beside it, so a stale shipped binary cannot be tested by accident.  Objects are rebuilt when the content
+hash of (source, headers, flags) recorded beside them differs -- not by modification time.
+"""
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -22,10 +30,47 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _digest(paths, extra=()):
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def _headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "vivit_hip.h")]
+
+
+def source_hash():
+    """Content hash (32 hex digits) of everything the library is compiled from: csrc/*.hip, csrc/*.h and
+    include/vivit_hip.h.  None when the sources are not beside the package (a binary-only install)."""
+    hips = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    if not hips or not os.path.exists(os.path.join(HERE, "..", "include", "vivit_hip.h")):
+        return None
+    return _digest(hips + _headers())[:32]
+
+
+def _hash_define():
+    return '-DVIVIT_SOURCE_HASH="%s"' % source_hash()
+
+
+def _stamp_stale(obj, stamp):
+    """True when ``obj`` is missing or was not built from the inputs whose digest is ``stamp``."""
+    try:
+        with open(obj + ".stamp") as f:
+            return not os.path.exists(obj) or f.read().strip() != stamp
+    except OSError:
+        return True
+
+
 def build(force=False, verbose=True):
     """Compile every HIP source to an object, link the shared library. Returns the library path."""
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "device_utils.h", "eig_internal.h")] + [
-        os.path.join(HERE, "..", "include", "vivit_hip.h")]
+    headers = _headers()
     objdir = os.path.join(CSRC, "obj")
     os.makedirs(objdir, exist_ok=True)
     objs = []
@@ -34,22 +79,28 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+        # api.hip carries the hash of the whole tree (vivit_hip_source_hash), so it is recompiled on every change
+        flags = FLAGS + ([_hash_define()] if src == "api.hip" else [])
+        stamp = _digest([s] + headers, flags)
+        if force or _stamp_stale(o, stamp):
+            cmd = [_hipcc()] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            procs.append((src, o, stamp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
-    for src, p in procs:
+    for src, o, stamp, p in procs:
         out, _ = p.communicate()
         if out.strip() and verbose:
             print(out)
         if p.returncode != 0:
             failed = True
             print(f"hipcc failed on {src}", file=sys.stderr)
+        else:
+            with open(o + ".stamp", "w") as f:
+                f.write(stamp + "\n")
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    if force or _stale(LIB, objs):
+    if force or procs or _stale(LIB, objs):
         cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -74,22 +125,25 @@ def build_host_sanitized(verbose=False):
     os.makedirs(objdir, exist_ok=True)
     flags = ["-O1", "-g", "--offload-host-only", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
              "-fPIC", "-std=c++17", "-Wno-unused-function"]
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "device_utils.h", "eig_internal.h")] + [
-        os.path.join(HERE, "..", "include", "vivit_hip.h")]
+    headers = _headers()
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if _stale(o, [s] + headers):
-            procs.append((src, subprocess.Popen([_hipcc()] + flags + ["-c", s, "-o", o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, p in procs:
+        fl = flags + ([_hash_define()] if src == "api.hip" else [])
+        stamp = _digest([s] + headers, fl)
+        if _stamp_stale(o, stamp):
+            procs.append((src, o, stamp, subprocess.Popen([_hipcc()] + fl + ["-c", s, "-o", o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, o, stamp, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc (host sanitizer build) failed on {src}:\n{out}")
+        with open(o + ".stamp", "w") as f:
+            f.write(stamp + "\n")
         if verbose and out.strip():
             print(out)
-    if _stale(ASAN_LIB, objs):
+    if procs or _stale(ASAN_LIB, objs):
         # a host-only object still refers to its (absent) device fat binary: define each of those symbols as an EMPTY
         # clang offload bundle (magic + zero entries), which the HIP runtime registers and never finds a kernel in
         undef = subprocess.run(["nm", "-u"] + objs, stdout=subprocess.PIPE, text=True).stdout.split()

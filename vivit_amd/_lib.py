@@ -22,7 +22,10 @@ _int = ctypes.c_int
 SIGNATURES = {
     "vivit_hip_abi_version": (_int, []),
     "vivit_hip_target": (ctypes.c_char_p, []),
+    "vivit_hip_source_hash": (ctypes.c_char_p, []),
     "vivit_hip_status_string": (ctypes.c_char_p, [_int]),
+    "vivit_persistent_kernels": (_int, [_int]),
+    "vivit_take_persist_timeout": (_int, [_ptr, _ptr]),
     "vivit_gemm_split_mode": (_int, []),
     "vivit_gram_syrk_f32_workspace_bytes": (_sz, [_i64, _i64]),
     "vivit_gram_syrk_f32": (_int, [_ptr, _i64, _i64, _i64, _ptr, _i64, _f32, _f32, _ptr, _sz, _ptr]),
@@ -78,13 +81,14 @@ SIGNATURES = {
     "vivit_unpack_lower_f32": (_int, [_ptr, _i64, _ptr, _i64, _ptr]),
 }
 
-ABI_VERSION = 1006  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
+ABI_VERSION = 1007  # include/vivit_hip.h of this checkout (vivit_hip_abi_version)
 
 _lib = None
 
 
 # status codes of include/vivit_hip.h
 VIVIT_OK, VIVIT_E_BADARG, VIVIT_E_WORKSPACE, VIVIT_E_LAUNCH, VIVIT_E_UNSUPPORTED = 0, -1, -2, -3, -4
+VIVIT_INFO_PERSIST_TIMEOUT = -1000  # device-side info word: a persistent kernel gave up (include/vivit_hip.h)
 
 
 class VivitHipError(RuntimeError):
@@ -117,8 +121,29 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
+    _check_provenance(lib)
     _lib = lib
     return lib
+
+
+def _check_provenance(lib):
+    """The library must have been compiled from the sources beside this package (content hash, _build.source_hash):
+    a stale shipped binary is refused instead of being tested by accident.  VIVIT_HIP_ALLOW_STALE=1 turns the error into
+    a warning (bisecting with an old library); a binary-only install (no csrc/) has nothing to compare with."""
+    from . import _build
+
+    want = _build.source_hash()
+    have = lib.vivit_hip_source_hash().decode()
+    if want is None or have == want:
+        return
+    msg = (f"{LIB_PATH} was built from other sources (library hash {have}, source tree {want}): rebuild it "
+           "(`python -c 'import __graft_entry__ as g; g.build()'`)")
+    if os.environ.get("VIVIT_HIP_ALLOW_STALE") == "1":
+        import warnings
+
+        warnings.warn(msg)
+        return
+    raise ImportError(msg)
 
 
 def check(status, what):

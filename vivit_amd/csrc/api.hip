@@ -22,8 +22,13 @@ using namespace vivit;
 
 extern "C" {
 
-int vivit_hip_abi_version(void) { return 1006; }
+#ifndef VIVIT_SOURCE_HASH
+#define VIVIT_SOURCE_HASH "unknown"   // builds outside vivit_amd/_build.py (which passes the hash of the source tree)
+#endif
+
+int vivit_hip_abi_version(void) { return 1007; }
 const char *vivit_hip_target(void) { return "gfx950"; }
+const char *vivit_hip_source_hash(void) { return VIVIT_SOURCE_HASH; }
 
 const char *vivit_hip_status_string(int status) {
   switch (status) {

@@ -97,6 +97,16 @@ enum { PROF_STAGE_BEGIN = 0, PROF_STAGE_PREP = 1, PROF_STAGE_SY2SB = 2, PROF_STA
        PROF_STAGE_SY2SB_PP = 9, PROF_STAGE_SY2SB_UPD = 10, PROF_NUM_STAGES = 11 };
 void prof_mark(int stage, hipStream_t stream);
 
+// profile.hip: the persistent kernels' failure word (device memory of the CURRENT device, no allocation: a __device__
+// variable).  A persistent kernel that gave up (co-residency not reached in two attempts, or a stalled exchange) ORs its
+// PERSIST_TMO_* bit into it; the next info finalisation of an eigensolver call reports VIVIT_INFO_PERSIST_TIMEOUT and
+// clears it.  nullptr on failure of the symbol lookup.
+int *persist_timeout_word();
+// 1 / 0: persistent kernels allowed by vivit_persistent_kernels(); -1: no override (the environment variables decide)
+int persist_override();
+// VIVIT_PERSIST_FAULT (tests): bit a set = attempt a of every persistent kernel's arrival gate gives up at once
+int persist_fault();
+
 // Compute units of the current device (cached per device): the one-XCD persistent kernels (sytrd_persist.hip, the panel
 // QR of sy2sb.hip) need 32 co-resident workgroups of one per CU on XCD 0, i.e. an 8-XCD part with all 256 CUs visible.
 inline int device_cu_count() {

@@ -34,6 +34,34 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- arrival gate of the persistent kernels (sytrd_persist.hip, sy2sb.hip:qr_persist_kernel, sb2st.hip) --------------
+// Their workgroups exchange data through memory, so all `nwg` of them must be resident at once.  Whether they are is
+// decided ONCE, atomically, before anything is written: `count` collects arrivals, `state` goes 0 (open) -> 1 (go: the
+// last arriver) or -> 2 (abort: the first workgroup that waited `limit` ticks of s_memrealtime, 100 MHz) by compare-and-
+// swap, so every workgroup -- also one that is only dispatched after the others gave up -- reads the same verdict.  An
+// aborted attempt has touched nothing; the launcher runs the kernel a second time behind it (attempt 1, which returns at
+// once unless attempt 0 aborted), and only when that aborts too the solve fails with VIVIT_INFO_PERSIST_TIMEOUT.
+constexpr unsigned long long PERSIST_TIMEOUT_TICKS = 200000000ull;   // 2 s
+enum { PERSIST_OPEN = 0, PERSIST_GO = 1, PERSIST_ABORT = 2 };
+// bits of the sticky device word persist_timeout_word(): which persistent kernel gave up
+enum { PERSIST_TMO_SYTRD = 1, PERSIST_TMO_PANEL_QR = 2, PERSIST_TMO_SB2ST = 4 };
+
+__device__ __forceinline__ bool persist_arrive(int *count, int *state, int nwg, unsigned long long limit) {
+  const int mine = __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  int expect = PERSIST_OPEN;
+  if (mine == nwg)
+    __hip_atomic_compare_exchange_strong(state, &expect, PERSIST_GO, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  int st;
+  while ((st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == PERSIST_OPEN) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 >= limit) {
+      expect = PERSIST_OPEN;
+      __hip_atomic_compare_exchange_strong(state, &expect, PERSIST_ABORT, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return st == PERSIST_GO;
+}
+
 // Sum over the 64 lanes, identical in every lane: four DPP adds inside each row of 16 lanes (xor 1, xor 2, mirror in 8,
 // mirror in 16) and one readlane per row - about a tenth of the latency of the ds_bpermute butterfly.
 __device__ __forceinline__ float wave_sum_dpp(float v) {

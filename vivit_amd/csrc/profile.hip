@@ -1,6 +1,7 @@
 // Optional in-library kernel timing with HIP events (feeds bench.py's roofline block).
 // When enabled, the Gram SYRK launches and every `stride`-th symmetric matrix-vector launch of
 // the tridiagonalisation are bracketed by events on the stream they are launched on.
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -33,6 +34,40 @@ void prof_mark(int stage, hipStream_t stream) {
   if (hipEventCreate(&m.ev) != hipSuccess) return;
   (void)hipEventRecord(m.ev, stream);
   g_marks.push_back(m);
+}
+
+__device__ int g_persist_timeout = 0;
+
+int *persist_timeout_word() {
+  static int *cached[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  int *&p = cached[dev & 63];
+  if (!p) {
+    void *q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_persist_timeout)) != hipSuccess) return nullptr;
+    p = static_cast<int *>(q);
+  }
+  return p;
+}
+
+static int g_persist_override = -1;
+int persist_override() { return g_persist_override; }
+int persist_fault() {
+  static int f = -1;
+  if (f < 0) {
+    const char *e = getenv("VIVIT_PERSIST_FAULT");
+    f = e ? atoi(e) & 3 : 0;
+  }
+  return f;
+}
+
+__global__ void take_timeout_kernel(int32_t *info, int *word) {
+  const int bits = *word;
+  if (bits) {
+    *info = VIVIT_INFO_PERSIST_TIMEOUT;
+    *word = 0;
+  }
 }
 
 bool prof_enabled() { return g_prof_on; }
@@ -69,6 +104,26 @@ int vivit_profile_begin(int symv_stride) {
   g_prof_stride = symv_stride > 0 ? symv_stride : 1;
   g_prof_on = true;
   return VIVIT_OK;
+}
+
+// 1 / 0: allow / forbid the persistent kernels (sytrd_persist.hip, the panel QR of sy2sb.hip, sb2st.hip's chase) for the
+// following calls of this process, whatever VIVIT_*_PERSIST say; -1: back to the environment's choice.  Returns the
+// previous setting.  (The host wrapper retries a solve that ended with VIVIT_INFO_PERSIST_TIMEOUT on the launch chains.)
+int vivit_persistent_kernels(int on) {
+  const int prev = g_persist_override;
+  g_persist_override = on < 0 ? -1 : (on != 0);
+  return prev;
+}
+
+// *info = VIVIT_INFO_PERSIST_TIMEOUT if a persistent kernel gave up since the word was last taken (and clear it); for
+// callers of the stage-level entry points (vivit_sytrd_f32, vivit_sy2sb_f32, vivit_sy2sb_panel_qr_f32, vivit_sb2st_f32),
+// which have no info word of their own.  The eigensolver entry points do this themselves.
+int vivit_take_persist_timeout(int32_t *info, void *stream) {
+  if (!info) return VIVIT_E_BADARG;
+  int *word = persist_timeout_word();
+  if (!word) return VIVIT_E_LAUNCH;
+  take_timeout_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(info, word);
+  return launch_status();
 }
 
 int vivit_profile_end(double *out) {

@@ -247,14 +247,21 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
 // other XCDs have rewritten it; and they were slower than write-through stores throughout: 607 against 493 ms.)
 // Sweeps are dealt to the XCDs in blocks of 32 consecutive sweeps (a ticket counter per XCD, taken in order: a waiting
 // sweep's predecessor is always running or done, whatever is resident), so most hand-overs stay inside one L2.
-// Spins are bounded (2 s): the grid always drains; a timeout poisons d with NaN so that the solve fails loudly.
+// Spins are bounded (2 s): the grid always drains.  The arrival of all workgroups (they learn the set of XCDs from each
+// other) goes through the gate of device_utils.h:persist_arrive: an attempt that is not fully resident within 2 s aborts
+// with nothing written and the retry queued behind it runs (sytrd_persist.hip has the protocol); a second abort or a stall
+// later on poisons d with NaN AND raises PERSIST_TMO_SB2ST in the sticky failure word: the solve ends with
+// info = VIVIT_INFO_PERSIST_TIMEOUT, a status of its own.
 struct Sb2stCtl {
   int ticket[8];
-  int arrive, mask, dead, pad;
+  int arrive[2], state[2], mask[2];   // per attempt: arrival counter, gate state, XCDs present
+  int dead, pad;
 };
 
 __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ AB, int n, float *__restrict__ R2, int64_t ldr,
-                                                            float *__restrict__ tau2, int nk, int rmod, Sb2stCtl *ctl) {
+                                                            float *__restrict__ tau2, int nk, int rmod, Sb2stCtl *ctl, int attempt,
+                                                            int fault) {
+  if (attempt == 1 && __hip_atomic_load(&ctl->state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != PERSIST_ABORT) return;
   __shared__ __attribute__((aligned(16))) Sb2stLds lds;
   __shared__ int s_info[4];   // 0: sweep, 1: dead, 2: index of the XCD among those present, 3: number of XCDs
   const int tid = threadIdx.x, lane = tid & 63;
@@ -265,20 +272,19 @@ __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ 
     int xcc;
     __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 15;
-    __hip_atomic_fetch_or(&ctl->mask, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_or(&ctl->mask[attempt], 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(&ctl->arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    int dead = 0;
-    while (__hip_atomic_load(&ctl->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x)
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { dead = 1; break; }
-    const int mask = __hip_atomic_load(&ctl->mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_info[1] = dead;
+    const bool go = persist_arrive(&ctl->arrive[attempt], &ctl->state[attempt], (int)gridDim.x,
+                                   ((fault >> attempt) & 1) ? 0ull : PERSIST_TIMEOUT_TICKS);
+    const int mask = __hip_atomic_load(&ctl->mask[attempt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_info[1] = go ? 0 : 2;
     s_info[2] = __builtin_popcount(mask & ((1 << xcc) - 1));
     s_info[3] = __builtin_popcount(mask);
-    if (dead) __hip_atomic_store(&ctl->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // aborted at the gate: nothing has been written; only the second abort fails the solve
+    if (!go && attempt == 1) __hip_atomic_store(&ctl->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  if (s_info[1] == 2) return;
   const int xi = s_info[2], nx = s_info[3];
   // thread 0: wait until counter `A` (hi = true) or `B` of sweep sp has reached `need`
   int seenA = 0, seenB = 0;
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ 
       seenA = raw >> 16;
       seenB = raw & 0xffff;
       if (seen >= need) break;
-      if ((++spins & 1023) == 0 && (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull ||
+      if ((++spins & 1023) == 0 && (__builtin_amdgcn_s_memrealtime() - t0 > PERSIST_TIMEOUT_TICKS ||
                                     __hip_atomic_load(&ctl->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         s_info[1] = 1;
         __hip_atomic_store(&ctl->dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -369,9 +375,12 @@ __global__ __launch_bounds__(256) void sb2st_zero_kernel(float *__restrict__ tau
   if (i < nk) tau2[(int64_t)(n - 1) * nk + i] = 0.f;                       // control block
 }
 
-__global__ void sb2st_poison_kernel(const Sb2stCtl *ctl, int n, float *__restrict__ d) {
-  if (ctl->dead) d[0] = __builtin_nanf("");
-  if (n < 0) printf("sb2st persist: mask 0x%x dead %d tickets %d %d %d %d %d %d %d %d\n", ctl->mask, ctl->dead, ctl->ticket[0], ctl->ticket[1],
+__global__ void sb2st_poison_kernel(const Sb2stCtl *ctl, int n, float *__restrict__ d, int *__restrict__ tmo) {
+  if (ctl->dead) {
+    d[0] = __builtin_nanf("");
+    __hip_atomic_fetch_or(tmo, PERSIST_TMO_SB2ST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (n < 0) printf("sb2st persist: mask 0x%x 0x%x dead %d tickets %d %d %d %d %d %d %d %d\n", ctl->mask[0], ctl->mask[1], ctl->dead, ctl->ticket[0], ctl->ticket[1],
                     ctl->ticket[2], ctl->ticket[3], ctl->ticket[4], ctl->ticket[5], ctl->ticket[6], ctl->ticket[7]);
 }
 
@@ -397,7 +406,7 @@ static bool sb2st_persist_enabled() {
     const char *e = getenv("VIVIT_SB2ST_PERSIST");
     on = e ? atoi(e) : 1;
   }
-  return on != 0;
+  return on != 0 && persist_override() != 0;
 }
 
 int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ldr, int64_t r2rows, float *tau2,
@@ -410,12 +419,15 @@ int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ld
   // as for the other persistent kernels; a CPX partition or a CU-masked device takes the launch chain)
   const bool persist = sb2st_persist_enabled() && n >= 960 && (size_t)nk * sizeof(float) >= sizeof(Sb2stCtl) &&
                        device_cu_count() >= 256;
-  if (n >= 3 && persist) {
+  int *tmo = persist ? persist_timeout_word() : nullptr;
+  if (n >= 3 && persist && tmo) {
     Sb2stCtl *ctl = reinterpret_cast<Sb2stCtl *>(tau2 + (n - 1) * nk);
     sb2st_zero_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(tau2, ni, nk);
-    sb2st_persist_kernel<<<256, 256, 0, stream>>>(AB, ni, R2, ldr, tau2, nk, (int)r2rows, ctl);
+    // two attempts: the second returns at once unless the first aborted at its arrival gate (nothing written by then)
+    for (int attempt = 0; attempt < 2; ++attempt)
+      sb2st_persist_kernel<<<256, 256, 0, stream>>>(AB, ni, R2, ldr, tau2, nk, (int)r2rows, ctl, attempt, persist_fault());
     sb2st_extract_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(AB, ni, d, e);
-    sb2st_poison_kernel<<<1, 1, 0, stream>>>(ctl, getenv("VIVIT_SB2ST_DEBUG") ? -ni : ni, d);
+    sb2st_poison_kernel<<<1, 1, 0, stream>>>(ctl, getenv("VIVIT_SB2ST_DEBUG") ? -ni : ni, d, tmo);
     return launch_status();
   }
   if (n >= 3) {

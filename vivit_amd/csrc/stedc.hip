@@ -522,8 +522,16 @@ __global__ void scale_w_kernel(float *__restrict__ w, int n, const float *__rest
   if (i < n) w[i] /= scal[1];
 }
 
-__global__ void finalize_info_kernel(int32_t *info, int n, const float *__restrict__ scal) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && scal && scal[2] != 0.f) *info = n;
+// info = n for non-finite input; VIVIT_INFO_PERSIST_TIMEOUT when a persistent kernel of this solve gave up (its bit in
+// the sticky word, which is cleared here) -- the two are different failures and the host treats them differently
+__global__ void finalize_info_kernel(int32_t *info, int n, const float *__restrict__ scal, int *__restrict__ tmo) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (tmo && *tmo != 0) {
+    *info = VIVIT_INFO_PERSIST_TIMEOUT;
+    *tmo = 0;
+  } else if (scal && scal[2] != 0.f) {
+    *info = n;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -634,7 +642,7 @@ int stebz_launch(const float *d, const float *e, int64_t n, float *w, const floa
 }
 
 int info_finalize_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream) {
-  finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal);
+  finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word());
   return launch_status();
 }
 
@@ -644,7 +652,7 @@ int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq,
   if (Z)
     dc_transpose_out_kernel<<<dim3((unsigned)cdiv(n, 32), (unsigned)cdiv(n, 32)), 256, 0, stream>>>((int)n, Qt, ldq, order,
                                                                                                   Z, ldz);
-  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal);
+  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word());
   return launch_status();
 }
 
@@ -692,7 +700,7 @@ int dc_select_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq,
 }
 
 int info_scal_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream) {
-  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal);
+  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word());
   return launch_status();
 }
 

@@ -256,7 +256,10 @@ constexpr int QP_WG = 32, QP_THREADS = 512;
 struct QrPersistWs {
   float *ubuf;    // [2][QP_WG][SNB]
   float *dbuf;    // [2][SNB]
-  int *counter;   // monotonic arrival counter; [32 ..]: XCC ids
+  int *counter;   // per attempt a (0 | 1) at 8 a: monotonic arrival counter, arrival-gate state; [32 ..]: XCC ids
+  int *tmo;       // the sticky failure word (persist_timeout_word)
+  int attempt;    // 0: first launch; 1: the retry behind it (runs only if attempt 0 aborted at its arrival gate)
+  int fault;      // VIVIT_PERSIST_FAULT (tests)
 };
 
 __device__ __forceinline__ float sel8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7, int j) {
@@ -271,6 +274,9 @@ __global__ __launch_bounds__(QP_THREADS) void qr_persist_kernel(float *__restric
                                                                 int64_t gi0, float *__restrict__ A, int64_t lda, int64_t j0,
                                                                 float *__restrict__ tau1, float *__restrict__ betas) {
   if ((blockIdx.x & 7) != 0) return;
+  // the retry runs only when the first attempt aborted at its gate (device_utils.h:persist_arrive; sytrd_persist.hip)
+  if (pw.attempt == 1 && __hip_atomic_load(pw.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != PERSIST_ABORT) return;
+  int *const cnt = pw.counter + 8 * pw.attempt;
   const int w = blockIdx.x >> 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = tid & 7, rs = tid >> 3;
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(QP_THREADS) void qr_persist_kernel(float *__restric
   __shared__ float s_u[SNB], s_d[SNB], s_dn[SNB];
   __shared__ float s_red[QP_THREADS / 64][SNB];
   __shared__ float s_v[RW];
-  __shared__ int s_flag[2];   // 0: slow (not one XCD), 1: dead (timeout)
+  __shared__ int s_flag[2];   // 0: slow (not one XCD), 1: dead (1: stalled exchange, 2: aborted at the gate)
 
   float x[RI][8];
 #pragma unroll
@@ -296,11 +302,8 @@ __global__ __launch_bounds__(QP_THREADS) void qr_persist_kernel(float *__restric
     __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     __hip_atomic_store(pw.counter + 32 + w, xcc & 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(pw.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    int dead = 0;
-    while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < QP_WG)
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { dead = 1; break; }
+    const bool go = persist_arrive(cnt, cnt + 1, QP_WG, ((pw.fault >> pw.attempt) & 1) ? 0ull : PERSIST_TIMEOUT_TICKS);
+    const int dead = go ? 0 : 2;
     int slow = 0;
     const int x0 = __hip_atomic_load(pw.counter + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = 1; i < QP_WG; ++i) slow |= __hip_atomic_load(pw.counter + 32 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != x0;
@@ -309,6 +312,13 @@ __global__ __launch_bounds__(QP_THREADS) void qr_persist_kernel(float *__restric
   }
   __syncthreads();
   const bool slow = s_flag[0] != 0;
+  if (s_flag[1] == 2) {   // aborted at the gate: nothing has been written; the second abort fails the solve
+    if (tid == 0 && w == 0 && pw.attempt == 1) {
+      __hip_atomic_fetch_or(pw.tmo, PERSIST_TMO_PANEL_QR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      betas[0] = __builtin_nanf("");
+    }
+    return;
+  }
   const int grp = lane & ~7;   // first lane of this row slot's eight threads
 
   // partial sums of column cn over this workgroup's rows (x = the UPDATED column cn), diagonal row cn, out to the exchange
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(QP_THREADS) void qr_persist_kernel(float *__restric
         if (w == 0) *db = s_dn[lane];
       }
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(pw.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
 
@@ -366,8 +376,8 @@ __global__ __launch_bounds__(QP_THREADS) void qr_persist_kernel(float *__restric
     if (wave == 0) {   // exchange: all 32 workgroups have delivered column c's partials
       const int target = (c + 2) * QP_WG;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { s_flag[1] = 1; break; }
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+        if (__builtin_amdgcn_s_memrealtime() - t0 > PERSIST_TIMEOUT_TICKS) { s_flag[1] = 1; break; }
       const float *ub = pw.ubuf + (size_t)par * QP_WG * SNB + lane;
       float pv[QP_WG];
 #pragma unroll
@@ -426,7 +436,10 @@ __global__ __launch_bounds__(QP_THREADS) void qr_persist_kernel(float *__restric
       *reinterpret_cast<float4 *>(dst) = make_float4(x[0][0], x[0][1], x[0][2], x[0][3]);
       *reinterpret_cast<float4 *>(dst + 4) = make_float4(x[0][4], x[0][5], x[0][6], x[0][7]);
     }
-    if (tid == 0 && s_flag[1]) betas[0] = __builtin_nanf("");   // a timed-out exchange: poison the band
+    if (tid == 0 && s_flag[1]) {   // a stalled exchange: poison the band and raise the status of its own
+      betas[0] = __builtin_nanf("");
+      __hip_atomic_fetch_or(pw.tmo, PERSIST_TMO_PANEL_QR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -436,7 +449,7 @@ static bool qr_persist_enabled() {
     const char *e = getenv("VIVIT_QR_PERSIST");
     on = e ? atoi(e) : 1;
   }
-  return on != 0;
+  return on != 0 && persist_override() != 0;
 }
 constexpr size_t QR_PERSIST_WS_BYTES = sizeof(float) * (2 * QP_WG * SNB + 2 * SNB) + 64 * sizeof(int) + 256;
 
@@ -448,18 +461,25 @@ static bool qr_persist_launch(float *pan, int64_t mp, int ncol, void *wsp, float
   pw.ubuf = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(wsp), 256));
   pw.dbuf = pw.ubuf + 2 * QP_WG * SNB;
   pw.counter = reinterpret_cast<int *>(pw.dbuf + 2 * SNB);
+  pw.tmo = persist_timeout_word();
+  pw.fault = persist_fault();
+  if (!pw.tmo) return false;
   if (hipMemsetAsync(pw.counter, 0, 64 * sizeof(int), stream) != hipSuccess) return false;
   const int64_t ri = cdiv(mp, (int64_t)QP_WG * 64);
   const dim3 grid(8 * QP_WG);
 #define QP_LAUNCH(RI) qr_persist_kernel<RI><<<grid, QP_THREADS, 0, stream>>>(pan, mp, ncol, pw, v1, v2, ldn, gi0, A, lda, j0, tau1, betas)
-  if (ri <= 1) QP_LAUNCH(1);
-  else if (ri <= 2) QP_LAUNCH(2);
-  else if (ri <= 3) QP_LAUNCH(3);
-  else if (ri <= 5) QP_LAUNCH(5);
-  else if (ri <= 8) QP_LAUNCH(8);
-  else if (ri <= 12) QP_LAUNCH(12);
-  else if (ri <= 16) QP_LAUNCH(16);
-  else QP_LAUNCH(20);
+  // two attempts: the second returns at once unless the first aborted at its arrival gate (nothing written by then)
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    pw.attempt = attempt;
+    if (ri <= 1) QP_LAUNCH(1);
+    else if (ri <= 2) QP_LAUNCH(2);
+    else if (ri <= 3) QP_LAUNCH(3);
+    else if (ri <= 5) QP_LAUNCH(5);
+    else if (ri <= 8) QP_LAUNCH(8);
+    else if (ri <= 12) QP_LAUNCH(12);
+    else if (ri <= 16) QP_LAUNCH(16);
+    else QP_LAUNCH(20);
+  }
 #undef QP_LAUNCH
   return true;
 }

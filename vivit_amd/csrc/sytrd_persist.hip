@@ -20,10 +20,14 @@
 // Workgroups find themselves on one XCD because the dispatcher deals workgroup b to XCD b % 8: the launch has 256
 // workgroups, 224 return at once.  The first exchange compares the XCC ids; should they ever differ the stores become
 // agent-scope atomic stores (write-through), which is correct anywhere (4 us per exchange).  Every spin is bounded (2 s):
-// the grid always drains, a timeout raises the non-finite-input flag so that the solve fails loudly.  One process per GPU:
-// two processes that launch this kernel on the same card at the same moment can each hold part of XCD 0 and time out
-// (VIVIT_SYTRD_PERSIST=0 / VIVIT_QR_PERSIST=0 select the launch chains; tests/test_distributed_gpu.py does for its two ranks
-// on one card).
+// the grid always drains.  Co-residency is decided once, atomically, by the arrival gate (device_utils.h:persist_arrive):
+// an attempt that does not get all its workgroups resident within 2 s aborts WITHOUT having written anything, and the
+// launcher has a second attempt queued behind it (returns at once when the first one ran).  When that aborts too, or an
+// exchange stalls later, the kernel ORs PERSIST_TMO_SYTRD into the sticky failure word and the solve ends with
+// info = VIVIT_INFO_PERSIST_TIMEOUT -- a status of its own, not the non-finite-input one (the host wrapper then repeats the
+// solve on the launch chain when it still has the input).  One process per GPU: two processes that launch this kernel on
+// the same card at the same moment can each hold part of XCD 0 and time out (VIVIT_SYTRD_PERSIST=0 / VIVIT_QR_PERSIST=0
+// select the launch chains; tests/test_distributed_gpu.py does for its two ranks on one card).
 #include <cstdlib>
 
 #include "common.h"
@@ -38,8 +42,11 @@ constexpr int TP_THREADS = 512;  // 8 waves; wave g owns the local rows g, g + 8
 struct PersistWs {
   float *ybuf;     // [2][NP]
   float *rowbuf;   // [2][NP]
-  int *counter;    // monotonic arrival counter
+  int *counter;    // [32]: per attempt a (0 | 1) at 8 a: monotonic arrival counter, arrival-gate state
   int *xcc;        // [32] XCC id of each workgroup
+  int *tmo;        // the sticky failure word (persist_timeout_word)
+  int attempt;     // 0: first launch; 1: the retry behind it (runs only if attempt 0 aborted at its arrival gate)
+  int fault;       // VIVIT_PERSIST_FAULT (tests)
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -51,13 +58,16 @@ __device__ __forceinline__ float ld_l2(const float *p) {
 template <int KC, int RPW, int NWG>   // column chunks of 256: n <= 256 KC; rows per wave: n <= 8 NWG RPW; NWG = 32 (one XCD) or 256 (all)
 __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restrict__ A, int64_t lda, int n, SytrdWs ws, PersistWs pw) {
   if (NWG == TP_WG && (blockIdx.x & 7) != 0) return;
+  // the retry runs only when the first attempt aborted at its gate (that verdict is final once attempt 0 has drained)
+  if (pw.attempt == 1 && __hip_atomic_load(pw.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != PERSIST_ABORT) return;
+  int *const cnt = pw.counter + 8 * pw.attempt;
   constexpr int NP = 256 * KC;
   const int w = NWG == TP_WG ? blockIdx.x >> 3 : blockIdx.x;
   const int tid = threadIdx.x, g = tid >> 6, l = tid & 63, lane = l;
   __shared__ __attribute__((aligned(16))) float s_x[2][NP];   // replica of the current row, double-buffered
   __shared__ __attribute__((aligned(16))) float s_y[NP];      // gathered y
   __shared__ __attribute__((aligned(16))) float s_r[NP];      // gathered row j + 1 (before update j)
-  __shared__ int s_flag[2];                                   // 0: slow (not one XCD), 1: dead (timeout)
+  __shared__ int s_flag[2];                                   // 0: slow (not one XCD), 1: dead (1: stalled exchange, 2: aborted at the gate)
 
   // ---- the own rows, full width, from the lower triangle
   f2 a[RPW][KC][2];
@@ -83,11 +93,8 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
     __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     if (NWG == TP_WG) __hip_atomic_store(pw.xcc + w, xcc & 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(pw.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    int dead = 0;
-    while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NWG)
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { dead = 1; break; }
+    const bool go = persist_arrive(cnt, cnt + 1, NWG, ((pw.fault >> pw.attempt) & 1) ? 0ull : PERSIST_TIMEOUT_TICKS);
+    const int dead = go ? 0 : 2;
     int slow = NWG != TP_WG;   // all XCDs: always the agent-scope stores
     const int x0 = __hip_atomic_load(pw.xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = 1; i < TP_WG && NWG == TP_WG; ++i) slow |= __hip_atomic_load(pw.xcc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != x0;
@@ -96,6 +103,13 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
   }
   __syncthreads();
   const bool slow = s_flag[0] != 0;
+  if (s_flag[1] == 2) {   // aborted at the gate: nothing has been written; the second abort fails the solve
+    if (tid == 0 && w == 0 && pw.attempt == 1) {
+      __hip_atomic_fetch_or(pw.tmo, PERSIST_TMO_SYTRD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ws.scal[2] = 1.f;
+    }
+    return;
+  }
 
   for (int j = 0; j < n - 2 && !s_flag[1]; ++j) {
     const int par = j & 1;
@@ -167,10 +181,10 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __hip_atomic_fetch_add(pw.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int target = (j + 2) * NWG;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(pw.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { s_flag[1] = 1; break; }
     }
     __syncthreads();
@@ -238,7 +252,10 @@ __global__ __launch_bounds__(TP_THREADS) void trd_persist_kernel(float *__restri
     ws.tau[n - 2] = 0.f;
     ws.tau[n - 1] = 0.f;
   }
-  if (tid == 0 && s_flag[1]) ws.scal[2] = 1.f;   // a timed-out exchange: fail the solve
+  if (tid == 0 && s_flag[1]) {   // a stalled exchange: fail the solve, with the status of its own
+    ws.scal[2] = 1.f;
+    __hip_atomic_fetch_or(pw.tmo, PERSIST_TMO_SYTRD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #pragma unroll
   for (int q = 0; q < RPW; ++q) {
     const int r = w + NWG * (g + 8 * q);
@@ -258,6 +275,7 @@ bool sytrd_persist_ok(int64_t n) {
     const char *e = getenv("VIVIT_SYTRD_PERSIST");
     on = e ? atoi(e) : 1;   // 1: all sizes, 2: one-XCD sizes only (n <= 1280)
   }
+  if (persist_override() == 0) return false;
   return on != 0 && n >= 64 && n <= (on == 2 ? 1280 : 2048) && device_cu_count() >= 256;
 }
 
@@ -271,22 +289,28 @@ int sytrd_persist_launch(float *A, int64_t n, int64_t lda, const SytrdWs &ws, hi
   pw.rowbuf = ws.vw + 2 * NP;
   pw.counter = reinterpret_cast<int *>(ws.vw + 4 * NP);
   pw.xcc = pw.counter + 32;
+  pw.tmo = persist_timeout_word();
+  pw.fault = persist_fault();
+  if (!pw.tmo) return VIVIT_E_LAUNCH;
   if (4 * NP + 64 > 3 * 64 * n) return VIVIT_E_WORKSPACE;
   if (hipMemsetAsync(pw.counter, 0, 64 * sizeof(int), stream) != hipSuccess) return VIVIT_E_LAUNCH;
   const dim3 grid(8 * TP_WG);
   const int ni = (int)n;
   // n <= 1280: the 32 workgroups of one XCD (2 us per exchange; <6, 6, 32> would spill 84 registers); above, all 256 CUs with
   // agent-scope exchanges (6.7 us: scripts/probe/grid_barrier.hip mode 3), a workgroup holds n / 256 rows
-  switch (kc) {
-    case 1: trd_persist_kernel<1, 1, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 2: trd_persist_kernel<2, 2, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 3: trd_persist_kernel<3, 3, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 4: trd_persist_kernel<4, 4, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 5: trd_persist_kernel<5, 5, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 6: trd_persist_kernel<6, 1, 256><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    case 8: trd_persist_kernel<8, 1, 256><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
-    default: return VIVIT_E_UNSUPPORTED;
-  }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    pw.attempt = attempt;
+    switch (kc) {
+      case 1: trd_persist_kernel<1, 1, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+      case 2: trd_persist_kernel<2, 2, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+      case 3: trd_persist_kernel<3, 3, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+      case 4: trd_persist_kernel<4, 4, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+      case 5: trd_persist_kernel<5, 5, 32><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+      case 6: trd_persist_kernel<6, 1, 256><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+      case 8: trd_persist_kernel<8, 1, 256><<<grid, TP_THREADS, 0, stream>>>(A, lda, ni, ws, pw); break;
+      default: return VIVIT_E_UNSUPPORTED;
+    }
+}
   return launch_status();
 }
 

@@ -28,6 +28,7 @@ all-reduce of ``P`` floats finishes the Newton step (vivit/optim/directional_dam
 For functional tests several ranks may share one GPU with the ``gloo`` backend; collectives on device tensors are then
 staged through host memory (``_staged``) -- test plumbing, never the measured path.
 """
+import os as _os
 from typing import Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -43,8 +44,21 @@ EXCHANGE_CHUNK_COLUMNS = 8192  # columns of a rank's parameter shard exchanged (
 
 # ------------------------------------------------------------------------------------------------------------------
 # collectives (thin wrappers: RCCL directly; gloo + device tensors are staged through the host for 1-GPU functional tests)
+def _forced() -> bool:
+    """``VIVIT_DIST_FORCE_COLLECTIVES=1``: a world of ONE rank issues every collective anyway (an all-to-all with itself,
+    an all-reduce over one rank, ...) instead of taking the single-process shortcuts.  That is how a one-GPU box executes the
+    RCCL code path of this module -- ``init_process_group("nccl")``, ``all_to_all_single(async_op=True)`` + ``work.wait()``
+    against the SYRK stream, the packed all-reduce -- at least once (tests/test_distributed_gpu.py); results are unchanged."""
+    return _os.environ.get("VIVIT_DIST_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def _active(group=None) -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _forced())
+
+
+def _alone(R: int) -> bool:
+    """True when the single-process shortcut may be taken (one rank and collectives not forced)."""
+    return R == 1 and not _forced()
 
 
 def world_size(group=None) -> int:
@@ -91,7 +105,7 @@ def all_gather_cat(t: torch.Tensor, group=None, out: Optional[torch.Tensor] = No
     t = t.contiguous()
     if out is None:
         out = torch.empty((R * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    if R == 1:
+    if _alone(R):
         out.copy_(t)
         return out
     if _staged(t, group):
@@ -204,7 +218,7 @@ def to_parameter_shard(local: torch.Tensor, lead_dims: int, group=None, index: i
     C, Ng = int(local.shape[0]), int(local.shape[1])
     F = local.detach().reshape(C, Ng, -1)
     P = F.shape[2]
-    if R == 1:
+    if _alone(R):
         return F.reshape(C * Ng, P)
     slices = parameter_slices(P, R, index)
     widths = [hi - lo for lo, hi in slices]
@@ -268,7 +282,7 @@ def check_equal_shards(n_local: int, group=None, *more) -> int:
     ``more``: further per-rank sizes (``None`` allowed) checked in the SAME collective -- every rank makes exactly one
     call whatever its arguments are, so ranks that disagree on an optional size raise instead of hanging."""
     R = world_size(group)
-    if R == 1:
+    if _alone(R):
         return n_local
     mine = (int(n_local),) + tuple(-1 if m is None else int(m) for m in more)
     sizes = [None] * R
@@ -456,8 +470,6 @@ def backproject_sum(coef: torch.Tensor, V_local: torch.Tensor, acc: BatchSharded
 # Smallest n whose band reduction is sharded by default; None = never (the prototype issues its two collectives per panel from
 # Python: at R = 8 its projected time equals the replicated reduction's, and no multi-GPU node could measure it -- so it is
 # opt-in: ``symeig(..., sharded_reduction=True)`` or VIVIT_SHARDED_BAND_MIN_N=<n> in the environment).
-import os as _os
-
 SHARDED_BAND_MIN_N = int(_os.environ["VIVIT_SHARDED_BAND_MIN_N"]) if _os.environ.get("VIVIT_SHARDED_BAND_MIN_N") else None
 
 
@@ -581,7 +593,7 @@ def symeig(G: torch.Tensor, group=None, overwrite: bool = False, sharded_reducti
     ``SHARDED_BAND_MIN_N`` is set and ``n`` reaches it.  Bulge chasing and the tridiagonal solve stay replicated (L2-resident, launch-free:
     nothing to shard)."""
     world = world_size(group)
-    if world == 1:
+    if _alone(world):
         return kernels.symeig(G, eigenvectors=True, overwrite=overwrite)
     n = G.shape[0]
     rank = rank_of(group)

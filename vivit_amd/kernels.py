@@ -263,23 +263,27 @@ def symeig(G: torch.Tensor, eigenvectors: bool = False, overwrite: bool = False,
     if G.dim() != 2 or G.shape[0] != G.shape[1]:
         raise ValueError(f"Input must be a square matrix. Got shape {tuple(G.shape)}.")
     n = G.shape[0]
-    A = _as2d(G)
-    if A.data_ptr() == G.data_ptr() and not overwrite:
-        A = A.clone()  # the solver destroys its input (reflectors are stored in it)
-    w = torch.empty(n, dtype=torch.float32, device=G.device)
-    Z = torch.empty((n, n), dtype=torch.float32, device=G.device) if eigenvectors else None
-    info = torch.zeros(1, dtype=torch.int32, device=G.device)
     lib = _lib.load()
-    ws, wsb = _workspace(lib.vivit_symeig_f32_workspace_bytes(n, 1 if eigenvectors else 0), G)
-    st = lib.vivit_symeig_f32(
-        A.data_ptr(), n, _ld(A), w.data_ptr(), Z.data_ptr() if eigenvectors else None, n, ws, wsb, info.data_ptr(), _stream(G)
-    )
-    _lib.check(st, "vivit_symeig_f32")
-    if info_out is not None:
-        info_out.append(info)
-    else:
-        check_info(info)  # device->host sync; the reference syncs here too (criterion callback)
-    return w, Z
+
+    def solve():
+        A = _as2d(G)
+        if A.data_ptr() == G.data_ptr() and not overwrite:
+            A = A.clone()  # the solver destroys its input (reflectors are stored in it)
+        w = torch.empty(n, dtype=torch.float32, device=G.device)
+        Z = torch.empty((n, n), dtype=torch.float32, device=G.device) if eigenvectors else None
+        info = torch.zeros(1, dtype=torch.int32, device=G.device)
+        ws, wsb = _workspace(lib.vivit_symeig_f32_workspace_bytes(n, 1 if eigenvectors else 0), G)
+        st = lib.vivit_symeig_f32(
+            A.data_ptr(), n, _ld(A), w.data_ptr(), Z.data_ptr() if eigenvectors else None, n, ws, wsb, info.data_ptr(), _stream(G)
+        )
+        _lib.check(st, "vivit_symeig_f32")
+        if info_out is not None:
+            info_out.append(info)
+        else:
+            check_info(info)  # device->host sync; the reference syncs here too (criterion callback)
+        return w, Z
+
+    return _retry_on_launch_chain(solve, intact=not overwrite, G=G)
 
 
 @_launcher
@@ -510,25 +514,96 @@ def symeig_reduce(G: torch.Tensor, overwrite: bool = False) -> SymeigPlan:
     if n < SYMEIG_ROWS_MIN_N:  # single-workgroup solver: all vectors cost nothing extra
         w, Z = symeig(G, eigenvectors=True, overwrite=overwrite)
         return SymeigPlan(w, n, full=Z)
-    A = _as2d(G)
-    if A.data_ptr() == G.data_ptr() and not overwrite:
-        A = A.clone()
-    w = torch.empty(n, dtype=torch.float32, device=G.device)
-    info = torch.zeros(1, dtype=torch.int32, device=G.device)
     lib = _lib.load()
-    state = torch.empty(lib.vivit_symeig_reduce_f32_workspace_bytes(n) + 256, dtype=torch.uint8, device=G.device)
-    st = lib.vivit_symeig_reduce_f32(A.data_ptr(), n, _ld(A), w.data_ptr(), state.data_ptr(), state.numel(),
-                                     info.data_ptr(), _stream(G))
-    _lib.check(st, "vivit_symeig_reduce_f32")
-    check_info(info)
-    return SymeigPlan(w, n, A=A, state=state)
+
+    def solve():
+        A = _as2d(G)
+        if A.data_ptr() == G.data_ptr() and not overwrite:
+            A = A.clone()
+        w = torch.empty(n, dtype=torch.float32, device=G.device)
+        info = torch.zeros(1, dtype=torch.int32, device=G.device)
+        state = torch.empty(lib.vivit_symeig_reduce_f32_workspace_bytes(n) + 256, dtype=torch.uint8, device=G.device)
+        st = lib.vivit_symeig_reduce_f32(A.data_ptr(), n, _ld(A), w.data_ptr(), state.data_ptr(), state.numel(),
+                                         info.data_ptr(), _stream(G))
+        _lib.check(st, "vivit_symeig_reduce_f32")
+        check_info(info)
+        return SymeigPlan(w, n, A=A, state=state)
+
+    return _retry_on_launch_chain(solve, intact=not overwrite, G=G)
+
+
+class PersistentKernelTimeout(RuntimeError):
+    """A persistent kernel of the eigensolver (one-launch tridiagonalisation, panel QR, bulge chase) could not get its
+    workgroups resident together -- twice -- or one of its exchanges stalled: ``info = VIVIT_INFO_PERSIST_TIMEOUT``
+    (include/vivit_hip.h, "Persistent kernels").  Not a numerical failure: the input may be fine; something else held
+    the GPU's compute units (another process on the card, a long collective).  The solve's outputs are garbage."""
 
 
 def check_info(info: torch.Tensor):
-    """Map the eigensolver's device-side status word to the reference's RuntimeError (synchronises)."""
+    """Map the eigensolver's device-side status word to the reference's RuntimeError (synchronises);
+    :class:`PersistentKernelTimeout` (a RuntimeError too) for the persistent kernels' own status."""
     nfail = int(info.item())
+    if nfail == _lib.VIVIT_INFO_PERSIST_TIMEOUT:
+        raise PersistentKernelTimeout(
+            "symeig: a persistent kernel could not become resident (two attempts of 2 s) or stalled; "
+            "VIVIT_SYTRD_PERSIST=0 VIVIT_QR_PERSIST=0 VIVIT_SB2ST_PERSIST=0 select the launch chains")
     if nfail != 0:
         raise RuntimeError(f"symeig: {nfail} eigenvalues did not converge")
+
+
+class persistent_kernels:
+    """``with persistent_kernels(False): ...`` -- run the enclosed solves on the launch chains
+    (``vivit_persistent_kernels``; the previous setting is restored on exit)."""
+
+    def __init__(self, on: bool):
+        self._on = 1 if on else 0
+
+    def __enter__(self):
+        self._prev = _lib.load().vivit_persistent_kernels(self._on)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().vivit_persistent_kernels(self._prev)
+        return False
+
+
+_BACKUP_ALWAYS_BYTES = 256 << 20   # inputs up to this size (n <= 8192) are always backed up before an in-place solve
+
+
+def _wants_backup(G: torch.Tensor) -> bool:
+    """An in-place solve (``overwrite=True``) keeps a copy of its input for the launch-chain retry when that is cheap
+    (<= 256 MB: 0.1 ms) or when the card is likely to be shared -- a multi-rank job, whose RCCL kernels compete with the
+    persistent kernels for compute units -- or on request (``VIVIT_PERSIST_BACKUP=1``; ``=0`` never)."""
+    import os
+
+    env = os.environ.get("VIVIT_PERSIST_BACKUP")
+    if env is not None:
+        return env != "0"
+    if G.numel() * 4 <= _BACKUP_ALWAYS_BYTES:
+        return True
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _retry_on_launch_chain(solve, intact: bool, G: Optional[torch.Tensor] = None):
+    """Run ``solve()``; if it ends with :class:`PersistentKernelTimeout` and the input is still there -- the solve worked
+    on a copy (``intact``), or ``G`` is solved in place and was backed up (:func:`_wants_backup`) -- repeat it ONCE with the
+    persistent kernels switched off: the same stages as launch chains, which need no co-residency.  Otherwise the error
+    propagates (the input is gone)."""
+    backup = G.clone() if (not intact and G is not None and _wants_backup(G)) else None
+    try:
+        return solve()
+    except PersistentKernelTimeout:
+        if not intact and backup is None:
+            raise
+        import warnings
+
+        warnings.warn("symeig: persistent kernel timed out; repeating the solve on the launch chains", RuntimeWarning)
+        if backup is not None:
+            G.copy_(backup)
+        with persistent_kernels(False):
+            return solve()
 
 
 SYMEIG_ROWS_MIN_N = 193  # below: single-workgroup solver, no row-range entry point
@@ -548,22 +623,24 @@ def symeig_rows(G: torch.Tensor, row_begin: int, row_end: int, overwrite: bool =
     if n < SYMEIG_ROWS_MIN_N:  # same HIP solver, slice afterwards
         w, Z = symeig(G, eigenvectors=True, overwrite=overwrite)
         return w, Z.T[row_begin:row_end].contiguous()
-    A = _as2d(G)
-    if A.data_ptr() == G.data_ptr() and not overwrite:
-        A = A.clone()
-    w = torch.empty(n, dtype=torch.float32, device=G.device)
-    Zt = torch.empty((max(row_end - row_begin, 1), n), dtype=torch.float32, device=G.device)
-    info = torch.zeros(1, dtype=torch.int32, device=G.device)
     lib = _lib.load()
-    ws, wsb = _workspace(lib.vivit_symeig_f32_workspace_bytes(n, 1), G)
-    st = lib.vivit_symeig_rows_f32(
-        A.data_ptr(), n, _ld(A), w.data_ptr(), Zt.data_ptr(), n, row_begin, row_end, ws, wsb, info.data_ptr(), _stream(G)
-    )
-    _lib.check(st, "vivit_symeig_rows_f32")
-    nfail = int(info.item())
-    if nfail != 0:
-        raise RuntimeError(f"symeig: {nfail} eigenvalues did not converge")
-    return w, Zt[: row_end - row_begin]
+
+    def solve():
+        A = _as2d(G)
+        if A.data_ptr() == G.data_ptr() and not overwrite:
+            A = A.clone()
+        w = torch.empty(n, dtype=torch.float32, device=G.device)
+        Zt = torch.empty((max(row_end - row_begin, 1), n), dtype=torch.float32, device=G.device)
+        info = torch.zeros(1, dtype=torch.int32, device=G.device)
+        ws, wsb = _workspace(lib.vivit_symeig_f32_workspace_bytes(n, 1), G)
+        st = lib.vivit_symeig_rows_f32(
+            A.data_ptr(), n, _ld(A), w.data_ptr(), Zt.data_ptr(), n, row_begin, row_end, ws, wsb, info.data_ptr(), _stream(G)
+        )
+        _lib.check(st, "vivit_symeig_rows_f32")
+        check_info(info)
+        return w, Zt[: row_end - row_begin]
+
+    return _retry_on_launch_chain(solve, intact=not overwrite, G=G)
 
 
 @_launcher
@@ -675,9 +752,7 @@ def symeig_banded_rows(A: torch.Tensor, tau1: torch.Tensor, scal: torch.Tensor, 
     st = lib.vivit_symeig_banded_rows_f32(A.data_ptr(), n, _ld(A), tau1.data_ptr(), scal.data_ptr(), w.data_ptr(), Zt.data_ptr(),
                                           n, row_begin, row_end, ws, wsb, info.data_ptr(), _stream(A))
     _lib.check(st, "vivit_symeig_banded_rows_f32")
-    nfail = int(info.item())
-    if nfail != 0:
-        raise RuntimeError(f"symeig: {nfail} eigenvalues did not converge")
+    check_info(info)
     return w, Zt[: row_end - row_begin]
 
 

@@ -309,7 +309,7 @@ def _tune_threads(dims=(784, 512, 10), C=10, gram_batch=256, eig_n=5120):
     return best, {"affinity": affinity, "cpu_count": os.cpu_count(), "probe": table}
 
 
-def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), eig_batches=(256, 512), repeats=3):
+def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256, 512), eig_batches=(512, 1024, 2048), repeats=3):
     """The oracle (CPU restatement of the reference algorithm) timed on this host on a bounded sample, both flavours
     the reference has for this MLP, never mixed:
       materialised -- einsum Gram over every parameter with the full 2 n^2 P work (vivit/utils/gram.py:230-232,
@@ -319,12 +319,13 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), eig_batches=(256, 
         the weights + materialised biases, then the same eigh.
     Median of ``repeats`` after one warm-up; the einsum Gram is timed at ``batches`` (it is the expensive phase of the
     sample: 2 n^2 P flop), eigh/eigvalsh at the larger ``eig_batches`` (on the same MLP's Gram matrix, built with the
-    factorised form) because LAPACK only approaches its n^3 regime there.  The exponent of each phase is FITTED between
-    its two sizes (never steeper than the flop count) and used to extrapolate to the full n (stated in ``sample``).
+    factorised form) because LAPACK only approaches its n^3 regime there.  The exponent of each phase is a least-squares
+    FIT over its three sizes (never steeper than the flop count; the fit's worst residual is reported) and extrapolates the
+    largest sample -- n = 5120 for the Gram, n = 20 480 = half the full size for eigh -- to the full n (stated in ``sample``).
     Thread count tuned first (``_tune_threads``)."""
     from oracle import vivit_oracle as oracle
 
-    threads, table = _tune_threads(dims, C, gram_batch=max(batches), eig_n=C * min(eig_batches))
+    threads, table = _tune_threads(dims, C, gram_batch=sorted(batches)[min(1, len(batches) - 1)], eig_n=C * min(eig_batches))
     _progress(f"cpu baseline: {threads} threads (probe {table})")
     cpu = torch.device("cpu")
 
@@ -344,32 +345,46 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), eig_batches=(256, 
         facs = mlp_sqrt_ggn_factors(dims, b, cpu)
         n = facs[0].shape[0]
         V = [f.view(C, b, -1) for f in facs]
-        # (the warm-up run is only needed once per process: thread pool, allocator)
-        t_gram = _median_time(lambda: oracle.compute_gram_mat(V, start_dim=2, flatten=True), repeats, warm=bi == 0)
+        # (the warm-up run is only needed once per process: thread pool, allocator; the LARGEST size of each phase is run once
+        # -- it is the expensive sample and the least noisy one)
+        last = bi == len(batches) - 1 and len(batches) > 2
+        t_gram = _median_time(lambda: oracle.compute_gram_mat(V, start_dim=2, flatten=True), 1 if last else repeats, warm=bi == 0)
         del V, facs
         t_fact = _median_time(fact_gram_fn(mlp_factorised_factors(dims, b, cpu)), repeats)
         _progress(f"cpu baseline: batch {b} (n={n}) einsum Gram {t_gram:.2f} s, factorised Gram {t_fact:.3f} s")
-        gram_rows.append({"batch": b, "n": n, "gram_materialised_s": t_gram, "gram_factorised_s": t_fact})
-    for b in eig_batches:
+        gram_rows.append({"batch": b, "n": n, "gram_materialised_s": t_gram, "gram_factorised_s": t_fact, "repeats": 1 if last else repeats})
+    for bi, b in enumerate(eig_batches):
         gram = fact_gram_fn(mlp_factorised_factors(dims, b, cpu))()
         n = gram.shape[0]
-        t_eig = _median_time(lambda: oracle.tensor_symeig(gram, eigenvectors=True), repeats)
-        t_eigv = _median_time(lambda: oracle.tensor_symeig(gram, eigenvectors=False), repeats)
-        _progress(f"cpu baseline: batch {b} (n={n}) eigh {t_eig:.2f} s, eigvalsh {t_eigv:.2f} s")
-        eig_rows.append({"batch": b, "n": n, "eigh_s": t_eig, "eigvalsh_s": t_eigv})
+        last = bi == len(eig_batches) - 1 and len(eig_batches) > 2
+        reps = 1 if (last or (bi == len(eig_batches) - 2 and len(eig_batches) > 2)) else repeats
+        t_eig = _median_time(lambda: oracle.tensor_symeig(gram, eigenvectors=True), reps, warm=bi == 0)
+        row = {"batch": b, "n": n, "eigh_s": t_eig, "repeats": reps}
+        if not last:   # (values only is a secondary line: its two smaller sizes are enough)
+            row["eigvalsh_s"] = _median_time(lambda: oracle.tensor_symeig(gram, eigenvectors=False), reps, warm=bi == 0)
+        _progress(f"cpu baseline: batch {b} (n={n}) eigh {t_eig:.2f} s" + (f", eigvalsh {row['eigvalsh_s']:.2f} s" if not last else ""))
+        eig_rows.append(row)
         del gram
 
     def extrap(rows, key, textbook):
-        a, b_ = rows[0], rows[-1]
-        e = textbook
-        if len(rows) > 1 and a[key] > 0:
-            e = min(math.log(b_[key] / a[key]) / math.log(b_["n"] / a["n"]), textbook)  # never steeper than the flop count
-        return b_[key] * (full_n / b_["n"]) ** e, e
+        """Least-squares line through (log n, log t) of all sampled sizes, slope capped at the flop count's exponent;
+        the prediction at full_n and the fit's worst residual |log(t_measured / t_fit)| (0 for two points)."""
+        pts = [(math.log(r["n"]), math.log(r[key])) for r in rows if key in r and r[key] > 0]
+        if len(pts) < 2:
+            r = rows[-1]
+            return r[key] * (full_n / r["n"]) ** textbook, textbook, 0.0
+        mx, my = sum(x for x, _ in pts) / len(pts), sum(y for _, y in pts) / len(pts)
+        sxx = sum((x - mx) ** 2 for x, _ in pts)
+        e = min(sum((x - mx) * (y - my) for x, y in pts) / sxx, textbook)   # never steeper than the flop count
+        # anchor the (possibly capped) line at the LARGEST sample: the regime closest to the full size
+        xl, yl = pts[-1]
+        resid = max(abs(y - (yl + e * (x - xl))) for x, y in pts)
+        return math.exp(yl + e * (math.log(full_n) - xl)), e, resid
 
-    tg, eg = extrap(gram_rows, "gram_materialised_s", 2.0)
-    tf, ef = extrap(gram_rows, "gram_factorised_s", 2.0)
-    te, ee = extrap(eig_rows, "eigh_s", 3.0)
-    tv, ev_ = extrap(eig_rows, "eigvalsh_s", 3.0)
+    tg, eg, rg = extrap(gram_rows, "gram_materialised_s", 2.0)
+    tf, ef, rf = extrap(gram_rows, "gram_factorised_s", 2.0)
+    te, ee, re_ = extrap(eig_rows, "eigh_s", 3.0)
+    tv, ev_, rv = extrap(eig_rows, "eigvalsh_s", 3.0)
     value = full_n / (tg + te)
     return {
         "value": value,
@@ -380,13 +395,16 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256), eig_batches=(256, 
         "thread_probe_s": table,
         "samples": {"gram": gram_rows, "eigh": eig_rows},
         "fitted_exponents": {"gram_materialised": eg, "gram_factorised": ef, "eigh": ee, "eigvalsh": ev_},
+        "fit_points": {"gram": len(gram_rows), "eigh": len(eig_rows)},
+        "fit_worst_log_residual": {"gram_materialised": rg, "gram_factorised": rf, "eigh": re_, "eigvalsh": rv},
         "extrapolated_s": {"gram_materialised": tg, "gram_factorised": tf, "eigh": te, "eigvalsh": tv},
         "materialised_eigenpairs_per_s": value,
         "factorised_eigenpairs_per_s": full_n / (tf + te),
         "sample": (
-            f"same MLP (P={full_P}), median of {repeats} after a warm-up, {threads} threads ({_cpu_model()}): einsum Gram at "
-            f"n={[r['n'] for r in gram_rows]}, torch.linalg.eigh at n={[r['n'] for r in eig_rows]}; value = materialised line "
-            f"extrapolated to n={full_n} with the exponents fitted between the two sizes (Gram n^{eg:.2f}, eigh n^{ee:.2f})"
+            f"same MLP (P={full_P}), median of {repeats} after a warm-up (largest size of each phase: one run), {threads} threads "
+            f"({_cpu_model()}): einsum Gram at n={[r['n'] for r in gram_rows]}, torch.linalg.eigh at n={[r['n'] for r in eig_rows]}; "
+            f"value = materialised line extrapolated to n={full_n} along the least-squares exponents of the {len(gram_rows)} / "
+            f"{len(eig_rows)} sizes (Gram n^{eg:.2f}, eigh n^{ee:.2f}; worst fit residual {max(rg, re_) * 100:.1f} %), anchored at the largest sample"
         ),
     }
 
@@ -515,8 +533,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the parity check after the timed loop")
     ap.add_argument("--no-secondary", action="store_true", help="skip the values-only / top-10 secondary lines")
-    ap.add_argument("--cpu-batches", default="128,256", help="batch sizes of the CPU baseline's einsum-Gram sample")
-    ap.add_argument("--cpu-eig-batches", default="512,1024", help="batch sizes of the CPU baseline's eigh sample (n = 10 x batch)")
+    ap.add_argument("--cpu-batches", default="128,256,512", help="batch sizes of the CPU baseline's einsum-Gram sample")
+    ap.add_argument("--cpu-eig-batches", default="512,1024,2048", help="batch sizes of the CPU baseline's eigh sample (n = 10 x batch)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (configs block)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="torch.distributed backend of a multi-rank run (default nccl = RCCL over xGMI; gloo: functional "
@@ -555,6 +573,20 @@ def main():
 
     from vivit_amd import _lib, kernels
     from vivit_amd import distributed as vdist
+
+    # what the process group REALLY is (not argv): world size, backend string, every rank's device -- into the JSON line
+    mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index),
+            "gcn_arch": getattr(torch.cuda.get_device_properties(dev_index), "gcnArchName", None),
+            "cus": torch.cuda.get_device_properties(dev_index).multi_processor_count, "pid": os.getpid()}
+    if dist is not None:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
+        world_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": ranks_info,
+                      "distinct_devices": len({(r["device_index"]) for r in ranks_info})}
+        if world_info["world_size"] != world:
+            raise SystemExit(f"process group has {world_info['world_size']} ranks, --gpus says {world}")
+    else:
+        world_info = {"world_size": 1, "backend": None, "ranks": [mine], "distinct_devices": 1}
 
     dims, batch, C = WORKLOADS[args.workload]
     n = C * batch
@@ -861,7 +893,8 @@ def main():
             "metric": f"GGN eigenpairs/sec (Gram build + symeig), MLP {dims[0]}-{dims[1]}-{dims[2]}, batch={batch}",
             "value": value,
             "unit": "eigenpairs/s",
-            "n_gpus": world,
+            "n_gpus": world_info["world_size"],
+            "world": world_info,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -901,8 +934,9 @@ def main():
             torch.cuda.empty_cache()
             out["configs"] = bench_configs.run_configs(device, progress=_progress)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dims, C, n, P_total, batches=tuple(min(int(b), batch) for b in args.cpu_batches.split(",")),
-                                               eig_batches=tuple(min(int(b), batch) for b in args.cpu_eig_batches.split(",")))
+            out["cpu_baseline"] = cpu_baseline(dims, C, n, P_total,
+                                               batches=tuple(sorted({min(int(b), batch) for b in args.cpu_batches.split(",")})),
+                                               eig_batches=tuple(sorted({min(int(b), batch) for b in args.cpu_eig_batches.split(",")})))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -117,3 +117,27 @@ def test_slide_refuses_unaligned_shapes():
     assert exc.value.status == _lib.VIVIT_E_UNSUPPORTED
     out = kernels.q2_apply_(Z0.clone(), R2, tau2, mode=-1)   # the solver's choice falls back to the block steps
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("waves,loaders", [(5, 0), (11, 0), (12, 0), (5, 2), (10, 2)])
+def test_slide_wave_configurations(tmp_path, waves, loaders):
+    """the self-load path of qs_apply_kernel (no loader waves: LOADERS=0, or more than ten compute waves --
+    which the product only takes for > 160 rows per CU, i.e. nrows > 40 960 or a CU-masked partition) has hand-counted
+    s_waitcnt vmcnt(4) waits that no test reached.  Child processes (the knobs are read once per process) force 5 / 11 / 12
+    compute waves without loaders, and two loader configurations for comparison: against the fp64 sequential reflectors,
+    against the block-step kernels, orthonormality, bit-reproducibility."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = tmp_path / "q2.json"
+    subprocess.run([sys.executable, os.path.join(here, "q2_slide_child.py"), str(out)], check=True, timeout=600,
+                   env=dict(os.environ, VIVIT_Q2_SLIDE_WAVES=str(waves), VIVIT_Q2_SLIDE_LOADERS=str(loaders)))
+    res = json.loads(out.read_text())
+    for key, row in res["sequential"].items():
+        assert row["block"] <= 3e-6 and row["slide"] <= 3e-6, (key, row)
+        assert row["slide"] <= 3.0 * row["block"] + 2e-7, (key, row)
+    for key, row in res["block_steps"].items():
+        assert row["diff"] <= 5e-6 and row["orth"] <= 5e-6 and row["bitwise_repeat"], (key, row)

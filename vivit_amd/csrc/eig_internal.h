@@ -81,11 +81,12 @@ int prescale_launch(float *A, int64_t n, int64_t lda, float *scal, float *part, 
 int symmetrize_launch(float *G, int64_t n, int64_t ldg, hipStream_t stream);
 
 // q2apply.hip: Zt[nrows x n] <- Zt * Q2^T (Q2 = bulge-chasing reflectors of sb2st_launch, R2 with r2rows = n)
-size_t q2_workspace_bytes(int64_t n);
+size_t q2_workspace_bytes(int64_t n, int64_t max_rows);   // max_rows: most rows one call will transform (< 0: unknown)
 int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const float *R2, int64_t ldr, const float *tau2,
                     void *ws, hipStream_t stream, int mode = -1);
 // q2slide.hip: the same transformation with a sliding window per row slab on the bf16 matrix pipe (many rows)
 size_t q2_slide_workspace_bytes(int64_t n);
+bool q2_slide_possible(int64_t nrows, int64_t n);   // by shape and environment only (workspace queries)
 bool q2_slide_ok(int64_t nrows, int64_t n, const float *Zt, int64_t ldz);
 int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const float *R2, int64_t ldr, const float *tau2, void *ws,
                     size_t ws_bytes, hipStream_t stream);

@@ -557,7 +557,7 @@ __device__ __forceinline__ gcptr dma_src(const float *P, int64_t ld, int64_t row
 }
 
 __device__ __forceinline__ void dma16(gcptr src, unsigned lds_byte_addr) {
-  __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory");
+  __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
 }
 
 template <int ALAY, int BLAY>
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx +
                                                        (unsigned)(wave * 1024));
   auto dma16b = [&](gcptr16 src, unsigned lds_byte_addr) __attribute__((always_inline)) {
-    __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory");
+    __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
   };
   // part q of the 12 requests of one K tile: q = 0..3 -> (block u = q / 2, operand q % 2), three pieces each
   auto issue_part = [&](int st, int q) __attribute__((always_inline)) {
@@ -2556,10 +2556,14 @@ static int gemm64_launch(int alay, int blay, GemmArgs p, void *workspace, size_t
     if (!workspace || workspace_bytes < slab_bytes) return VIVIT_E_WORKSPACE;
     p.slab = static_cast<float *>(workspace);
   }
-  // the bf16-pipe form needs room for the pieces of A behind the slab; without it the fp32 form runs
+  // The bf16-pipe form needs room for the pieces of A behind the slab.  Which kernel runs depends on SHAPE and ENVIRONMENT
+  // only (results are bit-identical from call to call, include/vivit_hip.h): a workspace smaller than the query's answer is
+  // refused -- it is never a silent switch to the fp32 kernel, whose summation order (and speed) differs.
   uint4 *apieces = nullptr;
-  if (gemm64_bx_enabled() && workspace && workspace_bytes >= need)
+  if (gemm64_bx_enabled()) {
+    if (!workspace || workspace_bytes < need) return VIVIT_E_WORKSPACE;
     apieces = reinterpret_cast<uint4 *>(static_cast<char *>(workspace) + align_up(slab_bytes, 256));
+  }
   p.tiles_m = 1;
   p.tiles_n = (int)cdiv(p.N, 256);
   p.syrk = 0;

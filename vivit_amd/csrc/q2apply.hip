@@ -459,9 +459,13 @@ static size_t q2_step_workspace_bytes(int64_t n) {
   return (size_t)Q2_WIN * 2 * (ngroups + 2) * QW * QWIN * sizeof(float) + 256;
 }
 
-// either form may be selected at run time (q2slide.hip: the sliding-window form for many rows)
-size_t q2_workspace_bytes(int64_t n) {
-  const size_t a = q2_step_workspace_bytes(n), b = q2_slide_workspace_bytes(n);
+// Either form may be selected at run time -- by SHAPE only: the sliding-window form (q2slide.hip) for at least
+// VIVIT_Q2_SLIDE_MIN_ROWS rows.  `max_rows` = the largest row count the caller will transform with this workspace; the
+// block images of the sliding-window form (up to 2 GB) are only included when such a call could select it (a top-10
+// selection at n = 40 960 reserves 0.2 GB instead of 2 GB).  max_rows < 0: unknown (the public mode switch) -> both.
+size_t q2_workspace_bytes(int64_t n, int64_t max_rows) {
+  const size_t a = q2_step_workspace_bytes(n);
+  const size_t b = (max_rows < 0 || q2_slide_possible(max_rows, n)) ? q2_slide_workspace_bytes(n) : 0;
   return a > b ? a : b;
 }
 
@@ -471,7 +475,7 @@ int q2_apply_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
   if (n < 3) return VIVIT_OK;
   // mode: -1 automatic, 0 block steps (this file), 1 sliding window (q2slide.hip)
   if (mode == 1 || (mode < 0 && q2_slide_ok(nrows, n, Zt, ldz)))
-    return q2_slide_launch(Zt, ldz, nrows, n, R2, ldr, tau2, ws, q2_workspace_bytes(n), stream);
+    return q2_slide_launch(Zt, ldz, nrows, n, R2, ldr, tau2, ws, q2_workspace_bytes(n, mode == 1 ? -1 : nrows), stream);
   static unsigned long long attr_done = 0;
   {
     int dev = 0;
@@ -555,7 +559,7 @@ using namespace vivit;
 
 extern "C" {
 
-size_t vivit_q2_apply_f32_workspace_bytes(int64_t n) { return n < 3 ? 0 : q2_workspace_bytes(n) + 512; }
+size_t vivit_q2_apply_f32_workspace_bytes(int64_t n) { return n < 3 ? 0 : q2_workspace_bytes(n, -1) + 512; }
 
 int vivit_q2_apply_f32(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const float *R2, int64_t ldr, const float *tau2,
                        void *workspace, size_t workspace_bytes, int mode, void *stream) {

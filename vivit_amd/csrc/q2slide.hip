@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
       for (int f = lw; f < QS_NFRAG; f += nl) {
         const unsigned char *src = a.img + seq * (int64_t)QS_IMG + (int64_t)f * 1024;
         const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG + (unsigned)f * 1024u);
-        __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");
+        __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory", "m0");
       }
     };
     if (nseq > 0) request(0);
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
       // were spilled by the 168-register instantiation)
       const unsigned char *src = a.img + seq * (int64_t)QS_IMG + (int64_t)f * 1024;
       const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG + (unsigned)f * 1024u);
-      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");
+      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory", "m0");
     }
   };
   const int npiece = (QS_NFRAG + nw - 1) / nw;   // pieces per wave (the last one only for some waves)
@@ -670,14 +670,18 @@ static int qs_env(const char *name, int dflt) {
 }
 
 // the sliding-window form pays when every CU gets a slab of a few waves: rows >= QS_MIN_ROWS (VIVIT_Q2_SLIDE_MIN_ROWS)
-bool q2_slide_ok(int64_t nrows, int64_t n, const float *Zt, int64_t ldz) {
+// (shape part of the decision: what the workspace queries can know)
+bool q2_slide_possible(int64_t nrows, int64_t n) {
   static int on = -1, min_rows = 0;
   if (on < 0) {
     on = qs_env("VIVIT_Q2_SLIDE", 1);
     min_rows = qs_env("VIVIT_Q2_SLIDE_MIN_ROWS", 14336);
   }
-  const bool vec = ((reinterpret_cast<uintptr_t>(Zt) & 15) == 0) && (ldz % 4 == 0) && (n % 4 == 0);
-  return on != 0 && vec && n >= 192 && nrows >= min_rows && device_cu_count() > 0;
+  return on != 0 && n % 4 == 0 && n >= 192 && nrows >= min_rows;
+}
+bool q2_slide_ok(int64_t nrows, int64_t n, const float *Zt, int64_t ldz) {
+  const bool vec = ((reinterpret_cast<uintptr_t>(Zt) & 15) == 0) && (ldz % 4 == 0);
+  return q2_slide_possible(nrows, n) && vec && device_cu_count() > 0;
 }
 
 int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const float *R2, int64_t ldr, const float *tau2, void *ws,

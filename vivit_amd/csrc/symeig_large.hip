@@ -194,7 +194,7 @@ size_t symeig_large_workspace_bytes(int64_t n, bool vectors) {
   size_t two = two_stage_workspace_bytes(n, vectors);
   size_t b = one > two ? one : two;   // either reduction may be selected at run time
   b += stedc_workspace_bytes(n, vectors);
-  if (vectors) b += bt_workspace_bytes(n) + q2_workspace_bytes(n) + 512;
+  if (vectors) b += bt_workspace_bytes(n) + q2_workspace_bytes(n, n) + 512;
   return b;
 }
 
@@ -290,7 +290,7 @@ static int symeig_large_impl(float *A, int64_t n, int64_t lda, float *w, float *
     int *order;
     st = stedc_dc_launch(d, e, n, dc_base, &Qt, &dd, &order, info, stream);
     if (st != VIVIT_OK) return st;
-    void *q2ws = take(q2_workspace_bytes(n));
+    void *q2ws = take(q2_workspace_bytes(n, n));
     if (rows_mode) {
       st = dc_rows_launch(n, dd, Qt, n, order, w, Z, ldz, r0, r1, scal, stream);
       if (st != VIVIT_OK) return st;
@@ -438,7 +438,7 @@ size_t symeig_reduce_workspace_bytes(int64_t n) {
 size_t symeig_select_workspace_bytes(int64_t n, int64_t K) {
   if (K < 1) K = 1;
   if (K > n) K = n;
-  size_t b = select_two_stage(n) ? q2_workspace_bytes(n) + 512 : 0;
+  size_t b = select_two_stage(n) ? q2_workspace_bytes(n, K) + 512 : 0;
   const size_t after = bt_workspace_bytes(n);
   if (K > SELECT_STEIN_MAX) {  // D&C buffers, reused by the back-transformations afterwards
     const size_t dc = align_up(stedc_workspace_bytes(n, true), 256);
@@ -520,7 +520,7 @@ int symeig_select_launch(const float *A, int64_t n, int64_t lda, const int *sel,
   }
   prof_mark(PROF_STAGE_TRIDIAG, stream);
   if (L.two_stage) {
-    void *q2ws = take(q2_workspace_bytes(n));
+    void *q2ws = take(q2_workspace_bytes(n, K));
     st = q2_apply_launch(Zt, ldz, K, n, L.R2, n, L.tau2, q2ws, stream);
     if (st != VIVIT_OK) return st;
     prof_mark(PROF_STAGE_Q2, stream);
@@ -586,7 +586,7 @@ int symeig_banded_rows_launch(float *A, int64_t n, int64_t lda, const float *tau
   int *order;
   st = stedc_dc_launch(d, e, n, dc_base, &Qt, &dd, &order, info, stream);
   if (st != VIVIT_OK) return st;
-  void *q2ws = take(q2_workspace_bytes(n));
+  void *q2ws = take(q2_workspace_bytes(n, n));
   st = dc_rows_launch(n, dd, Qt, n, order, w, Zt, ldz, r0, r1, scal, stream);
   if (st != VIVIT_OK) return st;
   prof_mark(PROF_STAGE_TRIDIAG, stream);

@@ -110,10 +110,15 @@ def make_problem(name):
         model = nn.Sequential(nn.Conv2d(4, 4, 2, groups=2), nn.ReLU(), nn.ConvTranspose2d(4, 2, 2, stride=2, groups=2), nn.Tanh(),
                               nn.Flatten(2), nn.Conv1d(2, 4, 3, stride=2, groups=2), nn.Flatten(), nn.Linear(28, 3))
         X, y, lossf, loss = torch.rand(3, 4, 3, 3), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
+    elif name == "net3d_ce":  # the 3-D rows of the reference's module map (__init__.py:92-101; convnd.py:25-30, convtransposend.py:25-30)
+        model = nn.Sequential(nn.Conv3d(2, 4, (2, 3, 2), stride=(1, 2, 1), padding=(1, 1, 0), groups=2), nn.ReLU(), nn.MaxPool3d(2, stride=(1, 2, 1)),
+                              nn.ConvTranspose3d(4, 2, 2, stride=(2, 1, 1), padding=(1, 0, 0), output_padding=(1, 0, 0)), nn.Tanh(),
+                              nn.AvgPool3d((2, 1, 2), stride=1, padding=(1, 0, 0)), nn.Flatten(), nn.Linear(2 * 6 * 2 * 3, 3))
+        X, y, lossf, loss = torch.rand(3, 2, 3, 5, 5), torch.randint(0, 3, (3,)), nn.CrossEntropyLoss(), "ce"
     return model, X, y, lossf, loss
 
 
-PROBLEMS = ["grouped_ce", "pool1d_ce", "zeropad_ce", "mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce", "branching_ce", "resblock_ce",
+PROBLEMS = ["net3d_ce", "grouped_ce", "pool1d_ce", "zeropad_ce", "mlp_ce", "mlp_mse", "cnn_ce", "bn_ce", "linear_extra_mse", "bn2d_ce", "branching_ce", "resblock_ce",
             "conv1d_mse", "conv3d_ce", "convtranspose_ce"]
 
 
@@ -147,11 +152,12 @@ def test_sqrt_ggn_and_batch_grad_factors(problem, subsampling, device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("problem", ["grouped_ce", "linear_extra_mse", "convtranspose_ce", "conv1d_mse", "cnn_ce"])
+@pytest.mark.parametrize("problem", ["grouped_ce", "linear_extra_mse", "convtranspose_ce", "conv1d_mse", "cnn_ce", "conv3d_ce", "net3d_ce"])
 def test_weight_rules_run_on_the_hip_kernels(problem, monkeypatch):
-    """The weight rules of Linear with extra input dimensions, of grouped and of transposed 1-D / 2-D convolutions and the
-    input rules of these modules are launches of the HIP kernels: the torch.func.vmap / einsum / autograd rules must not
-    be reached on the GPU."""
+    """The weight rules of Linear with extra input dimensions, of grouped and of transposed 1-D / 2-D convolutions, of
+    Conv3d / ConvTranspose3d, and the input rules of these modules and of 3-D pooling are launches of the HIP kernels: the
+    torch.func.vmap / einsum / autograd rules must not be reached on the GPU (round 5: no counted layer of the reference's
+    module map, vivit/extensions/secondorder/vivit/__init__.py:84-118, rides autograd.grad)."""
     from vivit_amd.backend import extensions as ext
 
     def forbidden(*a, **k):
@@ -194,6 +200,62 @@ def test_convtranspose_input_rule_on_the_convolution_kernel(cin, cout, k, s, p, 
         got = ext._hip_convtranspose_jac_t(m, M, x.detach())
         assert got is not None and got.shape == ref.shape
         close(got, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(6))
+def test_3d_rules_on_the_2d_kernels(case):
+    """Conv3d / ConvTranspose3d weight and input rules (one launch of the 2-D kernel per depth tap, depth slices stacked along
+    the image height) and Max/AvgPool3d (separable: in-plane stage + depth stage) against autograd / the vmap rule, with
+    strides, paddings, dilations, groups and output paddings that differ per axis; MaxPool3d also with many tied maxima."""
+    from vivit_amd.backend import extensions as ext
+
+    torch.manual_seed(case)
+    dev = torch.device("cuda:0")
+    conv = [dict(cin=2, cout=4, k=2, s=1, p=0, d=1, g=2), dict(cin=3, cout=5, k=(3, 2, 3), s=(2, 1, 2), p=(1, 0, 2), d=(1, 2, 1), g=1),
+            dict(cin=4, cout=6, k=3, s=2, p=1, d=1, g=2), dict(cin=2, cout=3, k=(2, 3, 1), s=(1, 3, 2), p=(2, 1, 0), d=(2, 1, 1), g=1),
+            dict(cin=3, cout=3, k=3, s=1, p=1, d=1, g=3), dict(cin=2, cout=2, k=(1, 3, 3), s=(3, 2, 1), p=(0, 2, 1), d=1, g=1)][case]
+    m = nn.Conv3d(conv["cin"], conv["cout"], conv["k"], stride=conv["s"], padding=conv["p"], dilation=conv["d"], groups=conv["g"]).to(dev)
+    x = torch.rand(3, conv["cin"], 6, 7, 5, device=dev, requires_grad=True)
+    y = m(x)
+    M = torch.rand(2, *y.shape, device=dev)
+    (gx,) = torch.autograd.grad(y, x, M, is_grads_batched=True)
+    close(ext._hip_conv3d_jac_t(m, M, x.detach()), gx, rtol=1e-5, atol=1e-6)
+    close(ext._hip_conv3d_weight_factor(m, M, x.detach()), ext._conv_weight_factor(m, M, x.detach()), rtol=1e-5, atol=1e-6)
+    tconv = [dict(cin=2, cout=3, k=2, s=2, p=0, d=1, op=1, g=1), dict(cin=4, cout=2, k=(2, 3, 2), s=(2, 1, 2), p=(0, 1, 0), d=1, op=0, g=2),
+             dict(cin=3, cout=2, k=3, s=1, p=1, d=1, op=0, g=1), dict(cin=4, cout=6, k=3, s=2, p=1, d=2, op=1, g=2),
+             dict(cin=3, cout=5, k=(2, 3, 3), s=(3, 1, 2), p=(1, 2, 0), d=(1, 1, 2), op=(2, 0, 1), g=1),
+             dict(cin=2, cout=2, k=(1, 2, 2), s=1, p=0, d=1, op=0, g=2)][case]
+    m = nn.ConvTranspose3d(tconv["cin"], tconv["cout"], tconv["k"], stride=tconv["s"], padding=tconv["p"], dilation=tconv["d"],
+                           output_padding=tconv["op"], groups=tconv["g"]).to(dev)
+    x = torch.rand(3, tconv["cin"], 3, 4, 3, device=dev, requires_grad=True)
+    y = m(x)
+    M = torch.rand(2, *y.shape, device=dev)
+    (gx,) = torch.autograd.grad(y, x, M, is_grads_batched=True)
+    got = ext._hip_convtranspose3d_jac_t(m, M, x.detach())
+    assert got is not None
+    close(got, gx, rtol=1e-5, atol=1e-6)
+    close(ext._hip_conv3d_weight_factor(m, M, x.detach()), ext._conv_weight_factor(m, M, x.detach()), rtol=1e-5, atol=1e-6)
+    pool_kw = [dict(kernel_size=2), dict(kernel_size=(3, 2, 2), stride=(1, 2, 1), padding=(1, 1, 0)), dict(kernel_size=3, stride=2, padding=1),
+               dict(kernel_size=(1, 3, 2), stride=(1, 1, 2)), dict(kernel_size=(2, 2, 3), stride=(2, 1, 1), padding=(1, 0, 1)), dict(kernel_size=(4, 1, 1))][case]
+    for cls in (nn.MaxPool3d, nn.AvgPool3d):
+        for ties in (False, True):
+            x = torch.rand(2, 3, 6, 7, 5, device=dev)
+            if ties:
+                x = (x * 3).floor()
+                if cls is nn.MaxPool3d:   # tie-breaking of the reference op is device-specific: check the VALUE of the selection
+                    pool = cls(**pool_kw)
+                    M = torch.rand(2, *pool(x).shape, device=dev)
+                    g = ext._hip_pool3d_jac_t(pool, M, x)
+                    # every output's cotangent lands on exactly one element of its window: the sums per (v, n) agree
+                    close(g.sum((2, 3, 4, 5)), M.sum((2, 3, 4, 5)), rtol=1e-5, atol=1e-6)
+                    continue
+            x.requires_grad_(True)
+            pool = cls(**pool_kw)
+            y = pool(x)
+            M = torch.rand(2, *y.shape, device=dev)
+            (gx,) = torch.autograd.grad(y, x, M, is_grads_batched=True)
+            close(ext._hip_pool3d_jac_t(pool, M, x.detach()), gx, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("problem", PROBLEMS)

@@ -126,9 +126,10 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
     if isinstance(module, _CONVS):
         if name == "bias":
             return _spatial_sum(M, 3)
-        if (M.is_cuda and M.dtype == torch.float32 and isinstance(module, (nn.Conv2d, nn.Conv1d, nn.ConvTranspose2d, nn.ConvTranspose1d))
-                and isinstance(module.padding, tuple) and module.padding_mode == "zeros"):
+        if (M.is_cuda and M.dtype == torch.float32 and isinstance(module.padding, tuple) and module.padding_mode == "zeros"):
             try:
+                if isinstance(module, (nn.Conv3d, nn.ConvTranspose3d)):
+                    return _hip_conv3d_weight_factor(module, M, x)
                 return _hip_conv_weight_factor(module, M, x)
             except _lib.VivitHipError as exc:  # shapes outside the kernel's launch limits: the torch rule below
                 if exc.status != _lib.VIVIT_E_UNSUPPORTED:
@@ -193,6 +194,144 @@ def _hip_conv_weight_factor(module, M: Tensor, x: Tensor) -> Tensor:
     return out.squeeze(4) if one_d else out
 
 
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(v)
+
+
+def _depth_range(n_out: int, n_in: int, s: int, p: int, off: int):
+    """Positions ``q`` in ``[0, n_out)`` whose partner ``q s - p + off`` lies in ``[0, n_in)``: ``(q_lo, q_hi, first partner)``
+    (``q_hi < q_lo``: none)."""
+    q_lo = max(0, -((off - p) // s))            # ceil((p - off) / s)
+    q_hi = min(n_out - 1, (n_in - 1 + p - off) // s)
+    return q_lo, q_hi, q_lo * s - p + off
+
+
+def _conv3d_weight_contract(coef: Tensor, image: Tensor, ks, st, pd, dl) -> Tensor:
+    """``out[v, n, c, i, kd, kh, kw] = sum_q coef[v, n, c, qd, qh, qw] image[n, i, qd sd - pd + kd dd, qh sh - ph + kh dh,
+    qw sw - pw + kw dw]`` -- the weight rule of a three-dimensional convolution -- on the TWO-dimensional HIP kernel, one
+    launch per depth tap ``kd``: the depth slices are stacked along the height of one tall image.  Behind each coefficient
+    slice stand ``ceil((KH - 1) dh / sh)`` zero rows, so that a window that starts in a slice's last rows and runs into the
+    next slice meets a zero coefficient; the image slices carry their height padding explicitly at the matching pitch.
+    ``coef: [V, N, C, QD, QH, QW]``, ``image: [N, I, D, H, W]`` -> ``[V, N, C, I, KD, KH, KW]``."""
+    Vc, Nc, Cc, QD, QH, QW = coef.shape
+    _, Ci, D, H, W = image.shape
+    (KD, KH, KW), (sd, sh, sw), (pdd, ph, pw), (dd, dh, dw) = ks, st, pd, dl
+    extra = -(-((KH - 1) * dh) // sh)
+    QHp = QH + extra
+    Hp = QHp * sh                      # pitch of an image slice: window row qh sh + kh dh of slice qd is row qd Hp + ...
+    tail = (KH - 1) * dh               # rows behind the last slice that windows of (zero) coefficient rows still address
+    cs = coef.new_zeros((Vc, Nc, Cc, QD, QHp, QW))
+    cs[..., :QH, :] = coef
+    cs = cs.view(Vc, Nc, Cc, QD * QHp, QW)
+    hrows = min(H, Hp - ph)            # image rows that fall inside a slice (the rest is never read by a live window)
+    outs = []
+    for kd in range(KD):
+        xs = image.new_zeros((Nc, Ci, QD * Hp + tail, W))
+        q_lo, q_hi, d_lo = _depth_range(QD, D, sd, pdd, kd * dd)
+        if q_hi >= q_lo and hrows > 0:
+            nq = q_hi - q_lo + 1
+            xv = xs[:, :, :QD * Hp].view(Nc, Ci, QD, Hp, W)
+            xv[:, :, q_lo:q_hi + 1, ph:ph + hrows] = image[:, :, d_lo:d_lo + (nq - 1) * sd + 1:sd, :hrows]
+        outs.append(kernels.conv2d_weight_mjp(cs, xs, (KH, KW), (sh, sw), (0, pw), (dh, dw)))
+    return torch.stack(outs, 4)
+
+
+def _hip_conv3d_weight_factor(module, M: Tensor, x: Tensor) -> Tensor:
+    """Weight rule of Conv3d / ConvTranspose3d (any ``groups``, zero padding; convnd.py:25-30, convtransposend.py:25-30)
+    on the HIP kernel of the two-dimensional rule (:func:`_conv3d_weight_contract`).  As in two dimensions, the transposed
+    convolution's rule is the same contraction with the roles of factor and input swapped, and a grouped layer is one
+    contraction per group on its channel slices."""
+    transposed = isinstance(module, nn.ConvTranspose3d)
+    ks, st, pd, dl = module.kernel_size, module.stride, module.padding, module.dilation
+    V, N, G = M.shape[0], M.shape[1], module.groups
+    if transposed:
+        coef = x.unsqueeze(0).expand(V, *x.shape).reshape(1, V * N, *x.shape[1:])     # [1, V N, Cin, Dq, Hq, Wq]
+        image = M.reshape(V * N, *M.shape[2:])                                         # [V N, Cout, D', H', W']
+    else:
+        coef, image = M, x
+    Cc, Ci = coef.shape[2] // G, image.shape[1] // G
+    parts = []
+    for g in range(G):
+        c = coef if G == 1 else coef[:, :, g * Cc:(g + 1) * Cc]
+        im = image if G == 1 else image[:, g * Ci:(g + 1) * Ci]
+        parts.append(_conv3d_weight_contract(c, im, ks, st, pd, dl))
+    out = parts[0] if G == 1 else torch.cat(parts, 2)
+    return out.view(V, N, *out.shape[2:]) if transposed else out
+
+
+def _hip_conv3d_jac_t(module, M: Tensor, x: Tensor) -> Tensor:
+    """Input rule of Conv3d (any ``groups``, zero padding) on the two-dimensional HIP kernel: for every depth tap ``kd`` the
+    output slices ``od`` are a batch of two-dimensional problems whose results are added into the input slices
+    ``d = od sd - pd + kd dd`` (for a fixed tap that map is one strided slice)."""
+    W = module.weight.detach()
+    (KD, KH, KW), (sd, sh, sw), (pdd, ph, pw), (dd, dh, dw) = module.kernel_size, module.stride, module.padding, module.dilation
+    V, N, Cout, OD, OH, OW = M.shape
+    _, Cin, D, H, Wd = x.shape
+    G = module.groups
+    Co, Ci = Cout // G, Cin // G
+    Mt = M.permute(0, 1, 3, 2, 4, 5).reshape(V, N * OD, Cout, OH, OW)
+    g = M.new_zeros((V, N, Cin, D, H, Wd))
+    for kd in range(KD):
+        o_lo, o_hi, d_lo = _depth_range(OD, D, sd, pdd, kd * dd)
+        if o_hi < o_lo:
+            continue
+        Wk = W[:, :, kd]
+        if G == 1:
+            res = kernels.conv2d_jac_t(Mt, Wk, (H, Wd), (sh, sw), (ph, pw), (dh, dw))
+        else:
+            res = torch.cat([kernels.conv2d_jac_t(Mt[:, :, i * Co:(i + 1) * Co].contiguous(), Wk[i * Co:(i + 1) * Co].contiguous(),
+                                                  (H, Wd), (sh, sw), (ph, pw), (dh, dw)) for i in range(G)], 2)
+        res = res.view(V, N, OD, Cin, H, Wd)[:, :, o_lo:o_hi + 1].permute(0, 1, 3, 2, 4, 5)
+        g[:, :, :, d_lo:d_lo + (o_hi - o_lo) * sd + 1:sd] += res
+    return g
+
+
+def _hip_convtranspose3d_jac_t(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
+    """Input rule of ConvTranspose3d: a forward convolution of ``M`` with the weight,
+    ``g[ci, q] = sum_{co, k} W[ci, co, k] M[co, q s - p + k d]`` -- per depth tap ``kd`` the two-dimensional rule of
+    :func:`_convtranspose2d_input` on the slices ``M[.., qd sd - pd + kd dd]`` (a batch), summed over the taps."""
+    W = module.weight.detach()
+    (KD, KH, KW), (sd, sh, sw), (pdd, ph, pw), (dd, dh, dw) = module.kernel_size, module.stride, module.padding, module.dilation
+    V, N, Cout, Dm, Hm, Wm = M.shape
+    _, Cin, QD, QH, QW = x.shape
+    g = M.new_zeros((V, N, Cin, QD, QH, QW))
+    for kd in range(KD):
+        q_lo, q_hi, d_lo = _depth_range(QD, Dm, sd, pdd, kd * dd)
+        if q_hi < q_lo:
+            continue
+        nq = q_hi - q_lo + 1
+        Mk = M[:, :, :, d_lo:d_lo + (nq - 1) * sd + 1:sd].permute(0, 1, 3, 2, 4, 5).reshape(V, N * nq, Cout, Hm, Wm)
+        res = _convtranspose2d_input(Mk, W[:, :, kd], (KH, KW), (sh, sw), (ph, pw), (dh, dw), module.groups, (QH, QW))
+        if res is None:
+            return None
+        g[:, :, :, q_lo:q_hi + 1] += res.view(V, N, nq, Cin, QH, QW).permute(0, 1, 3, 2, 4, 5)
+    return g
+
+
+def _hip_pool3d_jac_t(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
+    """MaxPool3d / AvgPool3d on the two-dimensional pooling kernels.  Both poolings are separable -- a window over
+    (d, h, w) is a window over (h, w) in every depth slice followed by a window over d -- and so are their Jacobians:
+    the depth stage is the two-dimensional kernel on the image ``[D, OH * OW]`` with a ``(kd, 1)`` window.  For the
+    maximum the composition selects the same element as the three-dimensional scan (first maximum in d-major order),
+    and -inf padding composes; the average (count_include_pad) divides by kh kw and then by kd."""
+    V, N, C, OD, OH, OW = M.shape
+    _, _, D, H, W = x.shape
+    ks = _triple(module.kernel_size)
+    st = _triple(module.stride if module.stride is not None else module.kernel_size)
+    pd = _triple(module.padding)
+    if isinstance(module, nn.MaxPool3d):
+        if _triple(module.dilation) != (1, 1, 1) or module.ceil_mode or module.return_indices:
+            return None
+        x2 = x.reshape(N, C * D, H, W)
+        y1 = F.max_pool2d(x2, ks[1:], st[1:], pd[1:])                                   # the in-plane maxima (forward values only)
+        g1 = kernels.maxpool2d_jac_t(M.reshape(V, N, C, OD, OH * OW), y1.reshape(N, C, D, OH * OW), (ks[0], 1), (st[0], 1), (pd[0], 0))
+        return kernels.maxpool2d_jac_t(g1.reshape(V, N, C * D, OH, OW), x2, ks[1:], st[1:], pd[1:]).view(V, N, C, D, H, W)
+    if module.ceil_mode or not module.count_include_pad or module.divisor_override is not None:
+        return None
+    g1 = kernels.avgpool2d_jac_t(M.reshape(V, N, C, OD, OH * OW), (D, OH * OW), (ks[0], 1), (st[0], 1), (pd[0], 0))
+    return kernels.avgpool2d_jac_t(g1.reshape(V, N, C * D, OH, OW), (H, W), ks[1:], st[1:], pd[1:]).view(V, N, C, D, H, W)
+
+
 def _conv_weight_factor(module, M: Tensor, x: Tensor) -> Tensor:
     """Weight rule of the convolution family (Conv1d/3d, grouped Conv2d, ConvTranspose1d/2d/3d; the derivative classes
     of vivit/extensions/secondorder/vivit/convnd.py:9-30 and convtransposend.py:9-30): per sample ``n`` and slice ``v``
@@ -230,8 +369,8 @@ def _single(v):
 def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
     """The layer rules that have a HIP kernel (csrc/jacobians.hip): activations, Flatten / Identity / Dropout(eval),
     Max/AvgPool1d/2d, Conv1d / Conv2d and ConvTranspose1d / 2d (any groups, zero padding), Pad / ZeroPad2d / Slicing,
-    BatchNorm (eval).  ``None``: no kernel for this module (Conv3d, ConvTranspose3d, 3-D pooling, custom modules) -- the
-    generic autograd rule takes over."""
+    BatchNorm (eval), and -- on the same two-dimensional kernels -- Conv3d, ConvTranspose3d, MaxPool3d, AvgPool3d.  ``None``: no
+    kernel for this module (custom modules, unsupported options such as ceil_mode) -- the generic autograd rule takes over."""
     kind = _ACTIVATIONS.get(type(module))
     if kind is not None:
         return kernels.act_jac_t(M, x, kind[0], getattr(module, kind[1]) if kind[1] else 0.0)
@@ -298,6 +437,18 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
         g = _hip_convtranspose_jac_t(module, M, x)
         if g is not None:
             return g
+    # three-dimensional layers on the two-dimensional kernels (one launch per depth tap / separable pooling)
+    if isinstance(module, nn.Conv3d) and x.dim() == 5 and isinstance(module.padding, tuple) and module.padding_mode == "zeros":
+        return _hip_conv3d_jac_t(module, M, x)
+    if (isinstance(module, nn.ConvTranspose3d) and x.dim() == 5 and isinstance(module.padding, tuple)
+            and getattr(module, "padding_mode", "zeros") == "zeros"):
+        g = _hip_convtranspose3d_jac_t(module, M, x)
+        if g is not None:
+            return g
+    if isinstance(module, (nn.MaxPool3d, nn.AvgPool3d)) and x.dim() == 5:
+        g = _hip_pool3d_jac_t(module, M, x)
+        if g is not None:
+            return g
     if isinstance(module, _BATCHNORM) and x.dim() >= 2:
         scale = torch.rsqrt(module.running_var + module.eps)
         if module.weight is not None:
@@ -306,15 +457,36 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
     return None
 
 
-def _hip_convtranspose_jac_t(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
-    """Input rule of ConvTranspose1d/2d (convtransposend.py:9-30) on the HIP kernel of the convolution's input rule.
+def _convtranspose2d_input(M: Tensor, W: Tensor, ks, st, pd, dl, G: int, hq) -> Optional[Tensor]:
+    """``g[ci, q] = sum_{co, k} W[ci, co, k] M[co, q s - p + k d]`` for ``M [V, N, Cout, H', W']``, ``W [Cin, Cout / G, kh,
+    kw]`` -> ``[V, N, Cin, *hq]`` on the HIP kernel of the convolution's input rule.
 
-    The transposed Jacobian of y = conv_transpose(x, W) is a forward convolution of ``M`` with ``W``:
-    ``g[ci, q] = sum_{co, k} W[ci, co, k] M[co, q s - p + k d]``.  With the kernel index reversed (k' = K - 1 - k) this is
-    the stride-1 input rule ``sum_{o, k'} W'[o, ci, k'] M[o, y + p' - k' d]`` of a convolution with weight
-    ``W'[co, ci, k'] = W[ci, co, K - 1 - k']`` and padding ``p' = (K - 1) d - p``, evaluated at ``y = q s`` -- the kernel
-    computes every y and the stride picks every s-th (s^2 of the work is discarded for s > 1; transposed convolutions are
-    rare on this path).  ``None`` when p' would be negative or the kernel's channel limit is exceeded."""
+    With the kernel index reversed (k' = K - 1 - k) this is the stride-1 input rule
+    ``sum_{o, k'} W'[o, ci, k'] M[o, y + p' - k' d]`` of a convolution with weight ``W'[co, ci, k'] = W[ci, co, K - 1 - k']``
+    and padding ``p' = (K - 1) d - p``, evaluated at ``y = q s`` -- the kernel computes every y and the stride picks every
+    s-th (s^2 of the work is discarded for s > 1; transposed convolutions are rare on this path).  ``None`` when p' would be
+    negative or the kernel's channel limit is exceeded."""
+    pad2 = tuple((k - 1) * d - p for k, d, p in zip(ks, dl, pd))
+    Cin = W.shape[0]
+    Co, Ci = W.shape[1], Cin // G
+    if min(pad2) < 0 or Co * ks[0] * ks[1] > 1024:
+        return None
+    # input size of the stride-1 rule whose output size is M's:  H' = full + 2 p' - d (K - 1)  <=>  full = H' + 2 p - d (K - 1)
+    full = tuple(h + 2 * p - d * (k - 1) for h, p, d, k in zip(M.shape[3:], pd, dl, ks))
+    if any(f < (q - 1) * s_ + 1 for f, q, s_ in zip(full, hq, st)):
+        return None
+    parts = []
+    for g in range(G):
+        Wg = W[g * Ci:(g + 1) * Ci].transpose(0, 1).flip(2, 3).contiguous()            # [Co, Ci, kh, kw], reversed taps
+        Mg = M if G == 1 else M[:, :, g * Co:(g + 1) * Co].contiguous()
+        parts.append(kernels.conv2d_jac_t(Mg, Wg, full, (1, 1), pad2, dl))
+    out = parts[0] if G == 1 else torch.cat(parts, 2)
+    return out[..., ::st[0], ::st[1]][..., :hq[0], :hq[1]].contiguous()
+
+
+def _hip_convtranspose_jac_t(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
+    """Input rule of ConvTranspose1d/2d (convtransposend.py:9-30): the transposed Jacobian of y = conv_transpose(x, W) is a
+    forward convolution of ``M`` with ``W`` (:func:`_convtranspose2d_input`); a 1-D layer is the 2-D one with a single row."""
     one_d = isinstance(module, nn.ConvTranspose1d)
     W = module.weight.detach()
     if one_d:
@@ -324,22 +496,9 @@ def _hip_convtranspose_jac_t(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
     else:
         ks, st, pd, dl = module.kernel_size, module.stride, module.padding, module.dilation
         hq = tuple(x.shape[2:])
-    pad2 = tuple((k - 1) * d - p for k, d, p in zip(ks, dl, pd))
-    G = module.groups
-    Co, Ci = module.out_channels // G, module.in_channels // G
-    if min(pad2) < 0 or Co * ks[0] * ks[1] > 1024:
+    out = _convtranspose2d_input(M, W, ks, st, pd, dl, module.groups, hq)
+    if out is None:
         return None
-    # input size of the stride-1 rule whose output size is M's:  H' = full + 2 p' - d (K - 1)  <=>  full = H' + 2 p - d (K - 1)
-    full = tuple(h + 2 * p - d * (k - 1) for h, p, d, k in zip(M.shape[3:], pd, dl, ks))
-    if any(f < (q - 1) * s + 1 for f, q, s in zip(full, hq, st)):
-        return None
-    parts = []
-    for g in range(G):
-        Wg = W[g * Ci:(g + 1) * Ci].transpose(0, 1).flip(2, 3).contiguous()            # [Co, Ci, kh, kw], reversed taps
-        Mg = M if G == 1 else M[:, :, g * Co:(g + 1) * Co].contiguous()
-        parts.append(kernels.conv2d_jac_t(Mg, Wg, full, (1, 1), pad2, dl))
-    out = parts[0] if G == 1 else torch.cat(parts, 2)
-    out = out[..., ::st[0], ::st[1]][..., :hq[0], :hq[1]].contiguous()
     return out.squeeze(3) if one_d else out
 
 

@@ -109,6 +109,28 @@ def _spatial_sum3(M: Tensor) -> Tensor:
     return memo
 
 
+def _bn_scale(module) -> Tensor:
+    scale = torch.rsqrt(module.running_var + module.eps)
+    return scale * module.weight.detach() if module.weight is not None else scale
+
+
+def _bn_eval_rules(module, M: Tensor, x: Tensor):
+    """``(M scale_c, sum_l M x, sum_l M)`` of a BatchNorm in eval mode from ONE pass over the factor ``M [V, N, C, *spatial]``
+    (``vivit_bn_eval_rules_f32``), remembered on the tensor: the weight rule, the bias rule and the input rule of the module
+    are three calls on the same ``M`` (round 4: three row reductions and one scaling pass, four reads of ``M``)."""
+    memo = getattr(M, "_vivit_bn_rules", None)
+    if memo is None or memo[0] is not module:
+        Mc = M if M.dim() > 3 else M.unsqueeze(-1)
+        xc = x if x.dim() > 2 else x.unsqueeze(-1)
+        out, mx, ms = kernels.bn_eval_rules(Mc, xc, _bn_scale(module))
+        memo = (module, out.view(M.shape), mx, ms)
+        try:
+            M._vivit_bn_rules = memo
+        except AttributeError:   # (tensor subclasses without a __dict__)
+            pass
+    return memo[1:]
+
+
 def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
     """``param_mjp(..., sum_batch=False)``: ``M`` [V, N, *out] -> [V, N, *param.shape]."""
     if isinstance(module, nn.Linear):
@@ -138,15 +160,17 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
     if isinstance(module, _BATCHNORM):
         if module.training:
             raise NotImplementedError("BatchNorm must be in eval mode (as in the reference tests)")
+        if M.is_cuda and M.dtype == torch.float32:
+            # sum_l M xhat = (sum_l M x - mean_c sum_l M) rstd_c: both row reductions (and the input rule's scaling) come out of
+            # one pass over M; the rest is [V, N, C]-sized
+            _, Mx, Ms = _bn_eval_rules(module, M, x)
+            if name == "bias":
+                return Ms
+            rstd = torch.rsqrt(module.running_var + module.eps)
+            return torch.addcmul(Mx * rstd, Ms, -(module.running_mean * rstd))
         if name == "bias":
             return _spatial_sum3(M)
         rstd = torch.rsqrt(module.running_var + module.eps)
-        if M.is_cuda:
-            # sum_l M xhat = (sum_l M x - mean_c sum_l M) rstd_c: two row reductions on HIP (the second shared with the bias
-            # rule), the rest is [V, N, C]-sized
-            L = x[0, 0].numel()
-            Mx = kernels.row_dot(M.reshape(-1, L), x.reshape(-1, L), rows_x=x.shape[0] * x.shape[1]).view(M.shape[:3])
-            return torch.addcmul(Mx * rstd, _spatial_sum3(M), -(module.running_mean * rstd))
         shape = [1, -1] + [1] * (x.dim() - 2)
         xhat = (x - module.running_mean.view(shape)) * rstd.view(shape)
         return _spatial_sum(M * xhat.unsqueeze(0), 3)
@@ -450,10 +474,9 @@ def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
         if g is not None:
             return g
     if isinstance(module, _BATCHNORM) and x.dim() >= 2:
-        scale = torch.rsqrt(module.running_var + module.eps)
-        if module.weight is not None:
-            scale = scale * module.weight.detach()
-        return kernels.channel_scale(M if M.dim() > 3 else M.unsqueeze(-1), scale).view(M.shape)
+        if _own_params(module):   # the parameter rules want the two row sums of the same pass
+            return _bn_eval_rules(module, M, x)[0]
+        return kernels.channel_scale(M if M.dim() > 3 else M.unsqueeze(-1), _bn_scale(module)).view(M.shape)
     return None
 
 

@@ -557,7 +557,7 @@ __device__ __forceinline__ gcptr dma_src(const float *P, int64_t ld, int64_t row
 }
 
 __device__ __forceinline__ void dma16(gcptr src, unsigned lds_byte_addr) {
-  __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
+  __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory");
 }
 
 template <int ALAY, int BLAY>
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx +
                                                        (unsigned)(wave * 1024));
   auto dma16b = [&](gcptr16 src, unsigned lds_byte_addr) __attribute__((always_inline)) {
-    __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory", "m0");
+    __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory");
   };
   // part q of the 12 requests of one K tile: q = 0..3 -> (block u = q / 2, operand q % 2), three pieces each
   auto issue_part = [&](int st, int q) __attribute__((always_inline)) {

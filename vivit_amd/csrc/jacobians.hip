@@ -432,6 +432,68 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float *__restrict__ 
   if (lane == 0) out[r] = acc;
 }
 
+// BatchNorm in eval mode, ALL its rules in one pass over the incoming factor (vivit_bn_eval_rules_f32): per row r = (v, n, c)
+//   mx[r] = sum_l M[r, l] X[r % rows_x, l]      (weight rule: sum_l M xhat = (mx - mean_c msum) rstd_c, finished by the caller)
+//   msum[r] = sum_l M[r, l]                      (bias rule; second term of the weight rule)
+//   out[r, l] = M[r, l] scale[c]                 (input rule)
+// One wave per row; same load pattern and summation order as row_dot_kernel, so mx / msum are bit-identical to its results.
+__global__ __launch_bounds__(256) void bn_eval_rules_kernel(const float *__restrict__ M, const float *__restrict__ X,
+                                                            const float *__restrict__ scale, float *__restrict__ out,
+                                                            float *__restrict__ mx, float *__restrict__ msum, int64_t rows,
+                                                            int64_t rows_x, int64_t C, int64_t L) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float *m = M + r * L;
+  const float *xr = X + (r % rows_x) * L;
+  float *o = out ? out + r * L : nullptr;
+  const float sc = scale ? scale[r % C] : 1.f;
+  float accx = 0.f, accm = 0.f;
+  if ((L & 3) == 0 && ((reinterpret_cast<uintptr_t>(M) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const float4 *m4 = reinterpret_cast<const float4 *>(m), *x4 = reinterpret_cast<const float4 *>(xr);
+    float4 *o4 = reinterpret_cast<float4 *>(o);
+    const int64_t L4 = L >> 2;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    int64_t l = lane;
+    for (; l + 64 < L4; l += 128) {
+      const float4 p = m4[l], q = m4[l + 64];
+      const float4 u = x4[l], v = x4[l + 64];
+      a0 += (p.x * u.x + p.y * u.y) + (p.z * u.z + p.w * u.w);
+      a1 += (q.x * v.x + q.y * v.y) + (q.z * v.z + q.w * v.w);
+      b0 += (p.x + p.y) + (p.z + p.w);
+      b1 += (q.x + q.y) + (q.z + q.w);
+      if (o) {
+        o4[l] = make_float4(p.x * sc, p.y * sc, p.z * sc, p.w * sc);
+        o4[l + 64] = make_float4(q.x * sc, q.y * sc, q.z * sc, q.w * sc);
+      }
+    }
+    if (l < L4) {
+      const float4 p = m4[l];
+      const float4 u = x4[l];
+      a0 += (p.x * u.x + p.y * u.y) + (p.z * u.z + p.w * u.w);
+      b0 += (p.x + p.y) + (p.z + p.w);
+      if (o) o4[l] = make_float4(p.x * sc, p.y * sc, p.z * sc, p.w * sc);
+    }
+    accx = a0 + a1;
+    accm = b0 + b1;
+  } else {
+    for (int64_t l = lane; l < L; l += 64) {
+      const float v = m[l];
+      accx += v * xr[l];
+      accm += v;
+      if (o) o[l] = v * sc;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    accx += __shfl_down(accx, off, 64);
+    accm += __shfl_down(accm, off, 64);
+  }
+  if (lane == 0) {
+    if (mx) mx[r] = accx;
+    if (msum) msum[r] = accm;
+  }
+}
+
 // ---- loss-Hessian square roots ------------------------------------------------------------------------------------------
 // Cross entropy: p = softmax(logits[n, :]).  exact: S[v, n, c] = sqrt(p_v) (delta_vc - p_c) * scale  (V = C slices);
 // sampled:  S[m, n, c] = (p_c - onehot[m, n, c]) * scale.   One workgroup per sample.
@@ -586,6 +648,16 @@ int vivit_row_dot_f32(const float *M, const float *X, float *out, int64_t rows, 
   if (rows == 0) return VIVIT_OK;
   if (!M || !out) return VIVIT_E_BADARG;
   row_dot_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, static_cast<hipStream_t>(stream)>>>(M, X, out, rows, X ? rows_x : 1, L);
+  return launch_status();
+}
+
+int vivit_bn_eval_rules_f32(const float *M, const float *X, const float *scale, float *out, float *mx, float *msum, int64_t rows,
+                            int64_t rows_x, int64_t C, int64_t L, void *stream) {
+  if (rows < 0 || L < 0 || rows_x <= 0 || C <= 0) return VIVIT_E_BADARG;
+  if (rows == 0) return VIVIT_OK;
+  if (!M || !X || (out && !scale) || (!out && !mx && !msum)) return VIVIT_E_BADARG;
+  if (rows % C != 0 && out) return VIVIT_E_BADARG;   // rows = (v, n, c) with c fastest
+  bn_eval_rules_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, static_cast<hipStream_t>(stream)>>>(M, X, scale, out, mx, msum, rows, rows_x, C, L);
   return launch_status();
 }
 

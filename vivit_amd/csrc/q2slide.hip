@@ -454,11 +454,15 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
     // over the compute waves were ~8 % of their time.  Two loader waves sit on the two SIMDs that carry two compute waves
     // when ten compute waves share four SIMDs.
     const int lw = wave - nw, nl = a.nload;
+    // (The asm below writes M0.  clang reserves M0 in inline asm -- it cannot be named as a clobber ("inline asm clobber list
+    // contains reserved registers: m0 ... may not be preserved") -- and hipcc writes M0 itself only for its own LDS-DMA
+    // builtins, s_movrel and s_sendmsg, none of which occurs in this kernel: every use of M0 here is set up by the same asm
+    // statement that consumes it.)
     auto request = [&](int64_t seq) __attribute__((always_inline)) {
       for (int f = lw; f < QS_NFRAG; f += nl) {
         const unsigned char *src = a.img + seq * (int64_t)QS_IMG + (int64_t)f * 1024;
         const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG + (unsigned)f * 1024u);
-        __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory", "m0");
+        __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");
       }
     };
     if (nseq > 0) request(0);
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
       // were spilled by the 168-register instantiation)
       const unsigned char *src = a.img + seq * (int64_t)QS_IMG + (int64_t)f * 1024;
       const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG + (unsigned)f * 1024u);
-      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory", "m0");
+      __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");
     }
   };
   const int npiece = (QS_NFRAG + nw - 1) / nw;   // pieces per wave (the last one only for some waves)

@@ -403,6 +403,25 @@ def conv2d_jac_t(M, weight, in_hw, stride, padding, dilation):
 
 
 @_launcher
+def bn_eval_rules(M, x, scale):
+    """All rules of a BatchNorm in eval mode in one pass over the factor (``vivit_bn_eval_rules_f32``): ``M [V, N, C, *spatial]``,
+    ``x [N, C, *spatial]`` (the module's input), ``scale [C]`` -> ``(M * scale_c  [like M], sum_l M x  [V, N, C], sum_l M  [V, N, C])``."""
+    _require_device(M, x, scale)
+    M, x, scale = M.contiguous(), x.contiguous(), scale.contiguous()
+    if M.dim() < 3 or tuple(M.shape[1:]) != tuple(x.shape) or scale.numel() != M.shape[2]:
+        raise ValueError(f"M must be [V, *x.shape] with {scale.numel()} channels, got {tuple(M.shape)} for x {tuple(x.shape)}")
+    Vd, N, C = M.shape[:3]
+    L = M[0, 0, 0].numel()
+    out = torch.empty_like(M)
+    mx = torch.empty((Vd, N, C), dtype=torch.float32, device=M.device)
+    ms = torch.empty((Vd, N, C), dtype=torch.float32, device=M.device)
+    st = _lib.load().vivit_bn_eval_rules_f32(M.data_ptr(), x.data_ptr(), scale.data_ptr(), out.data_ptr(), mx.data_ptr(), ms.data_ptr(),
+                                            Vd * N * C, N * C, C, L, _stream(M))
+    _lib.check(st, "vivit_bn_eval_rules_f32")
+    return out, mx, ms
+
+
+@_launcher
 def row_dot(M, X=None, rows_x: int = 1):
     """``out[r] = sum_l M[r, l] * (X[r % rows_x, l] if X is given else 1)`` for ``M [rows, L]`` (fixed summation order)."""
     _require_device(M, X)

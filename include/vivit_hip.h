@@ -220,9 +220,10 @@ int vivit_row_dot_f32(const float *M, const float *X, float *out, int64_t rows, 
  * positions; X [rows_x = N C, L] the module's input): mx[r] = sum_l M[r, l] X[r % rows_x, l] and msum[r] = sum_l M[r, l]
  * (the weight rule sum_l M xhat = (mx - mean_c msum) rstd_c and the bias rule; batchnormnd.py:3 with
  * BatchNormNdDerivatives.param_mjp), out[r, l] = M[r, l] scale[r % C] (the input rule, scale = weight_c rstd_c).  Any of
- * out / mx / msum may be NULL.  Same summation order as vivit_row_dot_f32 (bit-identical sums). */
+ * out / mx / msum may be NULL.  Same summation order as vivit_row_dot_f32 (bit-identical sums).  wmean / wrstd ([C], both or
+ * neither): mx then holds the finished weight rule (mx - wmean_c msum) wrstd_c with wmean = running_mean, wrstd = 1/sqrt(var + eps). */
 int vivit_bn_eval_rules_f32(const float *M, const float *X, const float *scale, float *out, float *mx, float *msum, int64_t rows,
-                            int64_t rows_x, int64_t C, int64_t L, void *stream);
+                            int64_t rows_x, int64_t C, int64_t L, const float *wmean, const float *wrstd, void *stream);
 /* Cross-entropy loss-Hessian square root from the logits [N, C]: p = softmax.  onehot == NULL (exact, V must equal C):
  * S[v, n, c] = sqrt(p_nv) (delta_vc - p_nc) scale;  onehot [V, N, C] (sampled): S[v, n, c] = (p_nc - onehot[v, n, c]) scale. */
 int vivit_ce_sqrt_hessian_f32(const float *logits, const float *onehot, float *S, int64_t N, int64_t C, int64_t V, float scale,

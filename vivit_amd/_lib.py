@@ -45,7 +45,7 @@ SIGNATURES = {
     "vivit_avgpool2d_jac_t_f32": (_int, [_ptr, _ptr] + [_i64] * 11 + [_ptr]),
     "vivit_conv2d_jac_t_f32": (_int, [_ptr, _ptr, _ptr] + [_i64] * 15 + [_ptr]),
     "vivit_row_dot_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr]),
-    "vivit_bn_eval_rules_f32": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
+    "vivit_bn_eval_rules_f32": (_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr]),
     "vivit_ce_sqrt_hessian_f32": (_int, [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr]),
     "vivit_symeig_f32_workspace_bytes": (_sz, [_i64, _int]),
     "vivit_symeig_f32": (_int, [_ptr, _i64, _i64, _ptr, _ptr, _i64, _ptr, _sz, _ptr, _ptr]),

@@ -109,20 +109,34 @@ def _spatial_sum3(M: Tensor) -> Tensor:
     return memo
 
 
+def _bn_constants(module):
+    """``(rstd, scale)`` of a BatchNorm in eval mode, remembered on the module while its statistics are unchanged (two tiny
+    launches per module and backward pass otherwise)."""
+    key = (module.running_var._version, module.running_var.data_ptr(), None if module.weight is None else module.weight._version,
+           module.eps)
+    memo = getattr(module, "_vivit_bn_constants", None)
+    if memo is None or memo[0] != key:
+        rstd = torch.rsqrt(module.running_var + module.eps)
+        scale = rstd * module.weight.detach() if module.weight is not None else rstd
+        memo = (key, rstd, scale)
+        module._vivit_bn_constants = memo
+    return memo[1], memo[2]
+
+
 def _bn_scale(module) -> Tensor:
-    scale = torch.rsqrt(module.running_var + module.eps)
-    return scale * module.weight.detach() if module.weight is not None else scale
+    return _bn_constants(module)[1]
 
 
 def _bn_eval_rules(module, M: Tensor, x: Tensor):
-    """``(M scale_c, sum_l M x, sum_l M)`` of a BatchNorm in eval mode from ONE pass over the factor ``M [V, N, C, *spatial]``
+    """``(M scale_c, (sum_l M x - mean_c sum_l M) rstd_c, sum_l M)`` of a BatchNorm in eval mode from ONE pass over the factor ``M [V, N, C, *spatial]``
     (``vivit_bn_eval_rules_f32``), remembered on the tensor: the weight rule, the bias rule and the input rule of the module
     are three calls on the same ``M`` (round 4: three row reductions and one scaling pass, four reads of ``M``)."""
     memo = getattr(M, "_vivit_bn_rules", None)
     if memo is None or memo[0] is not module:
         Mc = M if M.dim() > 3 else M.unsqueeze(-1)
         xc = x if x.dim() > 2 else x.unsqueeze(-1)
-        out, mx, ms = kernels.bn_eval_rules(Mc, xc, _bn_scale(module))
+        rstd, scale = _bn_constants(module)
+        out, mx, ms = kernels.bn_eval_rules(Mc, xc, scale, module.running_mean, rstd)   # mx: the finished weight rule
         memo = (module, out.view(M.shape), mx, ms)
         try:
             M._vivit_bn_rules = memo
@@ -163,11 +177,8 @@ def _param_factor(module, name: str, M: Tensor, x: Tensor) -> Tensor:
         if M.is_cuda and M.dtype == torch.float32:
             # sum_l M xhat = (sum_l M x - mean_c sum_l M) rstd_c: both row reductions (and the input rule's scaling) come out of
             # one pass over M; the rest is [V, N, C]-sized
-            _, Mx, Ms = _bn_eval_rules(module, M, x)
-            if name == "bias":
-                return Ms
-            rstd = torch.rsqrt(module.running_var + module.eps)
-            return torch.addcmul(Mx * rstd, Ms, -(module.running_mean * rstd))
+            _, Mw, Ms = _bn_eval_rules(module, M, x)
+            return Ms if name == "bias" else Mw
         if name == "bias":
             return _spatial_sum3(M)
         rstd = torch.rsqrt(module.running_var + module.eps)

@@ -437,10 +437,12 @@ __global__ __launch_bounds__(256) void row_dot_kernel(const float *__restrict__ 
 //   msum[r] = sum_l M[r, l]                      (bias rule; second term of the weight rule)
 //   out[r, l] = M[r, l] scale[c]                 (input rule)
 // One wave per row; same load pattern and summation order as row_dot_kernel, so mx / msum are bit-identical to its results.
+// wmean / wrstd (optional, [C]): mx is finished in place into the weight rule's value (mx - wmean_c msum) wrstd_c.
 __global__ __launch_bounds__(256) void bn_eval_rules_kernel(const float *__restrict__ M, const float *__restrict__ X,
                                                             const float *__restrict__ scale, float *__restrict__ out,
                                                             float *__restrict__ mx, float *__restrict__ msum, int64_t rows,
-                                                            int64_t rows_x, int64_t C, int64_t L) {
+                                                            int64_t rows_x, int64_t C, int64_t L,
+                                                            const float *__restrict__ wmean, const float *__restrict__ wrstd) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256) void bn_eval_rules_kernel(const float *__restr
     accm += __shfl_down(accm, off, 64);
   }
   if (lane == 0) {
-    if (mx) mx[r] = accx;
+    if (mx) mx[r] = wrstd ? (accx - wmean[r % C] * accm) * wrstd[r % C] : accx;
     if (msum) msum[r] = accm;
   }
 }
@@ -652,12 +654,13 @@ int vivit_row_dot_f32(const float *M, const float *X, float *out, int64_t rows, 
 }
 
 int vivit_bn_eval_rules_f32(const float *M, const float *X, const float *scale, float *out, float *mx, float *msum, int64_t rows,
-                            int64_t rows_x, int64_t C, int64_t L, void *stream) {
+                            int64_t rows_x, int64_t C, int64_t L, const float *wmean, const float *wrstd, void *stream) {
   if (rows < 0 || L < 0 || rows_x <= 0 || C <= 0) return VIVIT_E_BADARG;
   if (rows == 0) return VIVIT_OK;
-  if (!M || !X || (out && !scale) || (!out && !mx && !msum)) return VIVIT_E_BADARG;
-  if (rows % C != 0 && out) return VIVIT_E_BADARG;   // rows = (v, n, c) with c fastest
-  bn_eval_rules_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, static_cast<hipStream_t>(stream)>>>(M, X, scale, out, mx, msum, rows, rows_x, C, L);
+  if (!M || !X || (out && !scale) || (!out && !mx && !msum) || ((wmean == nullptr) != (wrstd == nullptr))) return VIVIT_E_BADARG;
+  if (rows % C != 0 && (out || wrstd)) return VIVIT_E_BADARG;   // rows = (v, n, c) with c fastest
+  bn_eval_rules_kernel<<<(unsigned)cdiv(rows, 4), 256, 0, static_cast<hipStream_t>(stream)>>>(M, X, scale, out, mx, msum, rows, rows_x, C, L,
+                                                                                             wmean, wrstd);
   return launch_status();
 }
 

@@ -403,11 +403,16 @@ def conv2d_jac_t(M, weight, in_hw, stride, padding, dilation):
 
 
 @_launcher
-def bn_eval_rules(M, x, scale):
+def bn_eval_rules(M, x, scale, mean=None, rstd=None):
     """All rules of a BatchNorm in eval mode in one pass over the factor (``vivit_bn_eval_rules_f32``): ``M [V, N, C, *spatial]``,
-    ``x [N, C, *spatial]`` (the module's input), ``scale [C]`` -> ``(M * scale_c  [like M], sum_l M x  [V, N, C], sum_l M  [V, N, C])``."""
+    ``x [N, C, *spatial]`` (the module's input), ``scale [C]`` -> ``(M * scale_c  [like M], sum_l M x  [V, N, C], sum_l M  [V, N, C])``;
+    with ``mean`` / ``rstd`` ``[C]`` the second result is the finished weight rule ``(sum_l M x - mean_c sum_l M) rstd_c``."""
     _require_device(M, x, scale)
     M, x, scale = M.contiguous(), x.contiguous(), scale.contiguous()
+    if (mean is None) != (rstd is None):
+        raise ValueError("mean and rstd come together")
+    if mean is not None:
+        mean, rstd = mean.contiguous(), rstd.contiguous()
     if M.dim() < 3 or tuple(M.shape[1:]) != tuple(x.shape) or scale.numel() != M.shape[2]:
         raise ValueError(f"M must be [V, *x.shape] with {scale.numel()} channels, got {tuple(M.shape)} for x {tuple(x.shape)}")
     Vd, N, C = M.shape[:3]
@@ -416,7 +421,8 @@ def bn_eval_rules(M, x, scale):
     mx = torch.empty((Vd, N, C), dtype=torch.float32, device=M.device)
     ms = torch.empty((Vd, N, C), dtype=torch.float32, device=M.device)
     st = _lib.load().vivit_bn_eval_rules_f32(M.data_ptr(), x.data_ptr(), scale.data_ptr(), out.data_ptr(), mx.data_ptr(), ms.data_ptr(),
-                                            Vd * N * C, N * C, C, L, _stream(M))
+                                            Vd * N * C, N * C, C, L, mean.data_ptr() if mean is not None else None,
+                                            rstd.data_ptr() if rstd is not None else None, _stream(M))
     _lib.check(st, "vivit_bn_eval_rules_f32")
     return out, mx, ms
 

@@ -52,9 +52,18 @@ SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.2943e9 + 3.2241
 # profiles/r03_pmc/v3_bx_clock_real.txt) and GRBM_GUI_ACTIVE / 8 / duration of the PMC pass on N(0,1) data
 # (round 4, profiles/r04_pmc/pmc_syrk_mfma_*: GRBM_GUI_ACTIVE 4.1806e10 / 8 over 2.986 s of gemm256_bx_kernel on N(0,1) data,
 # SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs; the in-kernel stamps are round 3's)
+# round 5 (profiles/r05_pmc/pmc_syrk_mfma_*: the same 98 launches on N(0,1) data on another box): GRBM_GUI_ACTIVE 4.2170e10 / 8 over
+# 2.951 s = 1.786 GHz, SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs = 73.6 % of the cycles
 SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors": 1.862, "in_kernel_stamps_randn": 1.725,
-                                                  "pmc_grbm_gui_active_randn": 1.750, "nominal": 2.4,
-                                                  "mfma_pipe_busy_pmc": 0.742}}
+                                                  "pmc_grbm_gui_active_randn": 1.786, "nominal": 2.4,
+                                                  "mfma_pipe_busy_pmc": 0.736}}
+# What the SAME per-K-tile instruction mix reaches with every byte of data movement removed (operand pieces in LDS once; no
+# DMA, barrier, flush): scripts/probe/bx_bare_loop.hip, profiles/r05_bx_bare_loop.log -- fraction of the bf16 / 6 ceiling and the
+# clock the chip holds, by operand data.  The power limit, not the kernel, takes the rest of the nominal peak.
+BX_BARE_LOOP_CEILING = {"randn": {"frac": 0.708, "tflops_fp32_equiv": 296.8, "clock_ghz": 1.778},
+                        "half_zeros_like_the_bench_factors": {"frac": 0.787, "tflops_fp32_equiv": 330.0, "clock_ghz": 1.969},
+                        "zeros": {"frac": 0.976, "tflops_fp32_equiv": 409.3, "clock_ghz": 2.383},
+                        "source": "scripts/probe/bx_bare_loop.hip on one MI355X, 3 s per data kind, all 256 CUs (profiles/r05_bx_bare_loop.log)"}
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
 MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 MFMA peak (256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz; same guide)
 
@@ -867,10 +876,16 @@ def main():
                     "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
                     "traffic": SYRK_BX_TRAFFIC_BYTES_PMC.get((args.workload, world)) if split == 6 else None,
                     "traffic_note": "bytes of the first-layer weight's SYRK (98.6 % of the Gram flops: 98 split + 98 product launches of "
-                                    "4096 columns), separate rocprofv3 --pmc passes (profiles/r04_pmc), FETCH_SIZE includes Infinity-Cache hits",
+                                    "4096 columns) on N(0,1) data, separate rocprofv3 --pmc passes (profiles/r04_pmc; profiles/r05_pmc reproduces "
+                                    "them: FETCH_SIZE 2.2955e9 KiB, WRITE_SIZE 7.1264e8 KiB), FETCH_SIZE includes Infinity-Cache hits",
                     "clock_ghz": SYRK_BX_CLOCK_GHZ.get((args.workload, world)) if split == 6 else None,
-                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.74) x (clock / 2.4 GHz); "
-                                  "measured with a diagnostic build (profiles/r03_pmc) and a PMC pass (profiles/r04_pmc), not in this run",
+                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.74) x (clock / 2.4 GHz); NOT "
+                                  "measured in this run: in-kernel stamps of a diagnostic build on the bench's own factors and on N(0,1) data "
+                                  "(profiles/r03_pmc/v3_bx_clock_*.txt, round-3 box), GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of a PMC pass over the 98 "
+                                  "launches of the first-layer SYRK on N(0,1) data (profiles/r05_pmc/pmc_syrk_mfma_*, round-5 box)",
+                    "bare_loop_ceiling": BX_BARE_LOOP_CEILING if split == 6 else None,
+                    "frac_of_bare_loop_on_like_data": (achieved / BX_BARE_LOOP_CEILING["half_zeros_like_the_bench_factors"]["tflops_fp32_equiv"])
+                    if split == 6 else None,
                 }
             roofline.update({
                 "launches_sampled": int(syrk_cnt), "avg_launch_ms": syrk_ms / max(syrk_cnt, 1),

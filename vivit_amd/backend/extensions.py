@@ -569,6 +569,7 @@ class BatchGrad(_Extension):
     """Per-sample gradients of the mini-batch loss (BackPACK ``BatchGrad``)."""
 
     savefield = "grad_batch"
+    uses_grad = True   # reads autograd's gradient: the extensions' stream waits for the backward pass at every hook (engine.py)
 
     def __init__(self, subsampling: Optional[List[int]] = None, factorised: bool = False):
         super().__init__(subsampling)

@@ -464,3 +464,39 @@ def test_damped_newton_optimizer_loop(factorised, device):
     assert losses[-1] < losses[0]
     with pytest.raises(ValueError):
         opt.step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("problem", ["resblock_ce", "cnn_ce"])
+def test_side_stream_is_bit_identical_and_ordered(problem, monkeypatch):
+    """backend/engine.py runs the extensions on a stream of their own (same kernels, same order): factors, per-sample
+    gradients and the Newton step must be BIT-identical to the single-stream run (VIVIT_SIDE_STREAM=0), also when the backward
+    pass' own stream is kept busy right up to the backward call and reads the results right behind it -- an ordering bug
+    (a factor read before the side stream wrote it, a gradient buffer recycled under its reads) shows as a difference."""
+    from helpers import constant_damping, top_k_criterion
+
+    set_kernel_backend(None)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model, X, y, lossf, _ = make_problem(problem)
+    model, X, y = model.to(dev), X.to(dev), y.to(dev)
+    busy = torch.randn(4096, 4096, device=dev)
+
+    def run():
+        comp = vivit_amd.DirectionalDampedNewtonComputation(warn_small_eigvals=0.0)
+        group = {"params": list(model.parameters()), "criterion": top_k_criterion(3, must_exceed=1e-8), "damping": constant_damping(1.0)}
+        for _ in range(3):
+            busy @ busy          # the caller's stream is busy when backward starts
+        run_backward(model, X, y, lossf, comp.get_extensions(), comp.get_extension_hook([group]))
+        step = [s.clone() for s in comp.get_result(group)]     # read on the caller's stream, right behind the block
+        run_backward(model, X, y, lossf, [SqrtGGNExact(), BatchGrad()])
+        facs = [p.sqrt_ggn_exact.clone() for p in model.parameters()] + [p.grad_batch.clone() for p in model.parameters()]
+        return step + facs
+
+    monkeypatch.setenv("VIVIT_SIDE_STREAM", "0")
+    ref = run()
+    monkeypatch.setenv("VIVIT_SIDE_STREAM", "1")
+    for _ in range(5):
+        got = run()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)

@@ -87,6 +87,12 @@ BADARG_CASES = [
     ("vivit_avgpool2d_jac_t_f32", (P, None, 12, 8, 8, 4, 4, 2, 2, 2, 2, 0, 0, None)),
     ("vivit_conv2d_jac_t_f32", (P, None, R, 6, 2, 8, 8, 4, 3, 3, 6, 6, 1, 1, 0, 0, 1, 1, None)),
     ("vivit_row_dot_f32", (None, None, R, 8, 8, 16, None)),
+    ("vivit_bn_eval_rules_f32", (None, Q, R, R, R, R, 12, 6, 3, 16, None, None, None)),            # no factor
+    ("vivit_bn_eval_rules_f32", (P, Q, None, R, R, R, 12, 6, 3, 16, None, None, None)),            # scaled output without a scale
+    ("vivit_bn_eval_rules_f32", (P, Q, R, None, None, None, 12, 6, 3, 16, None, None, None)),      # nothing to compute
+    ("vivit_bn_eval_rules_f32", (P, Q, R, R, R, R, 12, 6, 3, 16, R, None, None)),                  # mean without rstd
+    ("vivit_bn_eval_rules_f32", (P, Q, R, R, R, R, 13, 6, 3, 16, None, None, None)),               # rows not a multiple of C
+    ("vivit_take_persist_timeout", (None, None)),                                                  # no info word
     ("vivit_ce_sqrt_hessian_f32", (None, None, R, 4, 3, 3, 1.0, None)),
     ("vivit_ce_sqrt_hessian_f32", (P, None, R, 4, 3, 2, 1.0, None)),                       # exact factor needs V == C
     # K3 / K4 eigensolver

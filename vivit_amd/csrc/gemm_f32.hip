@@ -1142,6 +1142,17 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       srcB[u] += stepB;
     }
   };
+  // request r = 0..11 of a K tile on its own (part r / 3, piece r % 3): for placements finer than three at a time (BX_DMA_SPREAD)
+  auto issue_one = [&](int st, int rq) __attribute__((always_inline)) {
+    const int q = rq / 3, pc = rq - 3 * q, u = q >> 1;
+    if ((q & 1) == 0) {
+      dma16b(srcA[u] + pc * p.strideA, lds0 + (unsigned)(st * BX_STAGE + pc * BX_PIECE + 4 * u * 1024));
+      if (pc == 2) srcA[u] += stepA;
+    } else {
+      dma16b(srcB[u] + pc * p.strideB, lds0 + (unsigned)(st * BX_STAGE + BX_OPER + pc * BX_PIECE + 4 * u * 1024));
+      if (pc == 2) srcB[u] += stepB;
+    }
+  };
   auto issue = [&](int st) __attribute__((always_inline)) {  // the next not yet requested K tile into stage st
 #pragma unroll
     for (int q = 0; q < 4; ++q) issue_part(st, q);
@@ -1266,6 +1277,35 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       // the 12 requests of tile t + 2 go out three at a time between the column tiles of row 2 (a burst right behind the
       // barrier stalls the wave at issue while the matrix pipe runs dry)
       const bool req = t + 2 < t1;
+#if defined(BX_DMA_SPREAD) && BX_DMA_SPREAD == 1   // experiment: two requests per column tile of row 2, one per column tile of row 3
+      mfma_row(J2{}, fa2, fb, [&](int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (req) { issue_one(st2, 2 * j); issue_one(st2, 2 * j + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      {
+        const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
+        mfma_row(J3{}, fa3, fb, [&](int j) __attribute__((always_inline)) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (req) issue_one(st2, 8 + j);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
+        });
+      }
+#elif defined(BX_DMA_SPREAD) && BX_DMA_SPREAD == 2   // experiment: all twelve in row 3 (behind the fragment reads of each column tile)
+      mfma_row(J2{}, fa2, fb, nothing);
+      {
+        const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
+        mfma_row(J3{}, fa3, fb, [&](int j) __attribute__((always_inline)) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+          if (req) issue_part(st2, j);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+#else
       mfma_row(J2{}, fa2, fb, [&](int j) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         if (req) issue_part(st2, j);
@@ -1279,6 +1319,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
           for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
         });
       }
+#endif
       fan = load_a(stn, 0);
       st = st1;
       ++t;

@@ -1142,17 +1142,6 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       srcB[u] += stepB;
     }
   };
-  // request r = 0..11 of a K tile on its own (part r / 3, piece r % 3): for placements finer than three at a time (BX_DMA_SPREAD)
-  auto issue_one = [&](int st, int rq) __attribute__((always_inline)) {
-    const int q = rq / 3, pc = rq - 3 * q, u = q >> 1;
-    if ((q & 1) == 0) {
-      dma16b(srcA[u] + pc * p.strideA, lds0 + (unsigned)(st * BX_STAGE + pc * BX_PIECE + 4 * u * 1024));
-      if (pc == 2) srcA[u] += stepA;
-    } else {
-      dma16b(srcB[u] + pc * p.strideB, lds0 + (unsigned)(st * BX_STAGE + BX_OPER + pc * BX_PIECE + 4 * u * 1024));
-      if (pc == 2) srcB[u] += stepB;
-    }
-  };
   auto issue = [&](int st) __attribute__((always_inline)) {  // the next not yet requested K tile into stage st
 #pragma unroll
     for (int q = 0; q < 4; ++q) issue_part(st, q);
@@ -1274,27 +1263,18 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       __asm__ volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       FragA fa3 = load_a(st, 3);
-      // the 12 requests of tile t + 2 go out three at a time between the column tiles of row 2 (a burst right behind the
-      // barrier stalls the wave at issue while the matrix pipe runs dry)
+      // The 12 requests of tile t + 2 go out three at a time in ROW 3, behind the fragment reads of each column tile -- away
+      // from the barrier: a burst right behind it stalls the wave at issue while the matrix pipe runs dry (round 2), and three
+      // per column tile of row 2 (rounds 2-4), still within ~800 cycles of the release, cost 3 % of the kernel.  Same-box A/B
+      // at n = 40 960, P = 131 072 (scripts/probe/syrk_ab.sh, profiles/r05_syrk_ab*.log), N(0,1) / half-zero data: row 2
+      // (rounds 2-4) 225.1 / 246.3 TFLOP/s; two per column tile of row 2 + one per column tile of row 3 231.0 / 254.0; row 3
+      // (this) 233.4 / 256.4 (238.3 / 263.6 against 231.8 / 257.2 on a faster box); row 3, one behind every second MFMA
+      // 233.2 / 251.0; rows 2 + 3, one behind every fourth MFMA 232.3 / 250.6; row 3 with the wait + barrier moved between rows 2
+      // and 3 234.1 / 259.4 against 238.3 / 263.6 on that box.  The requests then have rows 0 and 1 of the next tile (48 MFMAs,
+      // ~0.9 us) + what is left of row 3 to land before the mid-tile wait.
       const bool req = t + 2 < t1;
-#if defined(BX_DMA_SPREAD) && BX_DMA_SPREAD == 1   // experiment: two requests per column tile of row 2, one per column tile of row 3
-      mfma_row(J2{}, fa2, fb, [&](int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (req) { issue_one(st2, 2 * j); issue_one(st2, 2 * j + 1); }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      {
-        const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
-        mfma_row(J3{}, fa3, fb, [&](int j) __attribute__((always_inline)) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (req) issue_one(st2, 8 + j);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
-        });
-      }
-#elif defined(BX_DMA_SPREAD) && BX_DMA_SPREAD == 2   // experiment: all twelve in row 3 (behind the fragment reads of each column tile)
       mfma_row(J2{}, fa2, fb, nothing);
+      // first fragments of tile t + 1: the B pieces of column tile j behind the MFMAs of column tile j - 1 of row 3
       {
         const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
         mfma_row(J3{}, fa3, fb, [&](int j) __attribute__((always_inline)) {
@@ -1305,21 +1285,6 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
           __builtin_amdgcn_sched_barrier(0);
         });
       }
-#else
-      mfma_row(J2{}, fa2, fb, [&](int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (req) issue_part(st2, j);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      // first fragments of tile t + 1: the B pieces of column tile j behind the MFMAs of column tile j of row 3
-      {
-        const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
-        mfma_row(J3{}, fa3, fb, [&](int j) __attribute__((always_inline)) {
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
-        });
-      }
-#endif
       fan = load_a(stn, 0);
       st = st1;
       ++t;

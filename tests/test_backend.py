@@ -489,8 +489,12 @@ def test_side_stream_is_bit_identical_and_ordered(problem, monkeypatch):
             busy @ busy          # the caller's stream is busy when backward starts
         run_backward(model, X, y, lossf, comp.get_extensions(), comp.get_extension_hook([group]))
         step = [s.clone() for s in comp.get_result(group)]     # read on the caller's stream, right behind the block
-        run_backward(model, X, y, lossf, [SqrtGGNExact(), BatchGrad()])
-        facs = [p.sqrt_ggn_exact.clone() for p in model.parameters()] + [p.grad_batch.clone() for p in model.parameters()]
+        # ... and INSIDE the block, right behind backward(): the end-of-pass callback must have joined the streams
+        m, lf = extend(model), extend(lossf)
+        m.zero_grad()
+        with backpack(SqrtGGNExact(), BatchGrad()):
+            lf(m(X), y).backward()
+            facs = [p.sqrt_ggn_exact.clone() for p in model.parameters()] + [p.grad_batch.clone() for p in model.parameters()]
         return step + facs
 
     monkeypatch.setenv("VIVIT_SIDE_STREAM", "0")

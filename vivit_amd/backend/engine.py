@@ -27,8 +27,10 @@ _ACTIVE = None  # the innermost active ``backpack`` context
 #   * extensions that consume autograd's gradient (``uses_grad``: BatchGrad) make it wait at every hook, and the gradient
 #     tensor is recorded on the side stream (the caching allocator must not recycle it under the side stream's reads); the
 #     forward activations the rules read are kept alive by the modules (``input0`` / ``output``) until the next forward pass;
-#   * leaving the ``with backpack(...)`` block makes the caller's stream wait for the side stream: whatever the caller reads
-#     afterwards (``param.sqrt_ggn_exact``, ``get_result``) is ordered behind the work that produced it.
+#   * when the backward pass ends (an autograd engine callback queued at the first hook of the pass) the stream that the
+#     pass ran on waits for the side stream, and so does the caller's stream when the ``with backpack(...)`` block is left:
+#     whatever the caller reads afterwards -- inside the block or behind it (``param.sqrt_ggn_exact``, ``get_result``) -- is
+#     ordered behind the work that produced it.
 # Kernels are the same and run in the same order relative to each other: results are bit-identical.
 _SIDE_STREAMS = {}
 
@@ -55,7 +57,8 @@ class backpack:
         self.state = {}  # (id(extension), id(tensor)) -> quantity back-propagated to that tensor
         self._keepalive = []
         self._outer = None
-        self._side_used = {}   # device index -> side stream used inside this block
+        self._side_used = {}   # device index -> (side stream, stream of the backward pass) used inside this block
+        self._join_queued = False
         self._uses_grad = any(getattr(e, "uses_grad", False) for e in extensions)
 
     def __enter__(self):
@@ -69,10 +72,16 @@ class backpack:
         _ACTIVE = self._outer
         self.state.clear()
         self._keepalive.clear()
-        for index, side in self._side_used.items():   # the caller's stream continues behind the extensions' work
+        for index, (side, _) in self._side_used.items():   # the caller's stream continues behind the extensions' work
             torch.cuda.current_stream(index).wait_stream(side)
         self._side_used.clear()
         return False
+
+    def _join(self):
+        """End of a backward pass (autograd engine callback): the pass' own stream waits for the extensions' stream."""
+        self._join_queued = False
+        for side, main in self._side_used.values():
+            main.wait_stream(side)
 
     # back-propagated quantities are keyed by the identity of the activation tensor
     def put(self, ext, tensor, value):
@@ -101,13 +110,17 @@ def _make_output_hook(module: Module):
         if side is None:
             run(ctx, grad)
             return None
+        main = torch.cuda.current_stream(grad.device)
         if ctx._uses_grad or not ctx.state:   # first hook of a pass, or an extension that reads autograd's gradient
-            side.wait_stream(torch.cuda.current_stream(grad.device))
+            side.wait_stream(main)
+        if not ctx._join_queued:              # once per pass: join the streams when the pass is over
+            ctx._join_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(ctx._join)
         if ctx._uses_grad:
             # autograd frees the gradient right after this hook returns; its memory belongs to the backward pass' stream and
             # would be handed out again while the side stream still reads it
             grad.record_stream(side)
-        ctx._side_used[grad.device.index] = side
+        ctx._side_used[grad.device.index] = (side, main)
         with torch.cuda.stream(side):
             run(ctx, grad)
         return None

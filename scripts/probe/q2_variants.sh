@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../.."
 for v in "$@"; do
-  case $v in [0-9]*) def="-DQS_VAR=$v";; *) def="-D$v";; esac
+  case $v in [0-9]*) def="-DQS_VAR=$v";; *) def="-D${v//,/ -D}";; esac   # NAME=1,OTHER=2 -> several defines
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function $def -c vivit_amd/csrc/q2slide.hip -o /tmp/q2slide_v$v.o
   objs=$(ls vivit_amd/csrc/obj/*.o | grep -v q2slide.o)
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o scripts/probe/libq2v$v.so $objs /tmp/q2slide_v$v.o

@@ -341,6 +341,9 @@ __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ 
       }
       float x = 0.f;
       if (k == 0) x = lane < L ? band_ld<true>(AB + (int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)) : 0.f;  // column s of the band
+#if defined(SB2ST_PVAR) && SB2ST_PVAR == 3   // timing only (wrong results): counter A goes out BEFORE the arithmetic -- the step without it
+      if (tid == 0) __hip_atomic_store(prog(s), ((k + 1) << 16) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 #if defined(SB2ST_PVAR) && SB2ST_PVAR == 1   // timing only (wrong results): no arithmetic, the hand-over chain alone
       float beta = x;
       lds.sE[tid] = rows.ev[0]; lds.sD[tid] = rows.dv[0];

@@ -964,6 +964,9 @@ __device__ unsigned int g_bx_stamp_cap = 0;
 template <int NPROD>
 __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
+#if defined(BX_STAMP) && BX_STAMP == 2   // timeline build (scripts/probe/bx_timeline.py): 8 words per workgroup
+  const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 #if !(defined(BX_EXP) && BX_EXP == 2)   // (experiment 2: timing without the gate check)
   if (p.gate && (*p.gate & p.gate_mask) != 0) return;  // the fp32 MFMA kernel takes this chunk
 #endif
@@ -1240,6 +1243,10 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __asm__ volatile("s_barrier" ::: "memory");
     if (1 < t1) issue(1);
+#if defined(BX_STAMP) && BX_STAMP == 2
+    const unsigned long long stamp_loop0 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && g_bx_stamp && p.syrk == 2 && blockIdx.x < g_bx_stamp_cap) g_bx_stamp[8 * blockIdx.x + 3] = stamp_loop0;
+#endif
     // two named fragment sets in ping-pong (tile t uses one and fills the other for tile t + 1)
     FragB fbX = load_b(0), fbY;
     FragA faX = load_a(0, 0), faY;
@@ -1308,10 +1315,24 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     if (t < t1) tile(fbX, faX, fbY, faY);
   }
 #if defined(BX_STAMP)
+#if BX_STAMP == 2   // (the launches that add a chunk into the lower tiles without mirroring: all but the last of a Gram SYRK)
+  if (tid == 0 && g_bx_stamp && p.syrk == 2 && blockIdx.x < g_bx_stamp_cap) {
+    int hwid, xcc;
+    __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long *w = g_bx_stamp + 8 * blockIdx.x;
+    w[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
+    w[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    w[2] = stamp_entry;
+    w[4] = __builtin_amdgcn_s_memrealtime();   // end of the K loop
+    w[6] = ((unsigned long long)(unsigned)xcc << 32) | (unsigned)hwid;
+  }
+#else
   if (tid == 0 && g_bx_stamp && blockIdx.y == 0 && blockIdx.x < g_bx_stamp_cap) {
     g_bx_stamp[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c0;
     g_bx_stamp[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
   }
+#endif
 #endif
   // The LAST flush of a full, 16-byte-aligned tile that must read C (beta != 0 on a single-chain product, or a SYRK tile
   // whose final values also go to the transposed tile).  The operand stages are dead now, so the old values of C are
@@ -1436,6 +1457,12 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
         }
       }
   }
+#if defined(BX_STAMP) && BX_STAMP == 2
+  if (tid == 0 && g_bx_stamp && p.syrk == 2 && blockIdx.x < g_bx_stamp_cap) g_bx_stamp[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();   // flush issued
+  __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's flush is in memory
+  __syncthreads();
+  if (tid == 0 && g_bx_stamp && p.syrk == 2 && blockIdx.x < g_bx_stamp_cap) g_bx_stamp[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -49,7 +49,7 @@ enum { PERSIST_TMO_SYTRD = 1, PERSIST_TMO_PANEL_QR = 2, PERSIST_TMO_SB2ST = 4 };
 __device__ __forceinline__ bool persist_arrive(int *count, int *state, int nwg, unsigned long long limit) {
   const int mine = __hip_atomic_fetch_add(count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   int expect = PERSIST_OPEN;
-  if (mine == nwg)
+  if (mine == nwg && limit != 0)   // (limit 0 = the injected fault of VIVIT_PERSIST_FAULT: the gate never opens, whoever is fastest)
     __hip_atomic_compare_exchange_strong(state, &expect, PERSIST_GO, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   int st;

@@ -45,18 +45,20 @@ SYRK_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * 3695931059.375 + 2766
 # round 2 on 8192-k chains: 5.97 / 0.27)
 # Round 4 (profiles/r04_pmc/pmc_syrk_*, final code: one 4096-column chain per launch, 98 launches of each kernel): 4.76 TB
 # fetched / 0.83 TB written -- the workgroups of an XCD start every chain together and share their operand panels again.
-SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.2943e9 + 3.2241e7) + (7.1264e8 + 9.6339e7)) * 1024.0}
+# Round 5 (profiles/r05_pmc/pmc_syrk_*, final code: the same 98 + 98 launches): 4.78 TB fetched / 0.83 TB written.
+SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.3010e9 + 3.2240e7) + (7.1264e8 + 9.6339e7)) * 1024.0}
 # clock the chip holds under that kernel, measured OUTSIDE this process (the product library carries no stamps):
 # in-kernel s_memtime / s_memrealtime stamps of a diagnostic build (scripts/probe/bx_clock.py + libstamp.so, median over
 # the 12 880 workgroups of the last chunk launch after 6 s of back-to-back SYRKs on the bench's own factors;
 # profiles/r03_pmc/v3_bx_clock_real.txt) and GRBM_GUI_ACTIVE / 8 / duration of the PMC pass on N(0,1) data
 # (round 4, profiles/r04_pmc/pmc_syrk_mfma_*: GRBM_GUI_ACTIVE 4.1806e10 / 8 over 2.986 s of gemm256_bx_kernel on N(0,1) data,
 # SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs; the in-kernel stamps are round 3's)
-# round 5 (profiles/r05_pmc/pmc_syrk_mfma_*: the same 98 launches on N(0,1) data on another box): GRBM_GUI_ACTIVE 4.2170e10 / 8 over
-# 2.951 s = 1.786 GHz, SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs = 73.6 % of the cycles
+# round 5 (profiles/r05_pmc/pmc_syrk_mfma_*: the same 98 launches on N(0,1) data, final code = global -> LDS requests issued in row 3):
+# GRBM_GUI_ACTIVE 4.0016e10 / 8 over 2.807 s = 1.782 GHz, SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs = 77.5 % of the cycles
+# (before the request placement, same round: 4.2170e10 / 8 over 2.951 s = 1.786 GHz, 73.6 %)
 SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors": 1.862, "in_kernel_stamps_randn": 1.725,
-                                                  "pmc_grbm_gui_active_randn": 1.786, "nominal": 2.4,
-                                                  "mfma_pipe_busy_pmc": 0.736}}
+                                                  "pmc_grbm_gui_active_randn": 1.782, "nominal": 2.4,
+                                                  "mfma_pipe_busy_pmc": 0.775}}
 # What the SAME per-K-tile instruction mix reaches with every byte of data movement removed (operand pieces in LDS once; no
 # DMA, barrier, flush): scripts/probe/bx_bare_loop.hip, profiles/r05_bx_bare_loop.log -- fraction of the bf16 / 6 ceiling and the
 # clock the chip holds, by operand data.  The power limit, not the kernel, takes the rest of the nominal peak.
@@ -876,10 +878,10 @@ def main():
                     "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
                     "traffic": SYRK_BX_TRAFFIC_BYTES_PMC.get((args.workload, world)) if split == 6 else None,
                     "traffic_note": "bytes of the first-layer weight's SYRK (98.6 % of the Gram flops: 98 split + 98 product launches of "
-                                    "4096 columns) on N(0,1) data, separate rocprofv3 --pmc passes (profiles/r04_pmc; profiles/r05_pmc reproduces "
-                                    "them: FETCH_SIZE 2.2955e9 KiB, WRITE_SIZE 7.1264e8 KiB), FETCH_SIZE includes Infinity-Cache hits",
+                                    "4096 columns) on N(0,1) data, separate rocprofv3 --pmc passes of the final code (profiles/r05_pmc/pmc_syrk_*: "
+                                    "FETCH_SIZE 2.3010e9 + 3.2240e7 KiB, WRITE_SIZE 7.1264e8 + 9.6339e7 KiB), FETCH_SIZE includes Infinity-Cache hits",
                     "clock_ghz": SYRK_BX_CLOCK_GHZ.get((args.workload, world)) if split == 6 else None,
-                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.74) x (clock / 2.4 GHz); NOT "
+                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.775) x (clock / 2.4 GHz); NOT "
                                   "measured in this run: in-kernel stamps of a diagnostic build on the bench's own factors and on N(0,1) data "
                                   "(profiles/r03_pmc/v3_bx_clock_*.txt, round-3 box), GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of a PMC pass over the 98 "
                                   "launches of the first-layer SYRK on N(0,1) data (profiles/r05_pmc/pmc_syrk_mfma_*, round-5 box)",

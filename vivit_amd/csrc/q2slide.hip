@@ -507,8 +507,16 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
     // contains reserved registers: m0 ... may not be preserved") -- and hipcc writes M0 itself only for its own LDS-DMA
     // builtins, s_movrel and s_sendmsg, none of which occurs in this kernel: every use of M0 here is set up by the same asm
     // statement that consumes it.)
+    // Every workgroup starts its share at another piece: the CUs of an XCD otherwise ask the L2 for the same line at the same
+    // time (the image stream alone, without arithmetic, runs 6-11 % faster rotated; the complete kernel 0.5-1 %:
+    // profiles/r05_q2_experiments.md).  The pieces land at their own LDS addresses whatever the order.
+    const int cnt = (QS_NFRAG - lw + nl - 1) / nl;
+    const int rot = (int)(blockIdx.x % (unsigned)cnt);
     auto request = [&](int64_t seq) __attribute__((always_inline)) {
-      for (int f = lw; f < QS_NFRAG; f += nl) {
+      for (int i = 0; i < cnt; ++i) {
+        int ii = i + rot;
+        if (ii >= cnt) ii -= cnt;
+        const int f = lw + nl * ii;
         const unsigned char *src = a.img + seq * (int64_t)QS_IMG + (int64_t)f * 1024;
         const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(seq & 1) * (unsigned)QS_IMG + (unsigned)f * 1024u);
         __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");

@@ -56,9 +56,11 @@ SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.3010e9 + 3.2240
 # round 5 (profiles/r05_pmc/pmc_syrk_mfma_*: the same 98 launches on N(0,1) data, final code = global -> LDS requests issued in row 3):
 # GRBM_GUI_ACTIVE 4.0016e10 / 8 over 2.807 s = 1.782 GHz, SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs = 77.5 % of the cycles
 # (before the request placement, same round: 4.2170e10 / 8 over 2.951 s = 1.786 GHz, 73.6 %)
+# and on the benchmark's OWN first-layer factor (scripts/pmc_syrk_full.py bench; profiles/r05_pmc/pmc_syrk_mfma_bench_*): GRBM_GUI_ACTIVE 4.0224e10 / 8
+# over 2.520 s = 1.996 GHz, SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 = 77.1 % of the cycles: 267.3 TFLOP/s = 0.771 x 1.996 / 2.4 = 0.641 of the ceiling
 SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors": 1.862, "in_kernel_stamps_randn": 1.725,
-                                                  "pmc_grbm_gui_active_randn": 1.782, "nominal": 2.4,
-                                                  "mfma_pipe_busy_pmc": 0.775}}
+                                                  "pmc_grbm_gui_active_randn": 1.782, "pmc_grbm_gui_active_bench_factors": 1.996, "nominal": 2.4,
+                                                  "mfma_pipe_busy_pmc": 0.775, "mfma_pipe_busy_pmc_bench_factors": 0.771}}
 # What the SAME per-K-tile instruction mix reaches with every byte of data movement removed (operand pieces in LDS once; no
 # DMA, barrier, flush): scripts/probe/bx_bare_loop.hip, profiles/r05_bx_bare_loop.log -- fraction of the bf16 / 6 ceiling and the
 # clock the chip holds, by operand data.  The power limit, not the kernel, takes the rest of the nominal peak.
@@ -884,7 +886,7 @@ def main():
                     "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.775) x (clock / 2.4 GHz); NOT "
                                   "measured in this run: in-kernel stamps of a diagnostic build on the bench's own factors and on N(0,1) data "
                                   "(profiles/r03_pmc/v3_bx_clock_*.txt, round-3 box), GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of a PMC pass over the 98 "
-                                  "launches of the first-layer SYRK on N(0,1) data (profiles/r05_pmc/pmc_syrk_mfma_*, round-5 box)",
+                                  "launches of the first-layer SYRK on N(0,1) data and on the bench's own factor (profiles/r05_pmc/pmc_syrk_mfma_*, round-5 boxes)",
                     "bare_loop_ceiling": BX_BARE_LOOP_CEILING if split == 6 else None,
                     "frac_of_bare_loop_on_like_data": (achieved / BX_BARE_LOOP_CEILING["half_zeros_like_the_bench_factors"]["tflops_fp32_equiv"])
                     if split == 6 else None,

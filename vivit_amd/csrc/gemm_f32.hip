@@ -1125,6 +1125,9 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     srcB[u] = (gcptr16)p.B + (kt0 * p.nrbB + bb) * 512 + 8 * lane;
   }
   const int64_t stepA = p.nrbA * 512, stepB = p.nrbB * 512;  // one k tile further
+  // (The addresses stay per-lane 64-bit registers, advanced by one v_lshl_add_u64 per request.  The scalar form -- block address in an
+  // SGPR pair advanced by s_add_u32 / s_addc_u32, one shared 32-bit lane offset, `global_load_lds_dwordx4 v, s[..]` -- measured 1.5-4 %
+  // SLOWER on the SYRK shape (225.1 / 248.8 against 227-234 / 252.5 TFLOP/s, round 5, scripts/probe/syrk_ab.sh).)
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx +
                                                        (unsigned)(wave * 1024));
   auto dma16b = [&](gcptr16 src, unsigned lds_byte_addr) __attribute__((always_inline)) {

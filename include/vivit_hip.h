@@ -326,7 +326,8 @@ int vivit_symeig_banded_rows_f32(float *A, int64_t n, int64_t lda, const float *
 /* Stage 1b of the two-stage path, exported for testing: symmetric BAND -> tridiagonal by bulge
  * chasing.  Half bandwidth NB = vivit_sb2st_half_bandwidth() (64).  AB: [n][2*NB+1] row-band
  * layout, AB[i][j - i + 2*NB] = A[i][j] for i - 2*NB <= j <= i (entries with i - j > NB must be
- * zero on entry: bulge room); destroyed.  d: [n], e: [n].  R2: [n][n], row s receives the
+ * zero on entry: bulge room); contents unspecified afterwards (the chase runs on a copy with padded
+ * rows inside the workspace).  d: [n], e: [n].  R2: [n][n], row s receives the
  * Householder vectors of sweep s (for the back-transformation). */
 int vivit_sb2st_half_bandwidth(void);
 size_t vivit_sb2st_f32_workspace_bytes(int64_t n);

@@ -62,7 +62,11 @@ int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq,
 // sy2sb.hip / sb2st.hip (two-stage tridiagonalisation)
 size_t sy2sb_workspace_bytes(int64_t n);
 int sy2sb_launch(float *A, int64_t n, int64_t lda, void *wsbase, float **tau1_out, hipStream_t stream);
-int sy2sb_extract_band_launch(const float *A, int64_t lda, int64_t n, float *AB, hipStream_t stream);
+// Row stride of the band array INSIDE the library: the 2 NB + 1 = 129 entries of a band row + 3 floats of padding, so that the
+// bulge chase can write a row's [E | D] segment with 16-byte stores (what such a store writes beyond the diagonal entry lands in
+// the padding).  The public entry points (vivit_sy2sb_f32, vivit_sb2st_f32) keep rows of 129.
+constexpr int SB2ST_LDP = 132;
+int sy2sb_extract_band_launch(const float *A, int64_t lda, int64_t n, float *AB, int64_t ldab, hipStream_t stream);
 size_t sy2sb_panel_qr_workspace_bytes(int64_t mp);
 int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float *tau, float *betas, float *T, void *wsbase,
                           size_t ws_bytes, hipStream_t stream);

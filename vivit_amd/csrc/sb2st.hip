@@ -2,7 +2,7 @@
 //
 // The symmetric band matrix (half bandwidth NB = 64) lives in a row-band layout with room for the
 // bulge:  AB[i][j - i + 2*NB] = A[i][j]  for  i - 2*NB <= j <= i   (n x (2*NB+1) floats, 21 MB at
-// n = 40 960: L2 / Infinity-Cache resident).  Sweep s annihilates column s below the sub-diagonal
+// n = 40 960: L2 / Infinity-Cache resident; inside the library rows have a stride of SB2ST_LDP = 132 floats).  Sweep s annihilates column s below the sub-diagonal
 // with a Householder reflector on rows s+1 .. s+NB and chases the resulting bulge down the band:
 // task (s, k) works on rows  R_k = [s+1+k*NB, s+1+(k+1)*NB):
 //     (i)   k > 0: apply H(s,k-1) from the right to the block E = A[R_k, R_{k-1}]   (creates the bulge)
@@ -26,7 +26,8 @@ namespace vivit {
 #define SB2ST_VARIANT 0
 #endif
 constexpr int NB = 64;             // half bandwidth
-constexpr int LDAB = 2 * NB + 1;   // band row length
+constexpr int LDAB = SB2ST_LDP;    // band row stride inside the library: 2 NB + 1 entries + 3 floats of padding (eig_internal.h)
+static_assert(LDAB >= 2 * NB + 1 + 3 && LDAB % 4 == 0, "a 16-byte store of a row's last entries needs three floats of padding");
 
 // value of lane `l` (compile-time constant) as a wave-uniform scalar
 __device__ __forceinline__ float rl(float v, int l) {
@@ -188,16 +189,30 @@ __device__ __forceinline__ float sb2st_core(int k, int L, int wave, int lane, co
 }
 
 // band rows rr0 <= rr < rr1 of this wave (r = 4 rr + wave) from LDS back to the band: lower part of D, and E
+// Sixteen bytes per lane, two band rows per instruction (lanes 0..31: row 4 (2 j) + wave, lanes 32..63: row 4 (2 j + 1) + wave): a
+// row's results are one contiguous segment [E row r (NB floats) | lower part of D row r (r + 1 floats)] that ends at the row's
+// diagonal entry, the last entry of the band row; lane h writes floats 4 h .. 4 h + 3 of it, and what the last store of a row
+// writes beyond the diagonal entry lands in the row's three floats of padding.  (The addresses are 4-byte aligned only.)  A
+// task's 128 single-float store instructions per workgroup kept the write-through queue full for 2.5 us (timing-only builds, all
+// on 256 workgroups with nobody waiting: 298 ms per chase, 171 ms without the bulk stores, 235 ms with these: SB2ST_PVAR notes
+// in DESIGN.md section 8); 32 sixteen-byte ones take half of that.
+template <bool COH>
+__device__ __forceinline__ void band_st4(float *p, float4 v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v w = {v.x, v.y, v.z, v.w};
+  if constexpr (COH) __asm__ volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+  else __asm__ volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(w) : "memory");
+}
 template <bool COH>
 __device__ __forceinline__ void sb2st_store(float *__restrict__ AB, int c0, int L, int k, int wave, int lane, int rr0, int rr1,
                                             const Sb2stLds &lds) {
+  const int half = lane >> 5, s4 = 4 * (lane & 31);
 #pragma unroll
-  for (int rr = 0; rr < NB / 4; ++rr) {
-    const int r = 4 * rr + wave;
-    if (rr >= rr0 && rr < rr1 && r < L) {
-      float *row = AB + (int64_t)(c0 + r) * LDAB;
-      if (k > 0) band_st<COH>(row + (NB - r + lane), lds.sE[r * LDT + lane]);
-      if (lane <= r) band_st<COH>(row + (2 * NB - r + lane), lds.sD[r * LDT + lane]);
+  for (int j = 0; j < NB / 8; ++j) {
+    const int rr = 2 * j + half, r = 4 * rr + wave;
+    if (rr >= rr0 && rr < rr1 && r < L && (s4 < NB ? k > 0 : s4 - NB <= r)) {
+      const float *src = s4 < NB ? lds.sE + r * LDT + s4 : lds.sD + r * LDT + (s4 - NB);
+      band_st4<COH>(AB + (int64_t)(c0 + r) * LDAB + (NB - r + s4), *reinterpret_cast<const float4 *>(src));
     }
   }
 }
@@ -396,6 +411,15 @@ __global__ __launch_bounds__(256) void sb2st_extract_kernel(const float *__restr
   else e[i] = 0.f;
 }
 
+// the caller's band (rows of 2 NB + 1) in the library's row stride (public entry point only)
+__global__ __launch_bounds__(256) void sb2st_pad_kernel(const float *__restrict__ AB, int64_t n, float *__restrict__ ABp) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * LDAB) return;
+  const int64_t i = idx / LDAB;
+  const int c = (int)(idx - i * LDAB);
+  ABp[idx] = c <= 2 * NB ? AB[i * (2 * NB + 1) + c] : 0.f;
+}
+
 int sb2st_num_levels(int64_t n) { return (int)cdiv(n, NB) + 1; }
 int64_t sb2st_ring_rows(int64_t n) { const int64_t need = n / NB + 64; return need < n ? need : n; }
 
@@ -459,7 +483,8 @@ int vivit_sb2st_half_bandwidth(void) { return NB; }
 
 size_t vivit_sb2st_f32_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
-  return sizeof(float) * (size_t)n * (size_t)sb2st_num_levels(n) + 256;
+  // tau2 + the band in the library's own row stride
+  return align_up(sizeof(float) * (size_t)n * (size_t)sb2st_num_levels(n), 256) + sizeof(float) * (size_t)n * (size_t)LDAB + 512;
 }
 
 // AB: [n][2*NB+1] row-band layout (see top of file), destroyed.  d: [n], e: [n-1 (n allocated)].
@@ -469,7 +494,10 @@ int vivit_sb2st_f32(float *AB, int64_t n, float *d, float *e, float *R2, void *w
   if (n < 1 || !AB || !d || !e || !R2) return VIVIT_E_BADARG;
   if (!workspace || workspace_bytes < vivit_sb2st_f32_workspace_bytes(n)) return VIVIT_E_WORKSPACE;
   float *tau2 = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(workspace), 256));
-  return sb2st_launch(AB, n, d, e, R2, n, n, tau2, static_cast<hipStream_t>(stream));
+  float *ABp = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(tau2 + (size_t)n * (size_t)sb2st_num_levels(n)), 256));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  sb2st_pad_kernel<<<(unsigned)cdiv(n * LDAB, 256), 256, 0, s>>>(AB, n, ABp);
+  return sb2st_launch(ABp, n, d, e, R2, n, n, tau2, s);
 }
 
 } // extern "C"

@@ -672,15 +672,15 @@ __global__ __launch_bounds__(256) void larft_kernel(const float *__restrict__ S,
 }
 
 // AB[i][d] = A[i][i - 2*NB + d] for NB <= d <= 2*NB (0 <= i-j <= NB), zero bulge room for d < NB
+// (ldab: row stride of AB, >= 2 NB + 1; entries beyond the band row -- the padding of the library's own layout -- are zeroed)
 __global__ __launch_bounds__(256) void sb_extract_band_kernel(const float *__restrict__ A, int64_t lda, int64_t n,
-                                                              float *__restrict__ AB) {
+                                                              float *__restrict__ AB, int64_t ldab) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int LD = 2 * SNB + 1;
-  if (idx >= n * LD) return;
-  const int64_t i = idx / LD;
-  const int d = (int)(idx - i * LD);
+  if (idx >= n * ldab) return;
+  const int64_t i = idx / ldab;
+  const int d = (int)(idx - i * ldab);
   const int64_t j = i - 2 * SNB + d;
-  AB[idx] = (d >= SNB && j >= 0) ? A[i * lda + j] : 0.f;
+  AB[idx] = (d >= SNB && d <= 2 * SNB && j >= 0) ? A[i * lda + j] : 0.f;
 }
 
 // split-K scratch: the largest need over the GEMM shapes used per panel (trailing size mp <= n)
@@ -912,8 +912,8 @@ int sy2sb_panel_qr_launch(float *pan, int64_t mp, float *Vt, int64_t ldv, float 
   return launch_status();
 }
 
-int sy2sb_extract_band_launch(const float *A, int64_t lda, int64_t n, float *AB, hipStream_t stream) {
-  sb_extract_band_kernel<<<(unsigned)cdiv(n * (2 * SNB + 1), 256), 256, 0, stream>>>(A, lda, n, AB);
+int sy2sb_extract_band_launch(const float *A, int64_t lda, int64_t n, float *AB, int64_t ldab, hipStream_t stream) {
+  sb_extract_band_kernel<<<(unsigned)cdiv(n * ldab, 256), 256, 0, stream>>>(A, lda, n, AB, ldab);
   return launch_status();
 }
 
@@ -935,7 +935,7 @@ int vivit_sy2sb_f32(float *A, int64_t n, int64_t lda, float *AB, float *tau1, vo
   float *t1;
   int st = sy2sb_launch(A, n, lda, workspace, &t1, s);
   if (st != VIVIT_OK) return st;
-  st = sy2sb_extract_band_launch(A, lda, n, AB, s);
+  st = sy2sb_extract_band_launch(A, lda, n, AB, 2 * SNB + 1, s);
   if (st != VIVIT_OK) return st;
   if (hipMemcpyAsync(tau1, t1, sizeof(float) * n, hipMemcpyDeviceToDevice, s) != hipSuccess) return VIVIT_E_LAUNCH;
   return VIVIT_OK;

@@ -182,7 +182,7 @@ static size_t two_stage_workspace_bytes(int64_t n, bool vectors) {
   size_t b = 0;
   b += align_up(sizeof(float) * 16, 256) + align_up(sizeof(float) * 2 * n, 256);       // scal, scan partials
   b += align_up(sy2sb_workspace_bytes(n), 256);
-  b += align_up(sizeof(float) * n * (2 * TS_NB + 1), 256);                              // AB
+  b += align_up(sizeof(float) * n * SB2ST_LDP, 256);                              // AB
   b += align_up(sizeof(float) * (vectors ? n : sb2st_ring_rows(n)) * n, 256);           // R2
   b += align_up(sizeof(float) * n * sb2st_num_levels(n), 256);                          // tau2
   b += align_up(sizeof(float) * n, 256) * 2;                                            // d, e
@@ -210,7 +210,7 @@ static int symeig_two_stage_values(float *A, int64_t n, int64_t lda, float *w, v
   float *scal = (float *)take(sizeof(float) * 16);
   float *part = (float *)take(sizeof(float) * 2 * n);
   void *sbws = take(sy2sb_workspace_bytes(n));
-  float *AB = (float *)take(sizeof(float) * n * (2 * TS_NB + 1));
+  float *AB = (float *)take(sizeof(float) * n * SB2ST_LDP);
   const int64_t rrows = sb2st_ring_rows(n);
   float *R2 = (float *)take(sizeof(float) * rrows * n);
   float *tau2 = (float *)take(sizeof(float) * n * sb2st_num_levels(n));
@@ -225,7 +225,7 @@ static int symeig_two_stage_values(float *A, int64_t n, int64_t lda, float *w, v
   float *tau1;
   st = sy2sb_launch(A, n, lda, sbws, &tau1, stream);
   if (st != VIVIT_OK) return st;
-  st = sy2sb_extract_band_launch(A, lda, n, AB, stream);
+  st = sy2sb_extract_band_launch(A, lda, n, AB, SB2ST_LDP, stream);
   if (st != VIVIT_OK) return st;
   prof_mark(PROF_STAGE_SY2SB, stream);
   st = sb2st_launch(AB, n, d, e, R2, n, rrows, tau2, stream);
@@ -263,7 +263,7 @@ static int symeig_large_impl(float *A, int64_t n, int64_t lda, float *w, float *
     float *scal = (float *)take(sizeof(float) * 16);
     float *part = (float *)take(sizeof(float) * 2 * n);
     void *sbws = take(sy2sb_workspace_bytes(n));
-    float *AB = (float *)take(sizeof(float) * n * (2 * TS_NB + 1));
+    float *AB = (float *)take(sizeof(float) * n * SB2ST_LDP);
     float *R2 = (float *)take(sizeof(float) * n * n);
     const size_t tau2_bytes = sizeof(float) * n * sb2st_num_levels(n);
     float *tau2 = (float *)take(tau2_bytes);
@@ -278,7 +278,7 @@ static int symeig_large_impl(float *A, int64_t n, int64_t lda, float *w, float *
     float *tau1;
     st = sy2sb_launch(A, n, lda, sbws, &tau1, stream);
     if (st != VIVIT_OK) return st;
-    st = sy2sb_extract_band_launch(A, lda, n, AB, stream);
+    st = sy2sb_extract_band_launch(A, lda, n, AB, SB2ST_LDP, stream);
     if (st != VIVIT_OK) return st;
     prof_mark(PROF_STAGE_SY2SB, stream);
     if (hipMemsetAsync(tau2, 0, tau2_bytes, stream) != hipSuccess) return VIVIT_E_LAUNCH;
@@ -397,7 +397,7 @@ static SelectLayout select_layout(void *ws, int64_t n) {
     L.scal = (float *)take(sizeof(float) * 16);
     L.part = (float *)take(sizeof(float) * 2 * n);
     L.sbws = take(sy2sb_workspace_bytes(n));
-    L.AB = (float *)take(sizeof(float) * n * (2 * TS_NB + 1));
+    L.AB = (float *)take(sizeof(float) * n * SB2ST_LDP);
     L.R2 = (float *)take(sizeof(float) * n * n);
     L.tau2 = (float *)take(sizeof(float) * n * sb2st_num_levels(n));
     L.tau1 = (float *)take(sizeof(float) * n);
@@ -423,7 +423,7 @@ size_t symeig_reduce_workspace_bytes(int64_t n) {
   if (select_two_stage(n)) {
     b += align_up(sizeof(float) * 16, 256) + align_up(sizeof(float) * 2 * n, 256);
     b += align_up(sy2sb_workspace_bytes(n), 256);
-    b += align_up(sizeof(float) * n * (2 * TS_NB + 1), 256);
+    b += align_up(sizeof(float) * n * SB2ST_LDP, 256);
     b += align_up(sizeof(float) * n * n, 256);
     b += align_up(sizeof(float) * n * sb2st_num_levels(n), 256);
     b += align_up(sizeof(float) * n, 256) * 3;
@@ -467,7 +467,7 @@ int symeig_reduce_launch(float *A, int64_t n, int64_t lda, float *w, void *ws, s
     st = sy2sb_launch(A, n, lda, L.sbws, &tau1, stream);
     if (st != VIVIT_OK) return st;
     if (hipMemcpyAsync(L.tau1, tau1, sizeof(float) * n, hipMemcpyDeviceToDevice, stream) != hipSuccess) return VIVIT_E_LAUNCH;
-    st = sy2sb_extract_band_launch(A, lda, n, L.AB, stream);
+    st = sy2sb_extract_band_launch(A, lda, n, L.AB, SB2ST_LDP, stream);
     if (st != VIVIT_OK) return st;
     prof_mark(PROF_STAGE_SY2SB, stream);
     if (hipMemsetAsync(L.tau2, 0, sizeof(float) * n * sb2st_num_levels(n), stream) != hipSuccess) return VIVIT_E_LAUNCH;
@@ -566,7 +566,7 @@ int symeig_banded_rows_launch(float *A, int64_t n, int64_t lda, const float *tau
     return r;
   };
   float *scal = (float *)take(sizeof(float) * 16);
-  float *AB = (float *)take(sizeof(float) * n * (2 * TS_NB + 1));
+  float *AB = (float *)take(sizeof(float) * n * SB2ST_LDP);
   float *R2 = (float *)take(sizeof(float) * n * n);
   const size_t tau2_bytes = sizeof(float) * n * sb2st_num_levels(n);
   float *tau2 = (float *)take(tau2_bytes);
@@ -574,7 +574,7 @@ int symeig_banded_rows_launch(float *A, int64_t n, int64_t lda, const float *tau
   float *e = (float *)take(sizeof(float) * n);
   if (hipMemcpyAsync(scal, scal_in, sizeof(float) * 16, hipMemcpyDeviceToDevice, stream) != hipSuccess) return VIVIT_E_LAUNCH;
   prof_mark(PROF_STAGE_BEGIN, stream);
-  int st = sy2sb_extract_band_launch(A, lda, n, AB, stream);
+  int st = sy2sb_extract_band_launch(A, lda, n, AB, SB2ST_LDP, stream);
   if (st != VIVIT_OK) return st;
   prof_mark(PROF_STAGE_SY2SB, stream);
   if (hipMemsetAsync(tau2, 0, tau2_bytes, stream) != hipSuccess) return VIVIT_E_LAUNCH;

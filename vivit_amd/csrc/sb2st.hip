@@ -89,23 +89,32 @@ __device__ __forceinline__ void sb2st_load(const float *__restrict__ AB, int c0,
 }
 
 // Blocks in registers -> LDS, the task's arithmetic, results back in LDS (rows of E and D as they go back to the band).
+// Band rows rr0 <= rr < rr1 of this wave (r = 4 rr + wave) from registers into the LDS blocks (rows beyond L and, for the first task
+// of a sweep, the whole E block are zero; D is completed to the full symmetric block).  The persistent kernel does this for all
+// rows while it waits for the hand-over of the last one and repeats it for that row alone afterwards.
+__device__ __forceinline__ void sb2st_stage(int k, int L, int wave, int lane, const Sb2stRows &t, Sb2stLds &lds, int rr0, int rr1) {
+  float *sE = lds.sE, *sD = lds.sD;
+#pragma unroll
+  for (int rr = 0; rr < NB / 4; ++rr) {
+    if (rr >= rr0 && rr < rr1) {
+      const int r = 4 * rr + wave;
+      const bool in = r < L;
+      const float e1 = (in && k > 0) ? t.ev[rr] : 0.f, d1 = in ? t.dv[rr] : 0.f;
+      sE[r * LDT + lane] = e1;
+      if (lane <= r) {
+        sD[r * LDT + lane] = d1;
+        sD[lane * LDT + r] = d1;
+      }
+    }
+  }
+}
+
+// The task's arithmetic on the staged blocks (sb2st_stage by every wave, then this), results back in LDS.
 // x: column s of the band for k = 0.  (pv, ptau): reflector of task k - 1 in, of task k out.  Returns beta.
-__device__ __forceinline__ float sb2st_core(int k, int L, int wave, int lane, const Sb2stRows &t, float x, float &pv, float &ptau,
-                                            Sb2stLds &lds) {
+__device__ __forceinline__ float sb2st_core(int k, int L, int wave, int lane, float x, float &pv, float &ptau, Sb2stLds &lds) {
   float *sE = lds.sE, *sD = lds.sD;
   auto &red = lds.red;
   const int q0 = 16 * wave;
-#pragma unroll
-  for (int rr = 0; rr < NB / 4; ++rr) {
-    const int r = 4 * rr + wave;
-    const bool in = r < L;
-    const float e1 = (in && k > 0) ? t.ev[rr] : 0.f, d1 = in ? t.dv[rr] : 0.f;
-    sE[r * LDT + lane] = e1;
-    if (lane <= r) {
-      sD[r * LDT + lane] = d1;
-      sD[lane * LDT + r] = d1;
-    }
-  }
   __syncthreads();
 
   float er[16], d[16];
@@ -238,7 +247,8 @@ __global__ __launch_bounds__(256) void sb2st_task_kernel(float *__restrict__ AB,
   }
   Sb2stRows rows;
   sb2st_load<false>(AB, c0, L, wave, lane, rows);
-  const float beta = sb2st_core(k, L, wave, lane, rows, x, pv, ptau, lds);
+  sb2st_stage(k, L, wave, lane, rows, lds, 0, NB / 4);
+  const float beta = sb2st_core(k, L, wave, lane, x, pv, ptau, lds);
   if (wave == 0) {
     if (k == 0 && lane < L) AB[(int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)] = (lane == 0) ? beta : 0.f;
     if (lane < L) R2[(int64_t)(s % rmod) * ldr + c0 + lane] = pv;
@@ -344,6 +354,9 @@ __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ 
       if (s_info[1]) break;
       Sb2stRows rows;
       sb2st_load<true>(AB, c0, L, wave, lane, rows);
+      // into LDS while the hand-over of the last row is awaited: off the chain of the wavefront step (the stale copy of that row goes
+      // along and is replaced below)
+      sb2st_stage(k, L, wave, lane, rows, lds, 0, NB / 4);
 #if !(defined(SB2ST_PVAR) && SB2ST_PVAR == 2)
       if (tid == 0 && s > 0) wait_for(s - 1, true, k + 2 < kprev ? k + 2 : kprev);
 #endif
@@ -353,6 +366,7 @@ __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ 
         const float *row = AB + (int64_t)(c0 + NB - 1) * LDAB;
         rows.ev[NB / 4 - 1] = band_ld<true>(row + (1 + lane));
         rows.dv[NB / 4 - 1] = band_ld<true>(row + (NB + 1 + lane));
+        sb2st_stage(k, L, wave, lane, rows, lds, NB / 4 - 1, NB / 4);
       }
       float x = 0.f;
       if (k == 0) x = lane < L ? band_ld<true>(AB + (int64_t)(c0 + lane) * LDAB + (2 * NB - 1 - lane)) : 0.f;  // column s of the band
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(256) void sb2st_persist_kernel(float *__restrict__ 
       lds.sE[tid] = rows.ev[0]; lds.sD[tid] = rows.dv[0];
       __syncthreads();
 #else
-      const float beta = sb2st_core(k, L, wave, lane, rows, x, pv, ptau, lds);
+      const float beta = sb2st_core(k, L, wave, lane, x, pv, ptau, lds);
 #endif
       // ---- first row out, counter A
       if (wave == 0) {

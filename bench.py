@@ -912,7 +912,7 @@ def main():
             "metric": f"GGN eigenpairs/sec (Gram build + symeig), MLP {dims[0]}-{dims[1]}-{dims[2]}, batch={batch}",
             "value": value,
             "unit": "eigenpairs/s",
-            "n_gpus": world_info["world_size"],
+            "n_gpus": world_info["distinct_devices"],   # GPUs, not ranks: two gloo ranks on one card are ONE GPU (world.world_size says 2)
             "world": world_info,
             "steps": args.steps,
             "warmup": args.warmup,

@@ -59,8 +59,9 @@ extern "C" {
  * variables); -1: back to the environment's choice.  Returns the previous setting (-1, 0 or 1).  Host-side state only. */
 int vivit_persistent_kernels(int on);
 /* For callers of the STAGE-level entry points (vivit_sytrd_f32, vivit_sy2sb_f32, vivit_sy2sb_panel_qr_f32,
- * vivit_sb2st_f32), which have no info word: *info (device) = VIVIT_INFO_PERSIST_TIMEOUT if a persistent kernel gave up
- * since the failure word was last taken, and clears the word; *info is left alone otherwise.  The vivit_symeig*_f32 entry
+ * vivit_sb2st_f32), which have no info word: *info (device) = VIVIT_INFO_PERSIST_TIMEOUT if a persistent kernel launched on
+ * `stream` gave up since that stream's failure word was last taken, and clears the word (there is one word per device and
+ * stream, so a solve on another stream is never blamed); *info is left alone otherwise.  The vivit_symeig*_f32 entry
  * points do this themselves.  (A stage that gave up also poisons its output with NaN, so nothing fails silently.) */
 int vivit_take_persist_timeout(int32_t *info, void *stream);
 

@@ -1,9 +1,13 @@
 """Build libvivit_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build().
 
-Provenance: the library exports ``vivit_hip_source_hash()`` = ``source_hash()`` of the tree it was compiled from
-(every file of csrc/ + include/vivit_hip.h, by CONTENT); ``_lib.load()`` refuses a library whose hash differs from
-the sources beside it, so a stale shipped binary cannot be tested by accident.  Objects are rebuilt when the content
-hash of (source, headers, flags) recorded beside them differs -- not by modification time.
+Provenance: the library exports ``vivit_hip_source_hash()`` = ``"<source_hash()>-<flags_digest(flags)>"``: the content
+hash of the tree it was compiled from (every file of csrc/ + include/vivit_hip.h) and the digest of the compile flags of
+ALL its objects.  The function lives in an object generated at link time (csrc/obj/link/buildinfo.c), outside csrc/obj/,
+so a library relinked by hand from product objects plus one compiled with other defines (the timing-only variants of
+scripts/probe/) has no such symbol unless its script supplies one -- it cannot report the product's hash.
+``_lib.load()`` refuses a library whose hash differs from the sources beside it or whose flags are not a known build's,
+so neither a stale binary nor a variant can be tested by accident.  Objects are rebuilt when the content hash of
+(source, headers, flags) recorded beside them differs -- not by modification time.
 """
 import glob
 import hashlib
@@ -55,8 +59,29 @@ def source_hash():
     return _digest(hips + _headers())[:32]
 
 
-def _hash_define():
-    return '-DVIVIT_SOURCE_HASH="%s"' % source_hash()
+def flags_digest(flags):
+    """8 hex digits naming a set of compile flags (second half of ``vivit_hip_source_hash()``)."""
+    return hashlib.sha256(" ".join(flags).encode()).hexdigest()[:8]
+
+
+def _buildinfo_object(objdir, flags, extra_cflags=()):
+    """Compile the link-time object that defines ``vivit_hip_source_hash()`` for a library whose objects were ALL built
+    by this module with ``flags`` (every stale object has just been recompiled, the stamps say so)."""
+    linkdir = os.path.join(objdir, "link")
+    os.makedirs(linkdir, exist_ok=True)
+    text = ('const char *vivit_hip_source_hash(void) { return "%s-%s"; }\n' % (source_hash(), flags_digest(flags)))
+    c, o = os.path.join(linkdir, "buildinfo.c"), os.path.join(linkdir, "buildinfo.o")
+    try:
+        with open(c) as f:
+            same = f.read() == text
+    except OSError:
+        same = False
+    if not same or not os.path.exists(o):
+        with open(c, "w") as f:
+            f.write(text)
+        subprocess.check_call(["gcc", "-c", "-fPIC"] + list(extra_cflags) + [c, "-o", o])
+        return o, True
+    return o, False
 
 
 def _stamp_stale(obj, stamp):
@@ -79,8 +104,7 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        # api.hip carries the hash of the whole tree (vivit_hip_source_hash), so it is recompiled on every change
-        flags = FLAGS + ([_hash_define()] if src == "api.hip" else [])
+        flags = FLAGS
         stamp = _digest([s] + headers, flags)
         if force or _stamp_stale(o, stamp):
             cmd = [_hipcc()] + flags + ["-c", s, "-o", o]
@@ -100,8 +124,9 @@ def build(force=False, verbose=True):
                 f.write(stamp + "\n")
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    if force or procs or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    info, fresh = _buildinfo_object(objdir, FLAGS)
+    if force or procs or fresh or _stale(LIB, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + [info]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -109,6 +134,8 @@ def build(force=False, verbose=True):
 
 
 ASAN_LIB = os.path.join(HERE, "libvivit_hip_hostasan.so")
+ASAN_FLAGS = ["-O1", "-g", "--offload-host-only", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
+              "-fPIC", "-std=c++17", "-Wno-unused-function"]
 
 
 def sanitizer_runtime():
@@ -123,15 +150,14 @@ def build_host_sanitized(verbose=False):
     pool.  The result can refuse calls and plan launches; any kernel launch through it fails.  Returns the library path."""
     objdir = os.path.join(CSRC, "obj_asan")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["-O1", "-g", "--offload-host-only", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
-             "-fPIC", "-std=c++17", "-Wno-unused-function"]
+    flags = ASAN_FLAGS
     headers = _headers()
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        fl = flags + ([_hash_define()] if src == "api.hip" else [])
+        fl = flags
         stamp = _digest([s] + headers, fl)
         if _stamp_stale(o, stamp):
             procs.append((src, o, stamp, subprocess.Popen([_hipcc()] + fl + ["-c", s, "-o", o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -143,7 +169,8 @@ def build_host_sanitized(verbose=False):
             f.write(stamp + "\n")
         if verbose and out.strip():
             print(out)
-    if procs or _stale(ASAN_LIB, objs):
+    info, fresh = _buildinfo_object(objdir, flags)
+    if procs or fresh or _stale(ASAN_LIB, objs):
         # a host-only object still refers to its (absent) device fat binary: define each of those symbols as an EMPTY
         # clang offload bundle (magic + zero entries), which the HIP runtime registers and never finds a kernel in
         undef = subprocess.run(["nm", "-u"] + objs, stdout=subprocess.PIPE, text=True).stdout.split()
@@ -154,7 +181,7 @@ def build_host_sanitized(verbose=False):
                 f.write('__attribute__((aligned(4096))) const char %s[4096] = "__CLANG_OFFLOAD_BUNDLE__";\n' % nme)
         stub_o = os.path.join(objdir, "fatbin_stub.o")
         subprocess.check_call(["gcc", "-c", "-fPIC", stub_c, "-o", stub_o])
-        subprocess.check_call([_hipcc(), "-shared", "-fPIC", "--offload-host-only", "-fsanitize=address,undefined", "-o", ASAN_LIB] + objs + [stub_o])
+        subprocess.check_call([_hipcc(), "-shared", "-fPIC", "--offload-host-only", "-fsanitize=address,undefined", "-o", ASAN_LIB] + objs + [stub_o, info])
     return ASAN_LIB
 
 

@@ -128,17 +128,20 @@ def load():
 
 
 def _check_provenance(lib):
-    """The library must have been compiled from the sources beside this package (content hash, _build.source_hash):
-    a stale shipped binary is refused instead of being tested by accident.  VIVIT_HIP_ALLOW_STALE=1 turns the error into
-    a warning (bisecting with an old library); a binary-only install (no csrc/) has nothing to compare with."""
+    """The library must have been compiled from the sources beside this package (content hash, _build.source_hash) with
+    the flags of a known build (_build.flags_digest of the product's or the host-sanitizer build's flags): a stale shipped
+    binary, or a timing-only variant relinked with other defines, is refused instead of being tested by accident.
+    VIVIT_HIP_ALLOW_STALE=1 turns the error into a warning (bisecting with an old library, timing a variant); a
+    binary-only install (no csrc/) has nothing to compare with."""
     from . import _build
 
     want = _build.source_hash()
     have = lib.vivit_hip_source_hash().decode()
-    if want is None or have == want:
+    known = {f"{want}-{_build.flags_digest(fl)}" for fl in (_build.FLAGS, _build.ASAN_FLAGS)}
+    if want is None or have in known:
         return
-    msg = (f"{LIB_PATH} was built from other sources (library hash {have}, source tree {want}): rebuild it "
-           "(`python -c 'import __graft_entry__ as g; g.build()'`)")
+    msg = (f"{LIB_PATH} was built from other sources or with other flags (library hash {have}, this tree + product flags "
+           f"{want}-{_build.flags_digest(_build.FLAGS)}): rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
     if os.environ.get("VIVIT_HIP_ALLOW_STALE") == "1":
         import warnings
 

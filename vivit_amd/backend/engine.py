@@ -22,8 +22,9 @@ _ACTIVE = None  # the innermost active ``backpack`` context
 # Enqueued on the backward pass' own stream they nevertheless run one after the other with its kernels (BASELINE config 4:
 # 36 ms of plain backward + 27 ms of extension work = 64 ms).  With ``VIVIT_SIDE_STREAM`` != 0 (default) every hook body runs
 # on a second stream per device:
-#   * at the first hook of a pass (no back-propagated quantity pending) the side stream waits for the stream the hook was
-#     called on: the forward pass is complete, and every earlier use of recycled side-stream memory on that stream as well;
+#   * at the first hook of a pass ON EACH DEVICE (tracked per pass in ``_waited``; the end-of-pass callback clears it) the side
+#     stream waits for the stream the hook was called on: the forward pass is complete, and every earlier use of recycled
+#     side-stream memory on that stream as well;
 #   * extensions that consume autograd's gradient (``uses_grad``: BatchGrad) make it wait at every hook, and the gradient
 #     tensor is recorded on the side stream (the caching allocator must not recycle it under the side stream's reads); the
 #     forward activations the rules read are kept alive by the modules (``input0`` / ``output``) until the next forward pass;
@@ -32,6 +33,10 @@ _ACTIVE = None  # the innermost active ``backpack`` context
 #     whatever the caller reads afterwards -- inside the block or behind it (``param.sqrt_ggn_exact``, ``get_result``) -- is
 #     ordered behind the work that produced it.
 # Kernels are the same and run in the same order relative to each other: results are bit-identical.
+# Contract for a user ``extension_hook``: it runs on the side stream too.  It may read whatever the extensions stored
+# (``param.<savefield>``) and forward activations; a hook that reads ``param.grad`` or any other product of autograd's own
+# backward kernels must be paired with an extension whose ``uses_grad`` is True (the default of ``_Extension``; only the
+# sqrt-GGN family, which ignores the gradient, opts out) or run with ``VIVIT_SIDE_STREAM=0``.
 _SIDE_STREAMS = {}
 
 
@@ -59,7 +64,8 @@ class backpack:
         self._outer = None
         self._side_used = {}   # device index -> (side stream, stream of the backward pass) used inside this block
         self._join_queued = False
-        self._uses_grad = any(getattr(e, "uses_grad", False) for e in extensions)
+        self._waited = set()   # devices whose side stream has waited for the backward pass' stream in the CURRENT pass
+        self._uses_grad = any(getattr(e, "uses_grad", True) for e in extensions)
 
     def __enter__(self):
         global _ACTIVE
@@ -75,13 +81,21 @@ class backpack:
         for index, (side, _) in self._side_used.items():   # the caller's stream continues behind the extensions' work
             torch.cuda.current_stream(index).wait_stream(side)
         self._side_used.clear()
+        # a backward pass that raised never ran its end-of-pass callback: a re-entered context must queue a new one
+        self._join_queued = False
+        self._waited.clear()
         return False
 
     def _join(self):
         """End of a backward pass (autograd engine callback): the pass' own stream waits for the extensions' stream."""
         self._join_queued = False
+        self._waited.clear()
         for side, main in self._side_used.values():
             main.wait_stream(side)
+        # quantities nobody popped (the factor handed to a network input that requires grad) must not look like a pass in
+        # progress to the next backward pass inside the same block
+        self.state.clear()
+        self._keepalive.clear()
 
     # back-propagated quantities are keyed by the identity of the activation tensor
     def put(self, ext, tensor, value):
@@ -106,16 +120,19 @@ def _make_output_hook(module: Module):
         ctx = _ACTIVE
         if ctx is None:
             return None
+        if not ctx._join_queued:              # once per pass: join the streams / drop left-over quantities when the pass is over
+            ctx._join_queued = True
+            ctx._waited.clear()
+            torch.autograd.Variable._execution_engine.queue_callback(ctx._join)
         side = _side_stream(grad.device)
         if side is None:
             run(ctx, grad)
             return None
         main = torch.cuda.current_stream(grad.device)
-        if ctx._uses_grad or not ctx.state:   # first hook of a pass, or an extension that reads autograd's gradient
+        index = grad.device.index
+        if ctx._uses_grad or index not in ctx._waited:   # an extension that reads autograd's gradient, or the first hook of this pass on this device
             side.wait_stream(main)
-        if not ctx._join_queued:              # once per pass: join the streams when the pass is over
-            ctx._join_queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(ctx._join)
+            ctx._waited.add(index)
         if ctx._uses_grad:
             # autograd frees the gradient right after this hook returns; its memory belongs to the backward pass' stream and
             # would be handed out again while the side stream still reads it

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from vivit_amd import _lib, kernels
-from vivit_amd.backend.custom_module import Pad, Slicing, SumModule
+from vivit_amd.backend.custom_module import ActiveIdentity, Pad, ScaleModule, Slicing, SumModule
 from vivit_amd.utils.ggn import Vmp
 from vivit_amd.utils.gram import mVp, pairwise_dot
 
@@ -71,6 +71,10 @@ class LinearFactor:
 
 class _Extension:
     savefield = None
+    # Stream contract (backend/engine.py): an extension whose ``apply`` reads ``g_out`` (autograd's gradient) keeps
+    # ``uses_grad = True`` -- the extensions' stream then waits for the backward pass at every hook and the gradient is
+    # recorded on it.  Only extensions that provably ignore ``g_out`` (the sqrt-GGN family) may set it to False.
+    uses_grad = True
 
     def __init__(self, subsampling: Optional[List[int]] = None):
         self._subsampling = subsampling
@@ -110,17 +114,13 @@ def _spatial_sum3(M: Tensor) -> Tensor:
 
 
 def _bn_constants(module):
-    """``(rstd, scale)`` of a BatchNorm in eval mode, remembered on the module while its statistics are unchanged (two tiny
-    launches per module and backward pass otherwise)."""
-    key = (module.running_var._version, module.running_var.data_ptr(), None if module.weight is None else module.weight._version,
-           module.eps)
-    memo = getattr(module, "_vivit_bn_constants", None)
-    if memo is None or memo[0] != key:
-        rstd = torch.rsqrt(module.running_var + module.eps)
-        scale = rstd * module.weight.detach() if module.weight is not None else rstd
-        memo = (key, rstd, scale)
-        module._vivit_bn_constants = memo
-    return memo[1], memo[2]
+    """``(rstd, scale)`` of a BatchNorm in eval mode, recomputed at every use (two tiny launches): the three rules of a module
+    share them through the memo :func:`_bn_eval_rules` keeps on the factor tensor, i.e. for one backward pass.  Nothing is
+    remembered on the module: writes through ``.data`` (``bn.weight.data = ...``, as the reference's tests re-initialise,
+    test/utils.py:111) leave ``_version`` and ``data_ptr`` unchanged, so no key on the module can tell stale constants."""
+    rstd = torch.rsqrt(module.running_var + module.eps)
+    scale = rstd * module.weight.detach() if module.weight is not None else rstd
+    return rstd, scale
 
 
 def _bn_scale(module) -> Tensor:
@@ -402,15 +402,20 @@ def _single(v):
 
 
 def _hip_jac_t_mat_prod(module, M: Tensor, x: Tensor) -> Optional[Tensor]:
-    """The layer rules that have a HIP kernel (csrc/jacobians.hip): activations, Flatten / Identity / Dropout(eval),
+    """The layer rules that have a HIP kernel (csrc/jacobians.hip): activations, Flatten / Identity / ActiveIdentity / Dropout(eval), ScaleModule,
     Max/AvgPool1d/2d, Conv1d / Conv2d and ConvTranspose1d / 2d (any groups, zero padding), Pad / ZeroPad2d / Slicing,
     BatchNorm (eval), and -- on the same two-dimensional kernels -- Conv3d, ConvTranspose3d, MaxPool3d, AvgPool3d.  ``None``: no
     kernel for this module (custom modules, unsupported options such as ceil_mode) -- the generic autograd rule takes over."""
     kind = _ACTIVATIONS.get(type(module))
     if kind is not None:
         return kernels.act_jac_t(M, x, kind[0], getattr(module, kind[1]) if kind[1] else 0.0)
-    if isinstance(module, (nn.Flatten, nn.Identity, nn.Dropout)):
+    if isinstance(module, (nn.Flatten, nn.Identity, nn.Dropout, ActiveIdentity)):
         return M.reshape(M.shape[0], *x.shape)
+    if isinstance(module, ScaleModule):   # SqrtGGNScaleModule (__init__.py:113-116): the Jacobian is ``weight * I``
+        if module.weight == 1.0:
+            return M
+        Mc = M if M.dim() > 3 else M.unsqueeze(-1)
+        return kernels.channel_scale(Mc, M.new_full((Mc.shape[2],), module.weight)).view(M.shape)
     # index modules: the transposed Jacobian of a zero / constant padding is a crop, that of a slicing a scatter into zeros
     # (SqrtGGNPad / SqrtGGNZeroPad2d / SqrtGGNSlicing, __init__.py:110-117) -- no recomputed forward, no autograd
     if isinstance(module, (Pad, nn.ZeroPad2d)):
@@ -635,6 +640,7 @@ def _loss_hessian_sqrt(module, strategy: str, mc_samples: int, samples: Optional
 
 class _SqrtGGN(_Extension):
     strategy = "exact"
+    uses_grad = False   # reads forward activations and the back-propagated factor only, never ``g_out``
 
     def __init__(self, subsampling=None, mc_samples: int = 1, samples: Optional[Tensor] = None, factorised: bool = False):
         super().__init__(subsampling)

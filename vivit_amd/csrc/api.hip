@@ -22,13 +22,12 @@ using namespace vivit;
 
 extern "C" {
 
-#ifndef VIVIT_SOURCE_HASH
-#define VIVIT_SOURCE_HASH "unknown"   // builds outside vivit_amd/_build.py (which passes the hash of the source tree)
-#endif
+// vivit_hip_source_hash() is NOT defined here: vivit_amd/_build.py generates it at link time (csrc/obj/link/buildinfo.c)
+// from the content hash of the tree AND the digest of the compile flags of every object it links, so a library relinked
+// from product objects plus a differently-compiled one (timing-only variants) cannot carry the product's hash.
 
 int vivit_hip_abi_version(void) { return 1007; }
 const char *vivit_hip_target(void) { return "gfx950"; }
-const char *vivit_hip_source_hash(void) { return VIVIT_SOURCE_HASH; }
 
 const char *vivit_hip_status_string(int status) {
   switch (status) {

@@ -97,11 +97,11 @@ enum { PROF_STAGE_BEGIN = 0, PROF_STAGE_PREP = 1, PROF_STAGE_SY2SB = 2, PROF_STA
        PROF_STAGE_SY2SB_PP = 9, PROF_STAGE_SY2SB_UPD = 10, PROF_NUM_STAGES = 11 };
 void prof_mark(int stage, hipStream_t stream);
 
-// profile.hip: the persistent kernels' failure word (device memory of the CURRENT device, no allocation: a __device__
-// variable).  A persistent kernel that gave up (co-residency not reached in two attempts, or a stalled exchange) ORs its
-// PERSIST_TMO_* bit into it; the next info finalisation of an eigensolver call reports VIVIT_INFO_PERSIST_TIMEOUT and
-// clears it.  nullptr on failure of the symbol lookup.
-int *persist_timeout_word();
+// profile.hip: the persistent kernels' failure word of (CURRENT device, `stream`) -- device memory, no allocation: an entry
+// of a __device__ array.  A persistent kernel that gave up (co-residency not reached in two attempts, or a stalled
+// exchange) ORs its PERSIST_TMO_* bit into it; the next info finalisation of an eigensolver call ON THE SAME STREAM reports
+// VIVIT_INFO_PERSIST_TIMEOUT and clears it.  nullptr on failure of the symbol lookup.
+int *persist_timeout_word(hipStream_t stream);
 // 1 / 0: persistent kernels allowed by vivit_persistent_kernels(); -1: no override (the environment variables decide)
 int persist_override();
 // VIVIT_PERSIST_FAULT (tests): bit a set = attempt a of every persistent kernel's arrival gate gives up at once

@@ -2,6 +2,9 @@
 // When enabled, the Gram SYRK launches and every `stride`-th symmetric matrix-vector launch of
 // the tridiagonalisation are bracketed by events on the stream they are launched on.
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -36,19 +39,34 @@ void prof_mark(int stage, hipStream_t stream) {
   g_marks.push_back(m);
 }
 
-__device__ int g_persist_timeout = 0;
+// One sticky word per (device, stream): solves on one stream are ordered, so the word a persistent kernel writes is taken
+// by the info finalisation of ITS solve; a solve on another stream (the hooks' side stream beside the caller's) has a word
+// of its own and cannot be blamed for it.  Slot 0 is shared by whatever comes after the 255th stream.
+constexpr int PERSIST_WORDS = 256;
+__device__ int g_persist_timeout[PERSIST_WORDS] = {0};
 
-int *persist_timeout_word() {
-  static int *cached[64] = {nullptr};
+int *persist_timeout_word(hipStream_t stream) {
+  static std::mutex mu;
+  static int *base[64] = {nullptr};
+  static std::map<std::pair<int, hipStream_t>, int> slot_of;
+  static int next_slot[64] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  int *&p = cached[dev & 63];
+  std::lock_guard<std::mutex> lock(mu);
+  int *&p = base[dev & 63];
   if (!p) {
     void *q = nullptr;
     if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_persist_timeout)) != hipSuccess) return nullptr;
     p = static_cast<int *>(q);
   }
-  return p;
+  auto key = std::make_pair(dev, stream);
+  auto it = slot_of.find(key);
+  if (it == slot_of.end()) {
+    int &nx = next_slot[dev & 63];
+    const int slot = nx + 1 < PERSIST_WORDS ? ++nx : 0;
+    it = slot_of.emplace(key, slot).first;
+  }
+  return p + it->second;
 }
 
 static int g_persist_override = -1;
@@ -115,12 +133,12 @@ int vivit_persistent_kernels(int on) {
   return prev;
 }
 
-// *info = VIVIT_INFO_PERSIST_TIMEOUT if a persistent kernel gave up since the word was last taken (and clear it); for
+// *info = VIVIT_INFO_PERSIST_TIMEOUT if a persistent kernel ON THIS STREAM gave up since its word was last taken (and clear it); for
 // callers of the stage-level entry points (vivit_sytrd_f32, vivit_sy2sb_f32, vivit_sy2sb_panel_qr_f32, vivit_sb2st_f32),
 // which have no info word of their own.  The eigensolver entry points do this themselves.
 int vivit_take_persist_timeout(int32_t *info, void *stream) {
   if (!info) return VIVIT_E_BADARG;
-  int *word = persist_timeout_word();
+  int *word = persist_timeout_word(static_cast<hipStream_t>(stream));
   if (!word) return VIVIT_E_LAUNCH;
   take_timeout_kernel<<<1, 1, 0, static_cast<hipStream_t>(stream)>>>(info, word);
   return launch_status();

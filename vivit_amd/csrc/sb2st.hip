@@ -460,7 +460,7 @@ int sb2st_launch(float *AB, int64_t n, float *d, float *e, float *R2, int64_t ld
   // as for the other persistent kernels; a CPX partition or a CU-masked device takes the launch chain)
   const bool persist = sb2st_persist_enabled() && n >= 960 && (size_t)nk * sizeof(float) >= sizeof(Sb2stCtl) &&
                        device_cu_count() >= 256;
-  int *tmo = persist ? persist_timeout_word() : nullptr;
+  int *tmo = persist ? persist_timeout_word(stream) : nullptr;
   if (n >= 3 && persist && tmo) {
     Sb2stCtl *ctl = reinterpret_cast<Sb2stCtl *>(tau2 + (n - 1) * nk);
     sb2st_zero_kernel<<<(unsigned)cdiv(n, 256), 256, 0, stream>>>(tau2, ni, nk);

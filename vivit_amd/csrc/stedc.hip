@@ -642,7 +642,7 @@ int stebz_launch(const float *d, const float *e, int64_t n, float *w, const floa
 }
 
 int info_finalize_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream) {
-  finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word());
+  finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word(stream));
   return launch_status();
 }
 
@@ -652,7 +652,7 @@ int dc_output_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq,
   if (Z)
     dc_transpose_out_kernel<<<dim3((unsigned)cdiv(n, 32), (unsigned)cdiv(n, 32)), 256, 0, stream>>>((int)n, Qt, ldq, order,
                                                                                                   Z, ldz);
-  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word());
+  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word(stream));
   return launch_status();
 }
 
@@ -700,7 +700,7 @@ int dc_select_launch(int64_t n, const float *dcur, const float *Qt, int64_t ldq,
 }
 
 int info_scal_launch(int32_t *info, int64_t n, const float *scal, hipStream_t stream) {
-  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word());
+  if (scal) finalize_info_kernel<<<1, 64, 0, stream>>>(info, (int)n, scal, persist_timeout_word(stream));
   return launch_status();
 }
 

@@ -461,7 +461,7 @@ static bool qr_persist_launch(float *pan, int64_t mp, int ncol, void *wsp, float
   pw.ubuf = reinterpret_cast<float *>(align_up(reinterpret_cast<uintptr_t>(wsp), 256));
   pw.dbuf = pw.ubuf + 2 * QP_WG * SNB;
   pw.counter = reinterpret_cast<int *>(pw.dbuf + 2 * SNB);
-  pw.tmo = persist_timeout_word();
+  pw.tmo = persist_timeout_word(stream);
   pw.fault = persist_fault();
   if (!pw.tmo) return false;
   if (hipMemsetAsync(pw.counter, 0, 64 * sizeof(int), stream) != hipSuccess) return false;

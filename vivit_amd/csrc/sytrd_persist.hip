@@ -289,7 +289,7 @@ int sytrd_persist_launch(float *A, int64_t n, int64_t lda, const SytrdWs &ws, hi
   pw.rowbuf = ws.vw + 2 * NP;
   pw.counter = reinterpret_cast<int *>(ws.vw + 4 * NP);
   pw.xcc = pw.counter + 32;
-  pw.tmo = persist_timeout_word();
+  pw.tmo = persist_timeout_word(stream);
   pw.fault = persist_fault();
   if (!pw.tmo) return VIVIT_E_LAUNCH;
   if (4 * NP + 64 > 3 * 64 * n) return VIVIT_E_WORKSPACE;

@@ -213,6 +213,12 @@ CASES = [
     # the single-workgroup one that serves the reference's own test sizes
     dict(name="multikernel", seed=6, C=10, N=32, shapes=[(16, 24), (16,)], k=10),
 ]
+# n = C*N = 2560 > 2048: the two-stage eigensolver the headline runs (band reduction, bulge chase, divide & conquer, Q2, Q1).
+# The factors are 30 MB: only their SEED is stored (tests/helpers.py:planted_factors regenerates them in the test -- the build
+# container and the GPU box run the same torch, whose CPU generator is deterministic) together with the reference's outputs.
+BIG_CASES = [
+    dict(name="two_stage", seed=8, C=10, N=256, shapes=[(48, 60), (48,)], k=10),
+]
 
 
 def run_case(vivit, case):
@@ -352,6 +358,72 @@ def run_case(vivit, case):
     return out
 
 
+def run_big_case(vivit, case):
+    """EigvalshComputation, EighComputation (top k) and the directional derivatives / damped Newton step of the reference
+    on seeded factors that are NOT stored (see BIG_CASES)."""
+    from vivit.utils.ggn import Vmp
+    from vivit.utils.gram import mVp, pairwise_dot
+
+    sys.path.insert(0, os.path.dirname(OUT))
+    from helpers import planted_factors   # the seeded recipe the tests regenerate the factors with (data, no product code)
+
+    C, N, shapes = case["C"], case["N"], case["shapes"]
+    V, G = planted_factors(case["seed"], C, N, shapes)
+    out = {"C": C, "N": N, "N_total": N, "N_grad": N, "k": case["k"], "seed": case["seed"],
+           "shapes_flat": np.array([d for s in shapes for d in (len(s),) + tuple(s)]),
+           # fingerprints of the regenerated factors (a torch whose generator differs must fail loudly, not subtly)
+           "V_checksum": np.array([float(v.double().sum()) for v in V] + [float(v.double().abs().sum()) for v in V]),
+           "g_checksum": np.array([float(g.double().sum()) for g in G] + [float(g.double().abs().sum()) for g in G])}
+
+    def fresh_params():
+        return [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+
+    def attach_vivit(params):
+        for p, v in zip(params, V):
+            p.vivit_ggn_exact = {"gram_mat": (lambda v=v: pairwise_dot(v, start_dim=2, flatten=False)),
+                                 "V_mat_prod": (lambda m, v=v: Vmp(v, m, 2)), "V_t_mat_prod": (lambda m, v=v: mVp(v, m, 2))}
+
+    def attach_sqrt(params):
+        for p, v, g in zip(params, V, G):
+            p.sqrt_ggn_exact = v.clone()
+            p.grad_batch = g.clone()
+
+    params = fresh_params()
+    comp = vivit.EigvalshComputation()
+    attach_vivit(params)
+    groups = [{"params": params}]
+    comp.get_extension_hook(groups)(FakeModule(params, N))
+    out["eigvalsh_one_0"] = comp.get_result(groups[0]).numpy()
+
+    crit = top_k_criterion(case["k"])
+    params = fresh_params()
+    comp = vivit.EighComputation(warn_small_eigvals=0.0)
+    attach_vivit(params)
+    groups = [{"params": params, "criterion": crit}]
+    comp.get_extension_hook(groups)(FakeModule(params, N))
+    evals, evecs = comp.get_result(groups[0])
+    out["eigh_evals"] = evals.numpy()
+    for i, e in enumerate(evecs):
+        out[f"eigh_evecs{i}"] = e.numpy()
+
+    params = fresh_params()
+    comp = vivit.DirectionalDerivativesComputation(warn_small_eigvals=0.0)
+    attach_sqrt(params)
+    groups = [{"params": params, "criterion": crit}]
+    comp.get_extension_hook(groups)(FakeModule(params, N))
+    gammas, lambdas = comp.get_result(groups[0])
+    out["gammas"], out["lambdas"] = gammas.numpy(), lambdas.numpy()
+
+    params = fresh_params()
+    comp = vivit.DirectionalDampedNewtonComputation(warn_small_eigvals=0.0)
+    attach_sqrt(params)
+    groups = [{"params": params, "criterion": crit, "damping": constant_damping(1.0)}]
+    comp.get_extension_hook(groups)(FakeModule(params, N))
+    for i, s in enumerate(comp.get_result(groups[0])):
+        out[f"newton{i}"] = s.numpy()
+    return out
+
+
 def run_eig_utils(vivit):
     """vivit/utils/eig.py on the matrices of test/utils/test_stable_symeig.py:10-11 plus a PSD one."""
     from vivit.utils.eig import shift_diag, symeig, symeig_psd
@@ -381,6 +453,10 @@ def main():
         res = run_case(vivit, case)
         np.savez_compressed(os.path.join(OUT, f"{case['name']}.npz"), **res)
         print(case["name"], {k: getattr(v, "shape", v) for k, v in list(res.items())[:4]}, "...", len(res), "arrays")
+    for case in BIG_CASES:
+        res = run_big_case(vivit, case)
+        np.savez_compressed(os.path.join(OUT, f"{case['name']}.npz"), **res)
+        print(case["name"], len(res), "arrays,", sum(v.nbytes for v in res.values() if hasattr(v, "nbytes")), "bytes")
     np.savez_compressed(os.path.join(OUT, "eig_utils.npz"), **run_eig_utils(vivit))
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
 

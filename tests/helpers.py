@@ -18,7 +18,45 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
+BIG_CASES = ["two_stage"]   # factors regenerated from their seed (tests/golden/make_golden.py:BIG_CASES)
+
+
+def planted_factors(seed, C, N, shapes, planted=10):
+    """Seeded factors of the BIG cases (shared by tests/golden/make_golden.py, which records the reference's outputs on them,
+    and by the tests, which regenerate them): ``randn / sqrt(N)`` like the small cases, plus ``planted`` rank-one terms in the
+    first parameter whose Gram eigenvalues 100 * 1.5^j stand clear of the bulk edge (~ 43) and of each other -- with plain
+    noise the top eigenvalues crowd at the Marchenko-Pastur edge and fp32 eigenvectors (the reference's own LAPACK ones
+    included) are only defined to ~ eps lambda_max / gap, which would turn the vector-valued comparisons into noise."""
+    g = torch.Generator().manual_seed(seed)
+    V = [torch.randn(C, N, *s, generator=g, dtype=torch.float32) / (N ** 0.5) for s in shapes]
+    G = [torch.randn(N, *s, generator=g, dtype=torch.float32) / N for s in shapes]
+    for j in range(planted):
+        u = torch.randn(C, N, generator=g, dtype=torch.float32)
+        w = torch.randn(*shapes[0], generator=g, dtype=torch.float32)
+        amp = (100.0 * 1.5 ** j) ** 0.5
+        V[0] += amp * (u / u.norm()).reshape(C, N, *([1] * len(shapes[0]))) * (w / w.norm())
+    return V, G
+
+
+def seeded_factors(gold, device="cpu"):
+    """The factors of a fixture that stores only their seed (torch's CPU generator; the build container and the GPU box run
+    the same torch), checked against the stored fingerprints."""
+    flat = [int(x) for x in gold["shapes_flat"]]
+    shapes, i = [], 0
+    while i < len(flat):
+        shapes.append(tuple(flat[i + 1:i + 1 + flat[i]]))
+        i += 1 + flat[i]
+    V, G = planted_factors(int(gold["seed"]), int(gold["C"]), int(gold["N"]), shapes)
+    have = [float(v.double().sum()) for v in V] + [float(v.double().abs().sum()) for v in V]
+    np.testing.assert_allclose(have, gold["V_checksum"], rtol=1e-9, err_msg="this torch's CPU generator differs from the one that recorded the fixture")
+    have = [float(x.double().sum()) for x in G] + [float(x.double().abs().sum()) for x in G]
+    np.testing.assert_allclose(have, gold["g_checksum"], rtol=1e-9)
+    return [v.to(device) for v in V], [x.to(device) for x in G]
+
+
 def golden_factors(gold, device="cpu"):
+    if "seed" in gold and "V0" not in gold:
+        return seeded_factors(gold, device)
     V, G = [], []
     i = 0
     while f"V{i}" in gold:

@@ -12,6 +12,7 @@ import torch
 
 import vivit_amd
 from helpers import (
+    BIG_CASES,
     CASES,
     FakeModule,
     OracleBackend,
@@ -142,6 +143,59 @@ def test_directional_derivatives_and_newton(case, device):
         ref = g[f"newton{i}"]
         assert tuple(s.shape) == ref.shape
         close(s, ref, rtol=1e-4, atol=1e-5 * max(np.abs(ref).max(), 1e-3))  # test: 1e-5/1e-5
+
+
+@pytest.mark.parametrize("case", BIG_CASES)
+def test_two_stage_size_against_the_reference(case, device):
+    """the solver the headline runs (n > 2048: band reduction, bulge chase, divide & conquer, Q2, Q1) pinned
+    by outputs of the IMPORTED REFERENCE, not only by fp64 LAPACK: n = C N = 2560, P = 2928 (so the sample side is the smaller
+    one), ``EigvalshComputation`` (whole spectrum), ``EighComputation`` top-10, gammas / lambdas and the damped Newton step, at
+    the reference tests' tolerances (test/linalg/test_eigvalsh.py:55-60, test_eigh.py:147-153,
+    test/optim/test_directional_damped_newton.py:72).  The 30 MB of factors are regenerated from their seed."""
+    g = load_golden(case)
+    V, G = golden_factors(g, device)
+    N = int(g["N"])
+    crit = top_k_criterion(int(g["k"]))
+    assert V[0].shape[0] * N == 2560
+
+    params = fresh_params(V, device)
+    comp = vivit_amd.EigvalshComputation()
+    attach_vivit(params, V, comp._savefield)
+    groups = [{"params": params}]
+    comp.get_extension_hook(groups)(FakeModule(params, N))
+    ref = g["eigvalsh_one_0"]
+    scale = np.abs(ref).max()
+    close(comp.get_result(groups[0]), ref, rtol=1e-4, atol=1e-5 * scale)
+
+    params = fresh_params(V, device)
+    comp = vivit_amd.EighComputation(warn_small_eigvals=0.0)
+    attach_vivit(params, V, comp._savefield)
+    groups = [{"params": params, "criterion": crit}]
+    comp.get_extension_hook(groups)(FakeModule(params, N))
+    evals, evecs = comp.get_result(groups[0])
+    close(evals, g["eigh_evals"], rtol=1e-4, atol=1e-5 * scale)
+    for i, e in enumerate(evecs):
+        assert e.shape == g[f"eigh_evecs{i}"].shape
+        close(e.abs(), np.abs(g[f"eigh_evecs{i}"]), rtol=2e-2, atol=2e-3)
+
+    comp = vivit_amd.DirectionalDerivativesComputation(warn_small_eigvals=0.0)
+    params = fresh_params(V, device)
+    attach_sqrt(params, V, G, comp._savefield_ggn)
+    groups = [{"params": params, "criterion": crit}]
+    comp.get_extension_hook(groups)(FakeModule(params, N))
+    gam, lam = comp.get_result(groups[0])
+    close(gam.abs(), np.abs(g["gammas"]), rtol=1e-4, atol=1e-4 * np.abs(g["gammas"]).max())
+    close(lam, g["lambdas"], rtol=1e-4, atol=1e-5 * np.abs(g["lambdas"]).max())
+
+    comp = vivit_amd.DirectionalDampedNewtonComputation(warn_small_eigvals=0.0)
+    params = fresh_params(V, device)
+    attach_sqrt(params, V, G, comp._savefield_ggn)
+    groups = [{"params": params, "criterion": crit, "damping": constant_damping(1.0)}]
+    comp.get_extension_hook(groups)(FakeModule(params, N))
+    for i, s in enumerate(comp.get_result(groups[0])):
+        ref = g[f"newton{i}"]
+        assert tuple(s.shape) == ref.shape
+        close(s, ref, rtol=1e-4, atol=1e-5 * max(np.abs(ref).max(), 1e-3))
 
 
 @pytest.mark.parametrize("case", CASES)

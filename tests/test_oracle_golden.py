@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, constant_damping, golden_factors, load_golden, top_k_criterion
+from helpers import BIG_CASES, CASES, constant_damping, golden_factors, load_golden, top_k_criterion
 from oracle import vivit_oracle as oracle
 
 
@@ -60,6 +60,29 @@ def test_directional_and_newton(case):
     for i, s in enumerate(steps):
         ref = g[f"newton{i}"]
         close(s, ref, rtol=1e-4, atol=1e-5 * max(np.abs(ref).max(), 1e-3))
+
+
+@pytest.mark.parametrize("case", BIG_CASES)
+def test_two_stage_size_against_the_reference(case):
+    """n = 2560 (the size class of the headline's two-stage solver): the oracle against the imported reference's
+    EigvalshComputation / EighComputation top-10 / gammas, lambdas / damped Newton step on seeded factors."""
+    g = load_golden(case)
+    V, G = golden_factors(g)
+    N = int(g["N"])
+    crit = top_k_criterion(int(g["k"]))
+    grams = [oracle.pairwise_dot(v, 2, False) for v in V]
+    ref = g["eigvalsh_one_0"]
+    scale = np.abs(ref).max()
+    close(oracle.eigvalsh_group(grams, N, None), ref, rtol=1e-4, atol=1e-5 * scale)
+    evals, evecs = oracle.eigh_group(grams, [lambda m, v=v: oracle.Vmp(v, m, 2) for v in V], crit, N, None)
+    close(evals, g["eigh_evals"], rtol=1e-4, atol=1e-5 * scale)
+    for i, e in enumerate(evecs):
+        close(e.abs(), np.abs(g[f"eigh_evecs{i}"]), rtol=2e-2, atol=2e-3)
+    gam, lam = oracle.directional_derivatives_group(V, G, crit, N)
+    close(gam.abs(), np.abs(g["gammas"]), rtol=1e-4, atol=1e-4 * np.abs(g["gammas"]).max())
+    close(lam, g["lambdas"], rtol=1e-4, atol=1e-5 * np.abs(g["lambdas"]).max())
+    for i, s in enumerate(oracle.damped_newton_group(V, G, crit, constant_damping(1.0), N)):
+        close(s, g[f"newton{i}"], rtol=1e-4, atol=1e-5 * max(np.abs(g[f"newton{i}"]).max(), 1e-3))
 
 
 def test_eig_utils():

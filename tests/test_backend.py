@@ -233,7 +233,7 @@ def test_two_backward_passes_in_one_block_with_input_requiring_grad(device):
 @pytest.mark.gpu
 def test_config4_resnet32_never_calls_autograd_grad(monkeypatch):
     """BASELINE config 4's model (ResNet-32, CIFAR-100-shaped, MC mc = 1; batch 8 here): inside the ``backpack`` block no layer
-    rule may ride ``torch.autograd.grad`` / ``vmap`` / ``einsum`` -- the shortcut ``ActiveIdentity`` of 12 of its 15 blocks did
+    rule may ride ``torch.autograd.grad`` / ``vmap`` / ``einsum`` -- the shortcut ``ActiveIdentity`` of 13 of its 15 blocks did
     until round 6 (reference map: vivit/extensions/secondorder/vivit/__init__.py:84-118).  The factors are
     then checked through the property the reference's own test uses (test_vivit_ggn.py:22-76): ``V V^T v = G v`` with the
     GGN-vector product of plain autograd on the same MC samples."""
@@ -247,7 +247,7 @@ def test_config4_resnet32_never_calls_autograd_grad(monkeypatch):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = bench_configs.resnet32(100).to(dev)
-    assert sum(type(m).__name__ == "ActiveIdentity" for m in model.modules()) == 12
+    assert sum(type(m).__name__ == "ActiveIdentity" for m in model.modules()) == 13   # 5 + 4 + 4 identity shortcuts of the 15 blocks
     N, C = 8, 100
     X, y = torch.rand(N, 3, 32, 32, device=dev), torch.randint(0, C, (N,), device=dev)
     with torch.no_grad():

@@ -79,6 +79,17 @@ WORKLOADS = {
 }
 
 
+# the committed rocprofv3 outputs behind roofline.traffic / clock_ghz / clock_note (separate --pmc passes + kernel trace of the same command)
+PMC_FILES = {
+    "traffic": ["profiles/r05_pmc/pmc_syrk_FETCH_SIZE_counter_collection.csv", "profiles/r05_pmc/pmc_syrk_WRITE_SIZE_counter_collection.csv",
+                "profiles/r05_pmc/pmc_syrk_FETCH_SIZE_kernel_trace.csv", "profiles/r05_pmc/pmc_syrk_WRITE_SIZE_kernel_trace.csv"],
+    "clock_and_pipe_busy_randn": ["profiles/r05_pmc/pmc_syrk_mfma_counter_collection.csv", "profiles/r05_pmc/pmc_syrk_mfma_kernel_trace.csv"],
+    "clock_and_pipe_busy_bench_factor": ["profiles/r05_pmc/pmc_syrk_mfma_bench_counter_collection.csv", "profiles/r05_pmc/pmc_syrk_mfma_bench_kernel_trace.csv"],
+    "command": "scripts/r05_measure.sh (rocprofv3 --pmc <counter> --kernel-trace -- python3 scripts/pmc_syrk_full.py [bench])",
+    "kernel_trace_of_the_bench": "profiles/r05_bench_n40960_v7_kernel_stats.csv",
+}
+
+
 def mlp_sqrt_ggn_factors(dims, batch, device, shard=(0, 1), seed=0, samples=None):
     """Materialised exact sqrt-GGN factors of Sequential(Linear, ReLU, Linear) + CrossEntropy(mean).
 
@@ -267,8 +278,11 @@ def _cpu_model():
     return "unknown"
 
 
+_T0 = time.perf_counter()
+
+
 def _progress(msg):
-    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def _median_time(fn, repeats=3, warm=True):
@@ -316,8 +330,8 @@ def _tune_threads(dims=(784, 512, 10), C=10, gram_batch=256, eig_n=5120):
         _progress(f"cpu baseline: thread probe {c} threads: einsum Gram (n={C * gram_batch}) {tg:.2f} s, eigh (n={eig_n}) {te:.2f} s")
         if t < best_t * 0.97:  # prefer fewer threads unless clearly faster
             best, best_t = c, t
-        elif t > best_t * 1.3:
-            break              # oversubscribed: do not try even more threads
+        elif t > best_t * 1.1:
+            break              # more threads are slower on this share of the box: do not try even more (bounds the leg's run time)
     torch.set_num_threads(best)
     return best, {"affinity": affinity, "cpu_count": os.cpu_count(), "probe": table}
 
@@ -366,8 +380,20 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256, 512), eig_batches=(
         t_fact = _median_time(fact_gram_fn(mlp_factorised_factors(dims, b, cpu)), repeats)
         _progress(f"cpu baseline: batch {b} (n={n}) einsum Gram {t_gram:.2f} s, factorised Gram {t_fact:.3f} s")
         gram_rows.append({"batch": b, "n": n, "gram_materialised_s": t_gram, "gram_factorised_s": t_fact, "repeats": 1 if last else repeats})
+    fact_rows = []
     for bi, b in enumerate(eig_batches):
-        gram = fact_gram_fn(mlp_factorised_factors(dims, b, cpu))()
+        # the eigh input IS the factorised Gram: time its construction here as well -- the factorised line is then fitted through
+        # n = 5120 / 10 240 / 20 480, all out of cache like the full size (the small sizes above run in L2/L3: their times jump
+        # 20x from n = 2560 to 5120 and no single exponent fits them -- fit residual 1.6 in round 5)
+        fg = fact_gram_fn(mlp_factorised_factors(dims, b, cpu))
+        t0 = time.perf_counter()
+        gram = fg()
+        t_fg = time.perf_counter() - t0
+        if bi == 0:   # first call of the leg at this size: once more, warm
+            t0 = time.perf_counter()
+            gram = fg()
+            t_fg = time.perf_counter() - t0
+        fact_rows.append({"batch": b, "n": gram.shape[0], "gram_factorised_s": t_fg, "repeats": 1})
         n = gram.shape[0]
         last = bi == len(eig_batches) - 1 and len(eig_batches) > 2
         reps = 1 if (last or (bi == len(eig_batches) - 2 and len(eig_batches) > 2)) else repeats
@@ -395,7 +421,7 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256, 512), eig_batches=(
         return math.exp(yl + e * (math.log(full_n) - xl)), e, resid
 
     tg, eg, rg = extrap(gram_rows, "gram_materialised_s", 2.0)
-    tf, ef, rf = extrap(gram_rows, "gram_factorised_s", 2.0)
+    tf, ef, rf = extrap(fact_rows if len(fact_rows) >= 2 else gram_rows, "gram_factorised_s", 2.0)
     te, ee, re_ = extrap(eig_rows, "eigh_s", 3.0)
     tv, ev_, rv = extrap(eig_rows, "eigvalsh_s", 3.0)
     value = full_n / (tg + te)
@@ -406,9 +432,9 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256, 512), eig_batches=(
         "kind": "port",
         "cpu_model": _cpu_model(),
         "thread_probe_s": table,
-        "samples": {"gram": gram_rows, "eigh": eig_rows},
+        "samples": {"gram": gram_rows, "eigh": eig_rows, "gram_factorised_large": fact_rows},
         "fitted_exponents": {"gram_materialised": eg, "gram_factorised": ef, "eigh": ee, "eigvalsh": ev_},
-        "fit_points": {"gram": len(gram_rows), "eigh": len(eig_rows)},
+        "fit_points": {"gram": len(gram_rows), "eigh": len(eig_rows), "gram_factorised": len(fact_rows) if len(fact_rows) >= 2 else len(gram_rows)},
         "fit_worst_log_residual": {"gram_materialised": rg, "gram_factorised": rf, "eigh": re_, "eigvalsh": rv},
         "extrapolated_s": {"gram_materialised": tg, "gram_factorised": tf, "eigh": te, "eigvalsh": tv},
         "materialised_eigenpairs_per_s": value,
@@ -476,6 +502,12 @@ def _watch_ranks(procs, poll_s=0.5, grace_s=20.0):
     return 0
 
 
+PANEL_EXCHANGE_US = 2.04        # one-XCD barrier + exchange (profiles/r03_grid_barrier_probe.log, mode 2)
+PANEL_LOCAL_LAUNCHES = 15       # dependent small launches per panel besides the QR (profiles/r05_bench_n40960_v7_kernel_stats.csv)
+DEPENDENT_LAUNCH_US = 3.0       # empty dependent kernel boundary (scripts/probe/launch_rate.hip: 3.0-3.3 us)
+VALU_F64_PEAK_TF = 78.6         # fp64 vector peak (MI355X_MICROARCH.md: 256 CUs x 128 flop/clk x 2.4 GHz)
+
+
 def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
     """Per-stage roofline of the eigensolver from the library's stage marks (ms summed over the timed steps).
     Algorithmic work per stage: band reduction (4/3) n^3 flop on MFMA; bulge chasing: n^2/(2 nb)
@@ -495,12 +527,21 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
     n3 = float(n) ** 3
     work = {
         1: ("hbm", 4.0 * n * n * 1.5, "B"),
-        2: (None, None, None),   # launch chains and 64-wide products: seconds only
+        # A LATENCY model, not a throughput one: the panel QR is a chain of 64 column steps per panel, each ending in an exchange
+        # between the 32 workgroups of one XCD (2.04 us measured for barrier + exchange on one XCD: profiles/r03_grid_barrier_probe.log,
+        # mode 2); around it a panel costs PANEL_LOCAL_LAUNCHES dependent small launches (T factor, coefficient products on 64-wide
+        # operands, load / store of the panel; count from profiles/r05_bench_n40960_v7_kernel_stats.csv) at 3.0 us per dependent
+        # kernel boundary (scripts/probe/launch_rate.hip).  No look-ahead can shorten the chain: in a TWO-sided reduction panel
+        # p + 1's columns need W_p, i.e. the complete streaming product A22 V_p (stage 9) of panel p.
+        2: ("latency", (n / nb - 1) * (nb * PANEL_EXCHANGE_US + PANEL_LOCAL_LAUNCHES * DEPENDENT_LAUNCH_US) * 1e-6, "s"),
         # every panel reads its trailing matrix once: 4 B x sum_p m_p^2 = n^3 / 48 bytes, 2 x 64 flop per element
         9: ("hbm", n3 / 48.0, "B") if g64_bf16 else ("mfma", 2.0 / 3.0 * n3, "flop"),
         10: ("mfma", 2.0 / 3.0 * n3, "flop"),
         3: ("hbm", (n * n / (2.0 * nb)) * 4 * nb * nb * 4.0, "B"),
-        4: (None, None, None),  # spectrum dependent (deflation): seconds only
+        # divide & conquer: the merges' cost depends on deflation (spectrum); what ANY with-vectors tridiagonal solver must move is
+        # the n x n eigenvector matrix, written once and read once by the final rank permutation: the floor stated here.  Values
+        # only (Sturm multisection): n eigenvalues x 9 rounds x 8 shifts x n recurrence steps of ~6 fp64 operations on the vector pipe
+        4: ("hbm", 8.0 * n * n, "B") if vectors else ("valu64", 9.0 * 8.0 * 6.0 * n * n, "flop"),
         5: ("mfma", 2.0 * n3 * row_frac, "flop"),   # back-transformations: only this rank's eigenvector rows
         6: ("mfma", 2.0 * n3 * row_frac, "flop"),
         7: ("hbm", 8.0 * n * n, "B"),
@@ -516,7 +557,17 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
         if bound is None:
             out.append(row)
             continue
-        if bound == "mfma":
+        if k == 4:
+            row["note"] = ("floor of any with-vectors tridiagonal solver (write Z once, read it once for the final permutation); the merges' own "
+                           "traffic depends on deflation" if vectors else "Sturm multisection, fp64 recurrences on the vector pipe")
+        if bound == "latency":
+            row.update({"model_seconds": amount, "frac": amount / sec, "unit": "s",
+                        "model": f"(n/64 - 1) panels x (64 exchanges x {PANEL_EXCHANGE_US} us + {PANEL_LOCAL_LAUNCHES} dependent launches x "
+                                 f"{DEPENDENT_LAUNCH_US} us); frac = model / measured"})
+        elif bound == "valu64":
+            ach = amount / sec / 1e12
+            row.update({"flops": amount, "achieved": ach, "peak": VALU_F64_PEAK_TF, "unit": "TFLOP/s", "frac": ach / VALU_F64_PEAK_TF})
+        elif bound == "mfma":
             ach = amount / sec / 1e12
             # each stage against the pipe it runs on: Q1's products, the band reduction's trailing updates and the
             # sliding-window Q2 kernel form fp32 products from exact bf16 splits (roofline = bf16 peak / split); the band
@@ -693,6 +744,12 @@ def main():
 
     def phase(a, b):
         return sum(ev[args.warmup + i][a].elapsed_time(ev[args.warmup + i][b]) for i in range(args.steps)) / 1e3 / args.steps
+
+    # run-to-run spread of THIS rank's steps (device time between the first and last event of each timed step): lets a reader
+    # tell box-to-box differences (+- 2 % between leases) from noise inside one run
+    per_step = sorted(ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][4]) for i in range(args.steps))
+    step_spread = {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1], "n": len(per_step),
+                   "clock": "HIP events around each step on the launch stream (rank 0)"}
 
     if world == 1:
         exch_s, gram_s, ar_s = 0.0, phase(0, 1), 0.0
@@ -887,6 +944,7 @@ def main():
                                   "measured in this run: in-kernel stamps of a diagnostic build on the bench's own factors and on N(0,1) data "
                                   "(profiles/r03_pmc/v3_bx_clock_*.txt, round-3 box), GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of a PMC pass over the 98 "
                                   "launches of the first-layer SYRK on N(0,1) data and on the bench's own factor (profiles/r05_pmc/pmc_syrk_mfma_*, round-5 boxes)",
+                    "pmc_files": PMC_FILES if split == 6 else None,
                     "bare_loop_ceiling": BX_BARE_LOOP_CEILING if split == 6 else None,
                     "frac_of_bare_loop_on_like_data": (achieved / BX_BARE_LOOP_CEILING["half_zeros_like_the_bench_factors"]["tflops_fp32_equiv"])
                     if split == 6 else None,
@@ -917,6 +975,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_spread": step_spread,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

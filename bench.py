@@ -311,7 +311,8 @@ def _tune_threads(dims=(784, 512, 10), C=10, gram_batch=256, eig_n=5120):
         affinity = ncpu
     ncpu = min(ncpu, affinity)
     _progress(f"cpu baseline: os.cpu_count() = {os.cpu_count()}, len(os.sched_getaffinity(0)) = {affinity}")
-    cands = [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]
+    # (on a many-core host the 8-thread candidate has lost every probe so far and costs 15 s of the leg: start at 16 there)
+    cands = [c for c in ((16, 32, 64, 128) if ncpu >= 64 else (8, 16, 32, 64, 128)) if c <= ncpu] or [ncpu]
     if ncpu not in cands and ncpu < 128:
         cands.append(ncpu)
     facs = mlp_sqrt_ggn_factors(dims, gram_batch, torch.device("cpu"))
@@ -375,11 +376,12 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256, 512), eig_batches=(
         # (the warm-up run is only needed once per process: thread pool, allocator; the LARGEST size of each phase is run once
         # -- it is the expensive sample and the least noisy one)
         last = bi == len(batches) - 1 and len(batches) > 2
-        t_gram = _median_time(lambda: oracle.compute_gram_mat(V, start_dim=2, flatten=True), 1 if last else repeats, warm=bi == 0)
+        g_reps = 1 if last else (repeats if bi == 0 else max(2, repeats - 1))   # (seconds per run from the second size on: two runs)
+        t_gram = _median_time(lambda: oracle.compute_gram_mat(V, start_dim=2, flatten=True), g_reps, warm=bi == 0)
         del V, facs
         t_fact = _median_time(fact_gram_fn(mlp_factorised_factors(dims, b, cpu)), repeats)
         _progress(f"cpu baseline: batch {b} (n={n}) einsum Gram {t_gram:.2f} s, factorised Gram {t_fact:.3f} s")
-        gram_rows.append({"batch": b, "n": n, "gram_materialised_s": t_gram, "gram_factorised_s": t_fact, "repeats": 1 if last else repeats})
+        gram_rows.append({"batch": b, "n": n, "gram_materialised_s": t_gram, "gram_factorised_s": t_fact, "repeats": g_reps})
     fact_rows = []
     for bi, b in enumerate(eig_batches):
         # the eigh input IS the factorised Gram: time its construction here as well -- the factorised line is then fitted through

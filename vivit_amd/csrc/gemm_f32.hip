@@ -961,7 +961,24 @@ __device__ unsigned long long *g_bx_stamp = nullptr;
 __device__ unsigned int g_bx_stamp_cap = 0;
 #endif
 
-template <int NPROD>
+#include "bx_kloop_asm.inc"
+#if defined(BX_ASM_VARIANT) && BX_ASM_VARIANT == 1
+#define BX_KLOOP_TEXT BX_KLOOP_ASM_V1_TEXT
+#elif defined(BX_ASM_VARIANT) && BX_ASM_VARIANT == 2
+#define BX_KLOOP_TEXT BX_KLOOP_ASM_V2_TEXT
+#elif defined(BX_ASM_VARIANT) && BX_ASM_VARIANT == 3
+#define BX_KLOOP_TEXT BX_KLOOP_ASM_V3_TEXT
+#elif defined(BX_ASM_VARIANT) && BX_ASM_VARIANT == 4
+#define BX_KLOOP_TEXT BX_KLOOP_ASM_V4_TEXT
+#else
+#define BX_KLOOP_TEXT BX_KLOOP_ASM_TEXT
+#endif
+
+// ASM: the steady part of the K loop runs as ONE hand-scheduled inline-asm block (bx_kloop_asm.inc, generated by
+// scripts/gen_bx_kloop.py: fixed register map, every memory instruction placed between the MFMAs by hand); prologue, the last
+// two tiles of a pass, the chain flushes and the epilogues stay the C++ below, which is also the reference implementation
+// (ASM = false, VIVIT_BX_ASM=0).  Same partial products in the same order per accumulator: bit-identical results.
+template <int NPROD, bool ASM = false>
 __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
 #if defined(BX_STAMP) && BX_STAMP == 2   // timeline build (scripts/probe/bx_timeline.py): 8 words per workgroup
@@ -1283,7 +1300,17 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       // and 3 234.1 / 259.4 against 238.3 / 263.6 on that box.  The requests then have rows 0 and 1 of the next tile (48 MFMAs,
       // ~0.9 us) + what is left of row 3 to land before the mid-tile wait.
       const bool req = t + 2 < t1;
+#if defined(BX_STAGGER)   // experiment (round 6): the waves of a workgroup issue their requests in DIFFERENT rows, so that at most two of
+      // them load the CU's one address unit at a time.  1: odd waves row 2, even waves row 3;  2: waves 0, 1 row 2, waves 2, 3 row 3
+      const int wsel = __builtin_amdgcn_readfirstlane(BX_STAGGER == 1 ? (wave & 1) : (wave < 2));
+      mfma_row(J2{}, fa2, fb, [&](int j) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (req && wsel) issue_part(st2, j);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#else
       mfma_row(J2{}, fa2, fb, nothing);
+#endif
       // first fragments of tile t + 1: the B pieces of column tile j behind the MFMAs of column tile j - 1 of row 3
       {
         const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
@@ -1291,7 +1318,11 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
           __builtin_amdgcn_sched_barrier(0);
+#if defined(BX_STAGGER)
+          if (req && !wsel) issue_part(st2, j);
+#else
           if (req) issue_part(st2, j);
+#endif
           __builtin_amdgcn_sched_barrier(0);
         });
       }
@@ -1301,6 +1332,32 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     };
     while (true) {
       const int tc = next_flush < t1 ? next_flush : t1;
+      if constexpr (ASM && NPROD == 6) {
+        // every tile of the asm block requests tile t + 2: it runs up to the last two tiles of the pass, on an even number of
+        // tiles (the chain ends of this loop stay where they are)
+        int na = ((tc < t1 - 2 ? tc : t1 - 2) - t) & ~1;
+        if (na > 0) {
+          const unsigned fa_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx + fofsA;
+          const unsigned fb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx + BX_OPER + fofsB;
+          const int64_t strideA_b = 2 * p.strideA, strideB_b = 2 * p.strideB, stepA_b = 2 * stepA, stepB_b = 2 * stepB;
+          __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the fragment sets of the C++ loop are not carried into the block)
+          __asm__ volatile(BX_KLOOP_TEXT
+                           : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
+                             "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),
+                             "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])
+                           : "v"(fa_lds), "v"(fb_lds), "v"(srcA[0]), "v"(srcA[1]), "v"(srcB[0]), "v"(srcB[1]), "s"(strideA_b), "s"(strideB_b),
+                             "s"(stepA_b), "s"(stepB_b), "s"(lds0), "s"(st), "s"(na)
+                           : BX_KLOOP_ASM_CLOBBERS);
+          // the block leaves the request pointers na tiles further and the stage of the new tile t: redo both here (cheap,
+          // and the operands above stay plain inputs -- 16 read-write accumulator operands already count twice)
+          srcA[0] += (int64_t)na * stepA; srcA[1] += (int64_t)na * stepA;
+          srcB[0] += (int64_t)na * stepB; srcB[1] += (int64_t)na * stepB;
+          st = (st + na) % 3;
+          t += na;
+          fbX = load_b(st);
+          faX = load_a(st, 0);
+        }
+      }
       while (t + 2 <= tc) {  // two tiles per trip, no exit in between (the sets swap roles and are back in place)
         tile(fbX, faX, fbY, faY);
         tile(fbY, faY, fbX, faX);
@@ -2251,6 +2308,19 @@ struct BxStrictScope {
   ~BxStrictScope() { tls_bx_gate_mask = saved; }
 };
 
+#ifndef BX_ASM_DEFAULT
+#define BX_ASM_DEFAULT 0
+#endif
+// VIVIT_BX_ASM=1 / 0: the hand-scheduled K loop (gemm256_bx_kernel<6, true>) or the C++ loop (the reference implementation)
+static bool bx_asm_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char *e = getenv("VIVIT_BX_ASM");
+    on = e ? (atoi(e) != 0) : BX_ASM_DEFAULT;
+  }
+  return on != 0;
+}
+
 static bool gemm256_attrs() {
   static unsigned long long attr_done = 0;
   {
@@ -2263,8 +2333,8 @@ static bool gemm256_attrs() {
                             reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_M>)};
       for (const void *f : fns)
         if (!ensure_dynamic_lds(f, GEMM256_LDS_BYTES, attr_done)) return false;
-      const void *bx[3] = {reinterpret_cast<const void *>(gemm256_bx_kernel<3>), reinterpret_cast<const void *>(gemm256_bx_kernel<6>),
-                           reinterpret_cast<const void *>(gemm256_bx_kernel<9>)};
+      const void *bx[4] = {reinterpret_cast<const void *>(gemm256_bx_kernel<3>), reinterpret_cast<const void *>(gemm256_bx_kernel<6>),
+                           reinterpret_cast<const void *>(gemm256_bx_kernel<9>), reinterpret_cast<const void *>(gemm256_bx_kernel<6, true>)};
       for (const void *f : bx)
         if (!ensure_dynamic_lds(f, GEMM256BX_LDS_BYTES, attr_done)) return false;
       attr_done |= 1ull << (dev & 63);
@@ -2361,8 +2431,13 @@ static int gemm256_launch(int alay, int blay, GemmArgs p, bool syrk, void *works
       q.syrk = (p.syrk == 1 && k0 + kc < p.K) ? 2 : p.syrk;
       q.gate = flag;
       q.sync = sync ? sync + chunk * (int64_t)sync_ints : nullptr;
-      if (bx == 6)
-        gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+      if (bx == 6 && bx_asm_enabled())
+        gemm256_bx_kernel<6, true><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+      else if (bx == 6)
+        if (bx_asm_enabled())
+    gemm256_bx_kernel<6, true><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+  else
+    gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
       else if (bx == 9)
         gemm256_bx_kernel<9><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
       else
@@ -2488,7 +2563,10 @@ static int bx_splitk_launch(int alay, int blay, const GemmArgs &p, bool syrk, vo
   const int64_t sbm = cdiv(q.tiles_m, sbh), sbn = cdiv(q.tiles_n, sbw);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
   const dim3 grid((unsigned)(nsb * 256), (unsigned)nsplit);
-  gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+  if (bx_asm_enabled())
+    gemm256_bx_kernel<6, true><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+  else
+    gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
   int st = launch_status();
   if (st != VIVIT_OK) return st;
   {  // BX_GATE: the fp32 MFMA kernel with the same K split and slab; returns at once unless the operand is flagged

@@ -1,65 +1,129 @@
 #!/usr/bin/env python3
-"""Generator of the hand-scheduled K loop of gemm256_bx_kernel<6> (vivit_amd/csrc/gemm_f32.hip) as ONE inline-asm block.
+"""Generator of the hand-scheduled K loop of gemm256_bx_kernel<6, ASM, NW> (vivit_amd/csrc/gemm_f32.hip) as inline-asm blocks.
 
     python scripts/gen_bx_kloop.py            # writes vivit_amd/csrc/bx_kloop_asm.inc (committed: the build never runs this)
 
-VERDICT r03-r05 asked for the loop body in assembly: fixed register map, the twelve global -> LDS requests of a K tile
-placed by hand between the MFMAs.  The block runs `ntiles` K tiles (16 k each) of the pipeline the C++ loop runs
-(gemm_f32.hip, "Pipeline (tile t lives in stage t % 3)") and is entered / left in that loop's invariant:
+VERDICT r03-r05 asked for the loop body in assembly: fixed register map, the global -> LDS requests of a K tile placed by
+hand between the MFMAs.  A block runs `ntiles` K tiles (16 k each) of the pipeline the C++ loop runs (gemm_f32.hip,
+"Pipeline (tile t lives in stage t % 3)") and is entered / left in that loop's invariant:
 
     entry: tile t has landed in stage st and is published (every wave is past the barrier that followed its wait), the
            requests of tile t + 1 are in flight, nothing of tile t is in registers;
-    exit : the same for t + ntiles; the 16 accumulator tiles are updated (st and the request pointers are inputs: the caller
+    exit : the same for t + ntiles; the accumulator tiles are updated (st and the request pointers are inputs: the caller
            advances its copies by ntiles).
 
 Arithmetic contract (bit-identical to the C++ loop): every accumulator tile (i, j) sees, per K tile, the six partial
 products in the order (lo hi), (hi lo), (mid mid), (mid hi), (hi mid), (hi hi) of (A piece, B piece) -- mfma_row<6> --
 and the K tiles in ascending order.  Only the order BETWEEN accumulators and the placement of memory instructions differ.
 
-One K tile per trip (the C++ loop needs two: its fragment sets ping-pong by name).  Per wave and K tile:
-    96 v_mfma_f32_32x32x16_bf16, 27 ds_read_b128 (12 B fragments, 12 A fragments, 3 of the next tile's first row),
-    12 global_load_lds_dwordx4 + 12 v_lshl_add_u64 (request pointers), one s_waitcnt vmcnt(0) + s_barrier in the middle.
-Rows 0-2 walk the four column tiles round-robin per product; row 3 walks column by column so that the B fragments of column
-j are dead behind its six MFMAs and the NEXT tile's B fragments of column j can take their registers.  The A fragments of
-the rows alternate between two register sets (row 0, 2: X; row 1, 3: Y; the next tile's row 0: X).
+Two geometries of the 256 x 256 x 16 workgroup tile:
+    NW = 4  four waves of 128 x 128 (4 x 4 accumulator tiles of 32 x 32, one wave per SIMD, 512 registers): per wave and K tile
+            96 MFMAs, 27 ds_read_b128, 12 global_load_lds_dwordx4;
+    NW = 8  eight waves of 128 x 64 (4 x 2 accumulator tiles, TWO waves per SIMD, 256 registers): per wave and K tile 48 MFMAs,
+            21 ds_read_b128, 6 requests.  The point of the second wave: a global -> LDS request holds its wave's issue for
+            ~60 cycles (MI355X_MICROARCH.md, LDS-DMA piece issue cost) -- with one wave per SIMD the matrix pipe idles for
+            what exceeds an MFMA's 24 free issue cycles (12 x 36 cycles per K tile = 12 % of it); with two the partner's MFMAs
+            run underneath.  The two wave groups (waves 0-3 / 4-7: one of each per SIMD) issue their requests in DIFFERENT rows.
+One K tile per trip.  Rows 0-2 walk the column tiles round-robin per product; row 3 walks column by column so that the B
+fragments of column j are dead behind its six MFMAs and the NEXT tile's B fragments of column j take their registers.  The A
+fragments of the rows alternate between two register sets (rows 0, 2: X; rows 1, 3: Y; the next tile's row 0: X).
 
-Register map (VGPRs named as clobbers, so hipcc keeps its own values out of them):
-    B fragments  v[128:175]   B(j, pc) = v[128 + 4 (3 j + pc) ..+3]
-    A set X      v[176:187]   A(pc)    = v[176 + 4 pc ..+3]        A set Y  v[188:199]
-    request pointers (64 bit, one per (operand, block u, piece pc)): v[200:223]
-    v224 / v225 / v226: LDS addresses of this lane's A fragments (tile t), B fragments (tile t + 1), A fragments (tile t + 1)
-    s[84:95]: stage offsets, request base, loop counter
+Register map (VGPRs / SGPRs named as clobbers, so hipcc keeps its own values out of them); base V0 = 128 (NW = 4) / 64 (NW = 8):
+    B fragments  v[V0 ..]           B(j, pc): 4 registers each, 3 NJ fragments
+    A sets X, Y  12 registers each
+    request pointers (64 bit, one per (operand, block u, piece pc))
+    three LDS addresses: this lane's A fragments (tile t), B fragments (tile t + 1), A fragments (tile t + 1)
+    s[84:89]: stage offsets (tiles t, t + 1, t + 2), request base, loop counter, scratch
 """
 import os
-import sys
 
 BX_PIECE = 8 * 1024
 BX_OPER = 3 * BX_PIECE
 BX_STAGE = 2 * BX_OPER
 
 PRODUCTS = [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]   # (A piece, B piece): mfma_row<6>, smallest partial products first
-
-# operand numbers of the asm statement (see the wrapper this script writes)
-ACC = lambda i, j: f"%{4 * i + j}"
-FOFS_A, FOFS_B = "%16", "%17"
-SRC = {("A", 0): "%18", ("A", 1): "%19", ("B", 0): "%20", ("B", 1): "%21"}
-STRIDE = {"A": "%22", "B": "%23"}
-STEP = {"A": "%24", "B": "%25"}
-LDS0, ST, NT = "%26", "%27", "%28"
-
-VB = lambda j, pc: f"v[{128 + 4 * (3 * j + pc)}:{128 + 4 * (3 * j + pc) + 3}]"
-VA = lambda s, pc: f"v[{(176 if s == 0 else 188) + 4 * pc}:{(176 if s == 0 else 188) + 4 * pc + 3}]"
-
-
-def pair(op, u, pc):
-    k = 200 + 2 * ((0 if op == "A" else 6) + 3 * u + pc)
-    return f"v[{k}:{k + 1}]"
-
-
-V_AA, V_BN, V_AN = "v224", "v225", "v226"
 S_CUR, S_NXT, S_NN, S_DMA, S_CNT, S_TMP = "s84", "s85", "s86", "s87", "s88", "s89"
-CLOBBER_V = list(range(128, 227))
 CLOBBER_S = list(range(84, 90))
+# addr = "saddr": the twelve request streams as SGPR base pairs s[40:63] + ONE per-lane 32-bit offset (global_load_lds v, s[..]);
+# steps in s[64:67]
+SADDR_BASE, SADDR_STEP = 40, 64
+CLOBBER_S_SADDR = list(range(40, 68))
+
+
+class Geometry:
+    def __init__(self, nw):
+        assert nw in (4, 8)
+        self.nw = nw
+        self.nj = 4 if nw == 4 else 2          # column tiles per wave
+        self.nu = 8 // nw                      # 1 KB blocks per wave, piece and operand
+        self.nacc = 4 * self.nj
+        self.nmfma = 6 * self.nacc
+        self.row = 6 * self.nj                 # MFMAs per row of accumulator tiles
+        v0 = 128 if nw == 4 else 64
+        self.vb0 = v0
+        self.vax = v0 + 12 * self.nj
+        self.vay = self.vax + 12
+        self.vp0 = self.vay + 12
+        self.npair = 2 * self.nu * 3
+        self.vaddr = self.vp0 + 2 * self.npair
+        self.clobber_v = list(range(v0, self.vaddr + 4))
+        # operand numbers of the asm statement (the C++ side passes them in this order)
+        k = self.nacc
+        self.fofs_a, self.fofs_b = f"%{k}", f"%{k + 1}"
+        k += 2
+        self.src = {}
+        for op in "AB":
+            for u in range(self.nu):
+                self.src[(op, u)] = f"%{k}"
+                k += 1
+        self.stride = {"A": f"%{k}", "B": f"%{k + 1}"}
+        self.step = {"A": f"%{k + 2}", "B": f"%{k + 3}"}
+        self.lds0, self.st, self.nt, self.grp = f"%{k + 4}", f"%{k + 5}", f"%{k + 6}", f"%{k + 7}"
+        self.noperands = k + 8
+
+    def acc(self, i, j):
+        return f"%{self.nj * i + j}"
+
+    def vb(self, j, pc):
+        k = self.vb0 + 4 * (3 * j + pc)
+        return f"v[{k}:{k + 3}]"
+
+    def va(self, s, pc):
+        k = (self.vax if s == 0 else self.vay) + 4 * pc
+        return f"v[{k}:{k + 3}]"
+
+    def pair(self, op, u, pc):
+        k = self.vp0 + 2 * ((0 if op == "A" else 3 * self.nu) + 3 * u + pc)
+        return f"v[{k}:{k + 1}]"
+
+    @property
+    def v_aa(self):
+        return f"v{self.vaddr}"
+
+    @property
+    def v_bn(self):
+        return f"v{self.vaddr + 1}"
+
+    @property
+    def v_an(self):
+        return f"v{self.vaddr + 2}"
+
+    @property
+    def v_off(self):
+        return f"v{self.vaddr + 3}"
+
+    def sbase(self, op, u, pc):
+        k = SADDR_BASE + 2 * ((0 if op == "A" else 3 * self.nu) + 3 * u + pc)
+        return k
+
+    def requests(self):
+        """The requests of one K tile in the C++ order: part q = (block u = q / 2, operand q % 2), three pieces each."""
+        out = []
+        for q in range(2 * self.nu):
+            u, op = q >> 1, "AB"[q & 1]
+            for pc in range(3):
+                out.append((op, u, pc))
+        return out
 
 
 class Emitter:
@@ -84,108 +148,92 @@ class Emitter:
         del self.lgkm[: max(idx) + 1]
 
 
-def requests():
-    """The 12 requests of one K tile in the C++ order: part q = (block u = q / 2, operand q % 2), three pieces each."""
-    out = []
-    for q in range(4):
-        u, op = q >> 1, "AB"[q & 1]
-        for pc in range(3):
-            out.append((op, u, pc))
-    return out
-
-
-def gen(req_gaps=None, setprio=False, nop_m0=True):
-    """`req_gaps`: for each of the 12 requests the MFMA slot (0..96) BEFORE which it is issued (>= 48: behind the barrier)."""
-    if req_gaps is None:
-        # the C++ placement: three per column tile of row 3 (behind the fragment reads of the column) -- slots 78, 84, 90, 96
-        req_gaps = [78] * 3 + [84] * 3 + [90] * 3 + [96] * 3
-    reqs = requests()
-    e = Emitter()
-    e.raw("; ---- entry: stage offsets of tiles t, t + 1, t + 2 from st; request pointers of the 12 (operand, block, piece) streams")
-    e.raw(f"s_mul_i32 {S_CUR}, {ST}, {BX_STAGE}")
-    e.raw(f"s_add_u32 {S_NXT}, {S_CUR}, {BX_STAGE}")
-    e.raw(f"s_cmp_eq_u32 {ST}, 2")
-    e.raw(f"s_cselect_b32 {S_NXT}, 0, {S_NXT}")
-    e.raw(f"s_add_u32 {S_NN}, {S_NXT}, {BX_STAGE}")
-    e.raw(f"s_cmp_eq_u32 {S_NXT}, {2 * BX_STAGE}")
-    e.raw(f"s_cselect_b32 {S_NN}, 0, {S_NN}")
-    e.raw(f"s_mov_b32 {S_CNT}, {NT}")
-    for op in "AB":
-        for u in range(2):
-            e.raw(f"v_lshl_add_u64 {pair(op, u, 0)}, {SRC[(op, u)]}, 0, 0")
-            e.raw(f"v_lshl_add_u64 {pair(op, u, 1)}, {STRIDE[op]}, 0, {SRC[(op, u)]}")
-            e.raw(f"v_lshl_add_u64 {pair(op, u, 2)}, {STRIDE[op]}, 1, {SRC[(op, u)]}")
-    # fragments of tile t: all of B, row 0 of A
-    e.raw(f"v_add_u32 {V_AA}, {S_CUR}, {FOFS_A}")
-    e.raw(f"v_add_u32 {V_BN}, {S_CUR}, {FOFS_B}")
-    # (row 0 of A first, then B column by column: the order in which a trip requests the NEXT tile's fragments, so that one
-    # model of the LDS return queue is valid at the loop head for the first trip and for every later one)
-    for pc in range(3):
-        e.ds_read(f"A0{pc}", VA(0, pc), V_AA, pc * BX_PIECE)
-    for j in range(4):
-        for pc in range(3):
-            e.ds_read(f"B{j}{pc}", VB(j, pc), V_BN, pc * BX_PIECE + j * 1024)
-    e.raw("BXK_LOOP_%=:")
-    e.raw(f"v_add_u32 {V_AA}, {S_CUR}, {FOFS_A}")
-    e.raw(f"v_add_u32 {V_BN}, {S_NXT}, {FOFS_B}")
-    e.raw(f"v_add_u32 {V_AN}, {S_NXT}, {FOFS_A}")
-    e.raw(f"s_add_u32 {S_DMA}, {LDS0}, {S_NN}")
-
-    # ---- the MFMA stream: (slot, acc, A fragment name / register, B fragment name / register)
+def loop_body(e, G, req_gaps, label, setprio=False, nop_m0=True, ds_per_gap=3, row0_colmajor=False, barrier="full", dma=True, addr="vaddr"):
+    """One K tile: the MFMA stream with its fillers; `req_gaps[r]` = the MFMA slot BEFORE which request r is issued.
+    `ds_per_gap`: at most this many ds_read_b128 per MFMA gap (MI355X_MICROARCH.md, LDS: a third read per gap by every wave
+    saturates the LDS array and stretches the gap to 48 cycles); `row0_colmajor`: row 0 column by column like row 3, so that the
+    B fragments of the last column, read at the very end of the previous tile, are first needed 18 MFMAs later instead of 3.
+    `barrier` = "none" / `dma` = False: TIMING-ONLY builds (wrong results) that take one ingredient out of the loop."""
+    R = G.row
+    reqs = G.requests()
+    assert len(req_gaps) == len(reqs)
+    e.raw(f"{label}:")
+    e.raw(f"v_add_u32 {G.v_aa}, {S_CUR}, {G.fofs_a}")
+    e.raw(f"v_add_u32 {G.v_bn}, {S_NXT}, {G.fofs_b}")
+    e.raw(f"v_add_u32 {G.v_an}, {S_NXT}, {G.fofs_a}")
+    e.raw(f"s_add_u32 {S_DMA}, {G.lds0}, {S_NN}")
     stream = []
     for i in range(3):
+        if i == 0 and row0_colmajor:
+            for j in range(G.nj):
+                for pa, pb in PRODUCTS:
+                    stream.append((i, j, pa, pb))
+            continue
         for pa, pb in PRODUCTS:
-            for j in range(4):
+            for j in range(G.nj):
                 stream.append((i, j, pa, pb))
-    for j in range(4):
+    for j in range(G.nj):
         for pa, pb in PRODUCTS:
             stream.append((3, j, pa, pb))
-    assert len(stream) == 96
-
-    fillers = {g: [] for g in range(97)}
+    assert len(stream) == G.nmfma
+    fillers = {g: [] for g in range(G.nmfma + 1)}
     # A fragments of rows 1..3 (current stage) and of the next tile's row 0 (next stage: behind the barrier)
-    fillers[0] += [("ds", f"A1{pc}", VA(1, pc), V_AA, pc * BX_PIECE + 1 * 1024) for pc in range(3)]
-    fillers[24] += [("ds", f"A2{pc}", VA(0, pc), V_AA, pc * BX_PIECE + 2 * 1024) for pc in range(3)]
-    fillers[48] += [("ds", f"A3{pc}", VA(1, pc), V_AA, pc * BX_PIECE + 3 * 1024) for pc in range(3)]
-    fillers[48] += [("barrier",)]
-    fillers[72] += [("ds", f"N0{pc}", VA(0, pc), V_AN, pc * BX_PIECE) for pc in range(3)]
-    for j in range(4):   # next tile's B fragments of column j behind the six MFMAs of column j of row 3
-        fillers[72 + 6 * (j + 1)] += [("ds", f"NB{j}{pc}", VB(j, pc), V_BN, pc * BX_PIECE + j * 1024) for pc in range(3)]
+    fillers[0] += [("ds", f"A1{pc}", G.va(1, pc), G.v_aa, pc * BX_PIECE + 1 * 1024) for pc in range(3)]
+    fillers[R] += [("ds", f"A2{pc}", G.va(0, pc), G.v_aa, pc * BX_PIECE + 2 * 1024) for pc in range(3)]
+    fillers[2 * R] += [("ds", f"A3{pc}", G.va(1, pc), G.v_aa, pc * BX_PIECE + 3 * 1024) for pc in range(3)]
+    fillers[2 * R] += [("barrier",)]
+    fillers[3 * R] += [("ds", f"N0{pc}", G.va(0, pc), G.v_an, pc * BX_PIECE) for pc in range(3)]
+    for j in range(G.nj):   # next tile's B fragments of column j behind the six MFMAs of column j of row 3
+        fillers[3 * R + 6 * (j + 1)] += [("ds", f"NB{j}{pc}", G.vb(j, pc), G.v_bn, pc * BX_PIECE + j * 1024) for pc in range(3)]
     for r, g in enumerate(req_gaps):
-        assert 48 <= g <= 96, "requests overwrite the stage of tile t - 1: only behind the mid-tile barrier"
-        fillers[g].append(("req", r))
+        assert 2 * R <= g <= G.nmfma, "requests overwrite the stage of tile t - 1: only behind the mid-tile barrier"
+        if dma:
+            fillers[g].append(("req", r))
+    # at most ds_per_gap fragment reads per gap: the overflow moves to the following gaps (never across the end of the trip)
+    for g in range(G.nmfma + 1):
+        reads = [f for f in fillers[g] if f[0] == "ds"]
+        if len(reads) > ds_per_gap and g < G.nmfma:
+            move = reads[ds_per_gap:]
+            fillers[g] = [f for f in fillers[g] if f not in move]
+            fillers[g + 1] = move + fillers[g + 1]
 
     def emit_fillers(g):
         for f in fillers[g]:
             if f[0] == "ds":
                 e.ds_read(f[1], f[2], f[3], f[4])
             elif f[0] == "barrier":
-                e.raw("s_waitcnt vmcnt(0)")      # this wave's share of tile t + 1 has landed
-                e.raw("s_barrier")               # publishes tile t + 1; every wave is past tile t - 1
+                if dma:
+                    e.raw("s_waitcnt vmcnt(0)")      # this wave's share of tile t + 1 has landed
+                if barrier == "full":
+                    e.raw("s_barrier")               # publishes tile t + 1; every wave is past tile t - 1
             elif f[0] == "req":
                 op, u, pc = reqs[f[1]]
-                ofs = (BX_OPER if op == "B" else 0) + pc * BX_PIECE + 4 * u * 1024
+                ofs = (BX_OPER if op == "B" else 0) + pc * BX_PIECE + G.nw * u * 1024
                 e.raw(f"s_add_u32 m0, {S_DMA}, {ofs}")
                 if nop_m0:
                     e.raw("s_nop 0")             # SALU write of M0 -> LDS-DMA read of M0: one wait state (gfx9 hazard table)
-                e.raw(f"global_load_lds_dwordx4 {pair(op, u, pc)}, off")
-                e.raw(f"v_lshl_add_u64 {pair(op, u, pc)}, {pair(op, u, pc)}, 0, {STEP[op]}")
+                if addr == "saddr":
+                    b = G.sbase(op, u, pc)
+                    st_ = SADDR_STEP + (0 if op == "A" else 2)
+                    e.raw(f"global_load_lds_dwordx4 {G.v_off}, s[{b}:{b + 1}]")
+                    e.raw(f"s_add_u32 s{b}, s{b}, s{st_}")
+                    e.raw(f"s_addc_u32 s{b + 1}, s{b + 1}, s{st_ + 1}")
+                else:
+                    e.raw(f"global_load_lds_dwordx4 {G.pair(op, u, pc)}, off")
+                    e.raw(f"v_lshl_add_u64 {G.pair(op, u, pc)}, {G.pair(op, u, pc)}, 0, {G.step[op]}")
 
     names_a = {0: "A0", 1: "A1", 2: "A2", 3: "A3"}
-    # at the loop head the fragments of this tile were requested in the previous trip (or at entry): model them as pending
-    e.lgkm = [f"A0{pc}" for pc in range(3)] + [f"B{j}{pc}" for j in range(4) for pc in range(3)]
+    # at the loop head the fragments of this tile were requested by the previous trip (or at entry), in this order
+    e.lgkm = [f"A0{pc}" for pc in range(3)] + [f"B{j}{pc}" for j in range(G.nj) for pc in range(3)]
     for g, (i, j, pa, pb) in enumerate(stream):
         emit_fillers(g)
         e.need([f"{names_a[i]}{pa}", f"B{j}{pb}"])
-        if setprio and g in (0, 48):
+        if setprio and g in (0, 2 * R):
             e.raw("s_setprio 1")
-        seta = 0 if i in (0, 2) else 1
-        e.raw(f"v_mfma_f32_32x32x16_bf16 {ACC(i, j)}, {VA(seta, pa)}, {VB(j, pb)}, {ACC(i, j)}")
-    emit_fillers(96)
-    # the next trip finds: B fragments (12) then A row 0 (3) pending, in THAT order for its lgkm model -> re-order check
-    pend = list(e.lgkm)
-    want = [f"N0{pc}" for pc in range(3)] + [f"NB{j}{pc}" for j in range(4) for pc in range(3)]
-    assert [p for p in pend if p.startswith("N")] == want, pend
+        e.raw(f"v_mfma_f32_32x32x16_bf16 {G.acc(i, j)}, {G.va(0 if i in (0, 2) else 1, pa)}, {G.vb(j, pb)}, {G.acc(i, j)}")
+    emit_fillers(G.nmfma)
+    want = [f"N0{pc}" for pc in range(3)] + [f"NB{j}{pc}" for j in range(G.nj) for pc in range(3)]
+    assert [p for p in e.lgkm if p.startswith("N")] == want, e.lgkm
     # rotate the stages: (cur, nxt, nn) <- (nxt, nn, cur)
     e.raw(f"s_mov_b32 {S_TMP}, {S_CUR}")
     e.raw(f"s_mov_b32 {S_CUR}, {S_NXT}")
@@ -193,17 +241,74 @@ def gen(req_gaps=None, setprio=False, nop_m0=True):
     e.raw(f"s_mov_b32 {S_NN}, {S_TMP}")
     e.raw(f"s_sub_u32 {S_CNT}, {S_CNT}, 1")
     e.raw(f"s_cmp_lg_u32 {S_CNT}, 0")
-    e.raw("s_cbranch_scc1 BXK_LOOP_%=")
+    e.raw(f"s_cbranch_scc1 {label}")
+
+
+def gen(nw=4, req_gaps=None, req_gaps_g1=None, setprio=False, nop_m0=True, **body_kw):
+    """`req_gaps`: placement of the requests (wave group 0); `req_gaps_g1`: of wave group 1 (NW = 8: waves 4-7), None = the same."""
+    G = Geometry(nw)
+    R = G.row
+    nreq = len(G.requests())
+    if req_gaps is None:
+        # the C++ placement: three per column tile of row 3, behind the fragment reads of the column
+        req_gaps = [3 * R + 6 * (q + 1) for q in range(nreq // 3) for _ in range(3)]
+    e = Emitter()
+    e.raw("; ---- entry: stage offsets of tiles t, t + 1, t + 2 from st; request pointers of the (operand, block, piece) streams")
+    e.raw(f"s_mul_i32 {S_CUR}, {G.st}, {BX_STAGE}")
+    e.raw(f"s_add_u32 {S_NXT}, {S_CUR}, {BX_STAGE}")
+    e.raw(f"s_cmp_eq_u32 {G.st}, 2")
+    e.raw(f"s_cselect_b32 {S_NXT}, 0, {S_NXT}")
+    e.raw(f"s_add_u32 {S_NN}, {S_NXT}, {BX_STAGE}")
+    e.raw(f"s_cmp_eq_u32 {S_NXT}, {2 * BX_STAGE}")
+    e.raw(f"s_cselect_b32 {S_NN}, 0, {S_NN}")
+    e.raw(f"s_mov_b32 {S_CNT}, {G.nt}")
+    for op in "AB":
+        for u in range(G.nu):
+            e.raw(f"v_lshl_add_u64 {G.pair(op, u, 0)}, {G.src[(op, u)]}, 0, 0")
+            e.raw(f"v_lshl_add_u64 {G.pair(op, u, 1)}, {G.stride[op]}, 0, {G.src[(op, u)]}")
+            e.raw(f"v_lshl_add_u64 {G.pair(op, u, 2)}, {G.stride[op]}, 1, {G.src[(op, u)]}")
+    if body_kw.get("addr") == "saddr":
+        # wave-uniform bases of the streams (lane 0 of each pointer: its lane offset is 0) + the one per-lane offset (16 lane)
+        first = G.pair("A", 0, 0)
+        for op in "AB":
+            for u in range(G.nu):
+                for pc in range(3):
+                    b, vp = G.sbase(op, u, pc), G.pair(op, u, pc)
+                    lo = int(vp[2:].split(":")[0])
+                    e.raw(f"v_readfirstlane_b32 s{b}, v{lo}")
+                    e.raw(f"v_readfirstlane_b32 s{b + 1}, v{lo + 1}")
+        lo0 = int(first[2:].split(":")[0])
+        e.raw(f"v_readfirstlane_b32 {S_TMP}, v{lo0}")
+        e.raw("s_nop 4")                                   # VALU-written SGPR -> read by VALU / VMEM
+        e.raw(f"v_sub_u32 {G.v_off}, v{lo0}, {S_TMP}")
+        e.raw(f"s_mov_b64 s[{SADDR_STEP}:{SADDR_STEP + 1}], {G.step['A']}")
+        e.raw(f"s_mov_b64 s[{SADDR_STEP + 2}:{SADDR_STEP + 3}], {G.step['B']}")
+    # fragments of tile t: row 0 of A first, then B column by column -- the order in which a trip requests the NEXT tile's
+    # fragments, so that one model of the LDS return queue is valid at the loop head for the first trip and every later one
+    e.raw(f"v_add_u32 {G.v_aa}, {S_CUR}, {G.fofs_a}")
+    e.raw(f"v_add_u32 {G.v_bn}, {S_CUR}, {G.fofs_b}")
+    for pc in range(3):
+        e.ds_read(f"A0{pc}", G.va(0, pc), G.v_aa, pc * BX_PIECE)
+    for j in range(G.nj):
+        for pc in range(3):
+            e.ds_read(f"B{j}{pc}", G.vb(j, pc), G.v_bn, pc * BX_PIECE + j * 1024)
+    if req_gaps_g1 is not None:
+        e.raw(f"s_cmp_lg_u32 {G.grp}, 0")
+        e.raw("s_cbranch_scc1 BXK_G1_%=")
+    loop_body(e, G, req_gaps, "BXK_G0_%=", setprio, nop_m0, **body_kw)
+    if req_gaps_g1 is not None:
+        e.raw("s_branch BXK_END_%=")
+        loop_body(e, G, req_gaps_g1, "BXK_G1_%=", setprio, nop_m0, **body_kw)
+        e.raw("BXK_END_%=:")
     e.raw("; ---- exit: nothing of the next tile is needed in registers (the C++ side re-reads its fragments)")
     e.raw("s_waitcnt lgkmcnt(0)")
-    # (st and the request pointers are plain inputs: the C++ side advances its own copies by ntiles)
-    return e.lines
+    return e.lines, G
 
 
-def render(lines, name="BX_KLOOP_ASM"):
-    body = "\n".join(f'  "{l}\\n\\t"' for l in lines)
-    clob = ", ".join([f'"v{k}"' for k in CLOBBER_V] + [f'"s{k}"' for k in CLOBBER_S] + [ '"scc"', '"memory"'])
-    return f"#define {name}_TEXT \\\n" + " \\\n".join(f'  "{l}\\n\\t"' for l in lines) + f"\n#define {name}_CLOBBERS {clob}\n"
+def render(lines, G, name, saddr=False):
+    clob = ", ".join([f'"v{k}"' for k in G.clobber_v] + [f'"s{k}"' for k in CLOBBER_S + (CLOBBER_S_SADDR if saddr else [])] + ['"scc"', '"memory"'])
+    # (m0 is written too: clang reserves it and refuses it as a clobber; hipcc keeps nothing live in m0 across an asm statement)
+    return (f"#define {name}_TEXT \\\n" + " \\\n".join(f'  "{l}\\n\\t"' for l in lines) + f"\n#define {name}_CLOBBERS {clob}\n")
 
 
 HEADER = """// GENERATED by scripts/gen_bx_kloop.py -- do not edit; see that script for the register map, the pipeline invariant at
@@ -211,21 +316,45 @@ HEADER = """// GENERATED by scripts/gen_bx_kloop.py -- do not edit; see that scr
 """
 
 
+def variants():
+    R8 = 12
+    return {
+        # ---- four waves (one per SIMD)
+        "BX_KLOOP_ASM": dict(nw=4),
+        "BX_KLOOP_ASM_V1": dict(nw=4, req_gaps=[54, 57, 60, 63, 66, 69, 75, 78, 81, 84, 87, 90]),   # one per three MFMAs over rows 2 + 3
+        "BX_KLOOP_ASM_V2": dict(nw=4, req_gaps=[76, 78, 80, 82, 84, 86, 88, 90, 92, 94, 96, 96]),   # one per two MFMAs in row 3
+        "BX_KLOOP_ASM_V3": dict(nw=4, setprio=True),
+        "BX_KLOOP_ASM_V4": dict(nw=4, nop_m0=False),
+        # ---- eight waves (two per SIMD).  Default: group 0 requests in row 2 (one per two MFMAs), group 1 in row 3
+        "BX_KLOOP8_ASM": dict(nw=8, req_gaps=[2 * R8 + 2 * k + 1 for k in range(6)], req_gaps_g1=[3 * R8 + 2 * k + 1 for k in range(6)]),
+        "BX_KLOOP8_ASM_V1": dict(nw=8, req_gaps=[3 * R8 + 6] * 3 + [3 * R8 + 12] * 3),                                       # both groups as the C++ loop
+        "BX_KLOOP8_ASM_V2": dict(nw=8, req_gaps=[3 * R8 + 2 * k + 1 for k in range(6)]),                                     # both in row 3, spread
+        "BX_KLOOP8_ASM_V3": dict(nw=8, req_gaps=[3 * R8 + 2 * k + 1 for k in range(6)], req_gaps_g1=[2 * R8 + 2 * k + 1 for k in range(6)]),   # groups swapped
+        # ---- attribution builds (T1, T2, T4-T6: TIMING ONLY, wrong results; T3 is correct): what one ingredient of the loop costs
+        "BX_KLOOP_ASM_T1": dict(nw=4, barrier="none"),
+        "BX_KLOOP_ASM_T2": dict(nw=4, dma=False),
+        "BX_KLOOP_ASM_T3": dict(nw=4, ds_per_gap=2, row0_colmajor=True, req_gaps=[51, 55, 59, 63, 67, 71, 75, 77, 81, 83, 87, 89]),
+        "BX_KLOOP_ASM_T4": dict(nw=4, ds_per_gap=2, row0_colmajor=True, req_gaps=[51, 55, 59, 63, 67, 71, 75, 77, 81, 83, 87, 89], barrier="none"),
+        "BX_KLOOP_ASM_T5": dict(nw=4, ds_per_gap=2, row0_colmajor=True, dma=False),
+        "BX_KLOOP_ASM_T6": dict(nw=4, ds_per_gap=2, row0_colmajor=True, dma=False, barrier="none"),
+        "BX_KLOOP_ASM_T7": dict(nw=4, ds_per_gap=2, row0_colmajor=True, req_gaps=[51, 55, 59, 63, 67, 71, 75, 77, 81, 83, 87, 89], addr="saddr"),
+        "BX_KLOOP8_ASM_T3": dict(nw=8, ds_per_gap=2, row0_colmajor=True, req_gaps=[2 * R8 + 2 * k + 3 for k in range(4)] + [3 * R8 + 3, 3 * R8 + 5],
+                                 req_gaps_g1=[3 * R8 + 3, 3 * R8 + 5, 3 * R8 + 9, 3 * R8 + 11] + [2 * R8 + 3, 2 * R8 + 5]),
+        "BX_KLOOP8_ASM_T4": dict(nw=8, ds_per_gap=2, row0_colmajor=True, req_gaps=[2 * R8 + 2 * k + 3 for k in range(4)] + [3 * R8 + 3, 3 * R8 + 5], barrier="none"),
+        "BX_KLOOP8_ASM_T6": dict(nw=8, ds_per_gap=2, row0_colmajor=True, dma=False, barrier="none"),
+    }
+
+
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vivit_amd", "csrc", "bx_kloop_asm.inc")
-    text = HEADER + render(gen())
-    # experiment variants (selected with -DBX_ASM_VARIANT=n; timing A/Bs, same arithmetic)
-    variants = {
-        1: dict(req_gaps=[54, 57, 60, 63, 66, 69, 75, 78, 81, 84, 87, 90]),          # one request per three MFMAs over rows 2 + 3
-        2: dict(req_gaps=[76, 78, 80, 82, 84, 86, 88, 90, 92, 94, 96, 96]),          # one per two MFMAs in row 3
-        3: dict(req_gaps=[78] * 3 + [84] * 3 + [90] * 3 + [96] * 3, setprio=True),
-        4: dict(req_gaps=[78] * 3 + [84] * 3 + [90] * 3 + [96] * 3, nop_m0=False),
-    }
-    for k, kw in variants.items():
-        text += render(gen(**kw), name=f"BX_KLOOP_ASM_V{k}")
+    text = HEADER
+    for name, kw in variants().items():
+        lines, G = gen(**kw)
+        text += render(lines, G, name, saddr=kw.get("addr") == "saddr")
+        print(name, len(lines), "lines,", G.noperands, "operands")
     with open(out, "w") as f:
         f.write(text)
-    print("wrote", os.path.normpath(out), len(gen()), "instructions per block")
+    print("wrote", os.path.normpath(out))
 
 
 if __name__ == "__main__":

@@ -36,10 +36,10 @@ def child(do_time):
     if do_time:
         n, p = 40960, 131072
         G = torch.empty(n, n, device=dev)
-        A = torch.randn(n, p, device=dev)
+        A = torch.randn(n, p, device=dev, generator=g)
         for kind in ("randn", "half zeros"):
             if kind == "half zeros":
-                A.mul_((torch.rand(n, p // 784 + 1, device=dev) < 0.5).repeat_interleave(784, 1)[:, :p])
+                A.mul_((torch.rand(n, p // 784 + 1, device=dev, generator=g) < 0.5).repeat_interleave(784, 1)[:, :p])
             kernels.gram_syrk(A, out=G)
             torch.cuda.synchronize()
             ts = []
@@ -53,6 +53,9 @@ def child(do_time):
         print("HASH", "headline-shaped", hashlib.sha256(G[:4096].cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
 
 
+MODES = ("0", "4", "8")   # VIVIT_BX_ASM: C++ loop | asm loop, four waves | asm loop, eight waves
+
+
 def main():
     if "--child" in sys.argv:
         return child("--time" in sys.argv)
@@ -63,7 +66,7 @@ def main():
     reps = 2 if "--time" in sys.argv else 1
     hashes = {}
     for rep in range(reps):
-        for asm in ("0", "1"):
+        for asm in MODES:
             e = dict(env, VIVIT_BX_ASM=asm)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"] + (["--time"] if "--time" in sys.argv else []),
                                env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -75,10 +78,10 @@ def main():
             for l in lines:
                 if l.startswith("TIME"):
                     print(f"asm={asm} rep {rep}: {l}", flush=True)
-    same = hashes["0"] == hashes["1"]
-    for a, b in zip(hashes["0"], hashes["1"]):
-        print(("same " if a == b else "DIFF ") + a + ("" if a == b else "   |   " + b))
-    print("bit-identical:", same)
+    same = all(hashes[m] == hashes[MODES[0]] for m in MODES)
+    for row in zip(*[hashes[m] for m in MODES]):
+        print(("same " if len(set(row)) == 1 else "DIFF ") + "   |   ".join(sorted(set(row))))
+    print("bit-identical:", same, "modes", MODES)
     raise SystemExit(0 if same else 1)
 
 

@@ -37,6 +37,8 @@ q = lambda x: f"median {x.median().item():.1f} (p10 {x.quantile(0.1).item():.1f}
 print(f"{kind}: {int(ok.sum())} workgroups on {len(torch.unique(cu))} CUs; launch span {us(exit_.max() - entry.min()).item():.0f} us")
 print("  prologue (entry -> first tile)  us:", q(us(loop0 - entry)))
 print("  K loop                          us:", q(us(loop1 - loop0)))
+ghz = st[:, 0].double() / (st[:, 1].double() * 10.0)      # s_memtime (core clock) over s_memrealtime (100 MHz) across the K loop
+print("  clock inside the K loop        GHz:", q(ghz), "| core cycles per K tile (256 per 4096-column launch):", q(st[:, 0].double() / 256))
 print("  flush (loop end -> in memory)   us:", q(us(exit_ - loop1)), "| of which until wave 0 has issued its last store:", q(us(st[:, 7] - loop1)))
 gaps = []
 for c in torch.unique(cu):

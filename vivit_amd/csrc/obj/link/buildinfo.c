@@ -1,1 +1,1 @@
-const char *vivit_hip_source_hash(void) { return "23b55f42271adc8582fe3cbd1040fc53-262e1d34"; }
+const char *vivit_hip_source_hash(void) { return "3d3f5573b26968bead646a9443d6df3e-262e1d34"; }

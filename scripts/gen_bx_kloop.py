@@ -148,7 +148,29 @@ class Emitter:
         del self.lgkm[: max(idx) + 1]
 
 
-def loop_body(e, G, req_gaps, label, setprio=False, nop_m0=True, ds_per_gap=3, row0_colmajor=False, barrier="full", dma=True, addr="vaddr"):
+def loop_body(e, G, req_gaps, label, setprio=False, nop_m0=True, ds_per_gap=3, row0_colmajor=False, barrier="full", dma=True, addr="vaddr",
+              unroll=1):
+    """`unroll` tiles per trip: the stage registers take their roles by renaming (no rotation moves), ntiles % unroll == 0."""
+    e.raw(f"{label}:")
+    regs = [S_CUR, S_NXT, S_NN]
+    for k in range(unroll):
+        one_tile(e, G, req_gaps, regs[k % 3], regs[(k + 1) % 3], regs[(k + 2) % 3], setprio, nop_m0, ds_per_gap, row0_colmajor, barrier, dma, addr)
+    if unroll % 3 != 0:   # rotate the stages: (cur, nxt, nn) <- (nxt, nn, cur), `unroll` times
+        e.raw(f"s_mov_b32 {S_TMP}, {regs[0]}")
+        if unroll % 3 == 1:
+            e.raw(f"s_mov_b32 {regs[0]}, {regs[1]}")
+            e.raw(f"s_mov_b32 {regs[1]}, {regs[2]}")
+            e.raw(f"s_mov_b32 {regs[2]}, {S_TMP}")
+        else:
+            e.raw(f"s_mov_b32 {regs[0]}, {regs[2]}")
+            e.raw(f"s_mov_b32 {regs[2]}, {regs[1]}")
+            e.raw(f"s_mov_b32 {regs[1]}, {S_TMP}")
+    e.raw(f"s_sub_u32 {S_CNT}, {S_CNT}, {unroll}")
+    e.raw(f"s_cmp_lg_u32 {S_CNT}, 0")
+    e.raw(f"s_cbranch_scc1 {label}")
+
+
+def one_tile(e, G, req_gaps, S_CUR, S_NXT, S_NN, setprio, nop_m0, ds_per_gap, row0_colmajor, barrier, dma, addr):
     """One K tile: the MFMA stream with its fillers; `req_gaps[r]` = the MFMA slot BEFORE which request r is issued.
     `ds_per_gap`: at most this many ds_read_b128 per MFMA gap (MI355X_MICROARCH.md, LDS: a third read per gap by every wave
     saturates the LDS array and stretches the gap to 48 cycles); `row0_colmajor`: row 0 column by column like row 3, so that the
@@ -157,7 +179,6 @@ def loop_body(e, G, req_gaps, label, setprio=False, nop_m0=True, ds_per_gap=3, r
     R = G.row
     reqs = G.requests()
     assert len(req_gaps) == len(reqs)
-    e.raw(f"{label}:")
     e.raw(f"v_add_u32 {G.v_aa}, {S_CUR}, {G.fofs_a}")
     e.raw(f"v_add_u32 {G.v_bn}, {S_NXT}, {G.fofs_b}")
     e.raw(f"v_add_u32 {G.v_an}, {S_NXT}, {G.fofs_a}")
@@ -234,14 +255,6 @@ def loop_body(e, G, req_gaps, label, setprio=False, nop_m0=True, ds_per_gap=3, r
     emit_fillers(G.nmfma)
     want = [f"N0{pc}" for pc in range(3)] + [f"NB{j}{pc}" for j in range(G.nj) for pc in range(3)]
     assert [p for p in e.lgkm if p.startswith("N")] == want, e.lgkm
-    # rotate the stages: (cur, nxt, nn) <- (nxt, nn, cur)
-    e.raw(f"s_mov_b32 {S_TMP}, {S_CUR}")
-    e.raw(f"s_mov_b32 {S_CUR}, {S_NXT}")
-    e.raw(f"s_mov_b32 {S_NXT}, {S_NN}")
-    e.raw(f"s_mov_b32 {S_NN}, {S_TMP}")
-    e.raw(f"s_sub_u32 {S_CNT}, {S_CNT}, 1")
-    e.raw(f"s_cmp_lg_u32 {S_CNT}, 0")
-    e.raw(f"s_cbranch_scc1 {label}")
 
 
 def gen(nw=4, req_gaps=None, req_gaps_g1=None, setprio=False, nop_m0=True, **body_kw):
@@ -305,10 +318,10 @@ def gen(nw=4, req_gaps=None, req_gaps_g1=None, setprio=False, nop_m0=True, **bod
     return e.lines, G
 
 
-def render(lines, G, name, saddr=False):
+def render(lines, G, name, saddr=False, unroll=1):
     clob = ", ".join([f'"v{k}"' for k in G.clobber_v] + [f'"s{k}"' for k in CLOBBER_S + (CLOBBER_S_SADDR if saddr else [])] + ['"scc"', '"memory"'])
     # (m0 is written too: clang reserves it and refuses it as a clobber; hipcc keeps nothing live in m0 across an asm statement)
-    return (f"#define {name}_TEXT \\\n" + " \\\n".join(f'  "{l}\\n\\t"' for l in lines) + f"\n#define {name}_CLOBBERS {clob}\n")
+    return (f"#define {name}_TEXT \\\n" + " \\\n".join(f'  "{l}\\n\\t"' for l in lines) + f"\n#define {name}_CLOBBERS {clob}\n#define {name}_UNROLL {unroll}\n")
 
 
 HEADER = """// GENERATED by scripts/gen_bx_kloop.py -- do not edit; see that script for the register map, the pipeline invariant at
@@ -317,31 +330,23 @@ HEADER = """// GENERATED by scripts/gen_bx_kloop.py -- do not edit; see that scr
 
 
 def variants():
-    R8 = 12
+    spread = [51, 55, 59, 63, 67, 71, 75, 77, 81, 83, 87, 89]      # one request per gap in rows 2 + 3, never beside fragment reads
+    row3 = [74, 75, 76, 77, 80, 81, 82, 83, 86, 87, 88, 89]        # all in row 3, one per gap
+    best = dict(nw=4, ds_per_gap=2, row0_colmajor=True, addr="saddr")
     return {
-        # ---- four waves (one per SIMD)
-        "BX_KLOOP_ASM": dict(nw=4),
-        "BX_KLOOP_ASM_V1": dict(nw=4, req_gaps=[54, 57, 60, 63, 66, 69, 75, 78, 81, 84, 87, 90]),   # one per three MFMAs over rows 2 + 3
-        "BX_KLOOP_ASM_V2": dict(nw=4, req_gaps=[76, 78, 80, 82, 84, 86, 88, 90, 92, 94, 96, 96]),   # one per two MFMAs in row 3
-        "BX_KLOOP_ASM_V3": dict(nw=4, setprio=True),
-        "BX_KLOOP_ASM_V4": dict(nw=4, nop_m0=False),
-        # ---- eight waves (two per SIMD).  Default: group 0 requests in row 2 (one per two MFMAs), group 1 in row 3
-        "BX_KLOOP8_ASM": dict(nw=8, req_gaps=[2 * R8 + 2 * k + 1 for k in range(6)], req_gaps_g1=[3 * R8 + 2 * k + 1 for k in range(6)]),
-        "BX_KLOOP8_ASM_V1": dict(nw=8, req_gaps=[3 * R8 + 6] * 3 + [3 * R8 + 12] * 3),                                       # both groups as the C++ loop
-        "BX_KLOOP8_ASM_V2": dict(nw=8, req_gaps=[3 * R8 + 2 * k + 1 for k in range(6)]),                                     # both in row 3, spread
-        "BX_KLOOP8_ASM_V3": dict(nw=8, req_gaps=[3 * R8 + 2 * k + 1 for k in range(6)], req_gaps_g1=[2 * R8 + 2 * k + 1 for k in range(6)]),   # groups swapped
-        # ---- attribution builds (T1, T2, T4-T6: TIMING ONLY, wrong results; T3 is correct): what one ingredient of the loop costs
-        "BX_KLOOP_ASM_T1": dict(nw=4, barrier="none"),
-        "BX_KLOOP_ASM_T2": dict(nw=4, dma=False),
-        "BX_KLOOP_ASM_T3": dict(nw=4, ds_per_gap=2, row0_colmajor=True, req_gaps=[51, 55, 59, 63, 67, 71, 75, 77, 81, 83, 87, 89]),
-        "BX_KLOOP_ASM_T4": dict(nw=4, ds_per_gap=2, row0_colmajor=True, req_gaps=[51, 55, 59, 63, 67, 71, 75, 77, 81, 83, 87, 89], barrier="none"),
-        "BX_KLOOP_ASM_T5": dict(nw=4, ds_per_gap=2, row0_colmajor=True, dma=False),
-        "BX_KLOOP_ASM_T6": dict(nw=4, ds_per_gap=2, row0_colmajor=True, dma=False, barrier="none"),
-        "BX_KLOOP_ASM_T7": dict(nw=4, ds_per_gap=2, row0_colmajor=True, req_gaps=[51, 55, 59, 63, 67, 71, 75, 77, 81, 83, 87, 89], addr="saddr"),
-        "BX_KLOOP8_ASM_T3": dict(nw=8, ds_per_gap=2, row0_colmajor=True, req_gaps=[2 * R8 + 2 * k + 3 for k in range(4)] + [3 * R8 + 3, 3 * R8 + 5],
-                                 req_gaps_g1=[3 * R8 + 3, 3 * R8 + 5, 3 * R8 + 9, 3 * R8 + 11] + [2 * R8 + 3, 2 * R8 + 5]),
-        "BX_KLOOP8_ASM_T4": dict(nw=8, ds_per_gap=2, row0_colmajor=True, req_gaps=[2 * R8 + 2 * k + 3 for k in range(4)] + [3 * R8 + 3, 3 * R8 + 5], barrier="none"),
-        "BX_KLOOP8_ASM_T6": dict(nw=8, ds_per_gap=2, row0_colmajor=True, dma=False, barrier="none"),
+        # ---- the product's block
+        "BX_KLOOP_ASM": dict(best, req_gaps=spread, unroll=3),
+        # ---- experiments (same arithmetic: results stay bit-identical)
+        "BX_KLOOP_ASM_E1": dict(best, req_gaps=spread, unroll=1),
+        "BX_KLOOP_ASM_E2": dict(best, req_gaps=row3, unroll=3),
+        "BX_KLOOP_ASM_E3": dict(best, req_gaps=spread, unroll=3, setprio=True),
+        "BX_KLOOP_ASM_E4": dict(best, req_gaps=spread, unroll=3, nop_m0=False),
+        "BX_KLOOP_ASM_E5": dict(nw=4, ds_per_gap=2, row0_colmajor=True, req_gaps=spread, unroll=3),          # 64-bit per-lane addresses
+        "BX_KLOOP_ASM_E6": dict(nw=4),                                                                       # the C++ loop's schedule
+        # ---- attribution builds (TIMING ONLY, wrong results): what one ingredient of the loop costs (profiles/r06_bx_attribution*.log)
+        "BX_KLOOP_ASM_T1": dict(best, req_gaps=spread, unroll=3, barrier="none"),
+        "BX_KLOOP_ASM_T2": dict(best, req_gaps=spread, unroll=3, dma=False),
+        "BX_KLOOP_ASM_T3": dict(best, req_gaps=spread, unroll=3, dma=False, barrier="none"),
     }
 
 
@@ -350,7 +355,7 @@ def main():
     text = HEADER
     for name, kw in variants().items():
         lines, G = gen(**kw)
-        text += render(lines, G, name, saddr=kw.get("addr") == "saddr")
+        text += render(lines, G, name, saddr=kw.get("addr") == "saddr", unroll=kw.get("unroll", 1))
         print(name, len(lines), "lines,", G.noperands, "operands")
     with open(out, "w") as f:
         f.write(text)

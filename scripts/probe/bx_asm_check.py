@@ -53,7 +53,7 @@ def child(do_time):
         print("HASH", "headline-shaped", hashlib.sha256(G[:4096].cpu().numpy().tobytes()).hexdigest()[:16], flush=True)
 
 
-MODES = ("0", "4", "8")   # VIVIT_BX_ASM: C++ loop | asm loop, four waves | asm loop, eight waves
+MODES = ("0", "1")   # VIVIT_BX_ASM: C++ loop | asm loop
 
 
 def main():

@@ -962,52 +962,33 @@ __device__ unsigned int g_bx_stamp_cap = 0;
 #endif
 
 #include "bx_kloop_asm.inc"
-#if defined(BX_KLOOP_TEXT_OVERRIDE)     // -DBX_KLOOP_TEXT_OVERRIDE=BX_KLOOP_ASM_T3_TEXT: any block of bx_kloop_asm.inc by name
+#if defined(BX_KLOOP_TEXT_OVERRIDE)     // attribution / experiment builds: any block of bx_kloop_asm.inc by name
 #define BX_KLOOP_TEXT BX_KLOOP_TEXT_OVERRIDE
-#elif defined(BX_ASM_VARIANT) && BX_ASM_VARIANT == 1
-#define BX_KLOOP_TEXT BX_KLOOP_ASM_V1_TEXT
-#elif defined(BX_ASM_VARIANT) && BX_ASM_VARIANT == 2
-#define BX_KLOOP_TEXT BX_KLOOP_ASM_V2_TEXT
-#elif defined(BX_ASM_VARIANT) && BX_ASM_VARIANT == 3
-#define BX_KLOOP_TEXT BX_KLOOP_ASM_V3_TEXT
-#elif defined(BX_ASM_VARIANT) && BX_ASM_VARIANT == 4
-#define BX_KLOOP_TEXT BX_KLOOP_ASM_V4_TEXT
+#define BX_KLOOP_CLOB BX_KLOOP_CLOB_OVERRIDE
+#define BX_KLOOP_UNROLL BX_KLOOP_UNROLL_OVERRIDE
 #else
 #define BX_KLOOP_TEXT BX_KLOOP_ASM_TEXT
-#endif
-#if defined(BX_KLOOP_CLOB_OVERRIDE)
-#define BX_KLOOP_CLOB BX_KLOOP_CLOB_OVERRIDE
-#else
 #define BX_KLOOP_CLOB BX_KLOOP_ASM_CLOBBERS
-#endif
-#if defined(BX_KLOOP8_TEXT_OVERRIDE)
-#define BX_KLOOP8_TEXT BX_KLOOP8_TEXT_OVERRIDE
-#elif defined(BX_ASM8_VARIANT) && BX_ASM8_VARIANT == 1
-#define BX_KLOOP8_TEXT BX_KLOOP8_ASM_V1_TEXT
-#elif defined(BX_ASM8_VARIANT) && BX_ASM8_VARIANT == 2
-#define BX_KLOOP8_TEXT BX_KLOOP8_ASM_V2_TEXT
-#elif defined(BX_ASM8_VARIANT) && BX_ASM8_VARIANT == 3
-#define BX_KLOOP8_TEXT BX_KLOOP8_ASM_V3_TEXT
-#else
-#define BX_KLOOP8_TEXT BX_KLOOP8_ASM_TEXT
+#define BX_KLOOP_UNROLL BX_KLOOP_ASM_UNROLL
 #endif
 
-// ASM: the steady part of the K loop runs as ONE hand-scheduled inline-asm block (bx_kloop_asm.inc, generated by
-// scripts/gen_bx_kloop.py: fixed register map, every memory instruction placed between the MFMAs by hand); prologue, the last
-// two tiles of a pass, the chain flushes and the epilogues stay the C++ below, which is also the reference implementation
-// (ASM = false, VIVIT_BX_ASM=0).  Same partial products in the same order per accumulator: bit-identical results.
-//
-// NW: waves per workgroup.  4 (rounds 2-5): 128 x 128 per wave, one wave per SIMD, 512 registers.  8 (round 6, ASM only): 128 x 64
-// per wave (4 x 2 accumulator tiles), TWO waves per SIMD at 256 registers each -- a global -> LDS request holds the issuing
-// wave for ~60 cycles, of which one MFMA hides 24: with one wave per SIMD the twelve requests of a K tile leave the matrix
-// pipe idle for ~12 % of the tile (the C++ loop and its asm twin measure the same, profiles/r06_bx_asm_4wave.log); with
-// two waves per SIMD the partner's MFMAs run underneath.  Same LDS stages, same fragment layout, same per-accumulator order.
-template <int NPROD, bool ASM = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
-  constexpr int NJ = NW == 8 ? 2 : 4;      // 32-wide column tiles per wave
-  constexpr int WNW = 8 / NJ;              // waves side by side along N
-  constexpr int NU = 8 / NW;               // 1 KB blocks per wave, piece and operand
-  static_assert(NW == 4 || (NW == 8 && ASM && NPROD == 6), "the eight-wave geometry exists for the asm K loop only");
+// ASM (default since round 6): the steady part of the K loop runs as ONE hand-scheduled inline-asm block (bx_kloop_asm.inc,
+// generated by scripts/gen_bx_kloop.py: fixed register map, every memory instruction placed between the MFMAs by hand);
+// prologue, the last tiles of a pass, the chain flushes and the epilogues stay the C++ below, which is also the reference
+// implementation (ASM = false, VIVIT_BX_ASM=0).  Same partial products in the same order per accumulator: bit-identical
+// results (tests/test_bx_asm_gpu.py).  What the block does differently, and what each point is worth in core cycles per K tile
+// (3072 of them are the 96 MFMAs; in-kernel stamps, profiles/r06_bx_attribution*.log; the C++ loop: 3525):
+//   * the twelve global -> LDS requests take a scalar base + ONE 32-bit lane offset instead of twelve 64-bit per-lane
+//     pointers (global_load_lds_dwordx4 v, s[..]): the requests cost ~30 cycles per tile instead of ~290 -- it is the address
+//     registers of a request, not its issue slot, that hold up the SIMD (eight waves, two per SIMD, did not hide it: same 3500);
+//   * never more than two ds_read_b128 per MFMA gap (a third one by every wave saturates the LDS array for that gap: ~100);
+//   * one request per gap over rows 2 + 3, never beside fragment reads (all in row 3: + 190);
+//   * row 0 column by column, so that the last column's B fragments, read at the end of the previous tile, are first needed
+//     18 MFMAs later; three tiles per trip with the stage registers renamed instead of rotated (- 45).
+//   Now 3283 (no barrier: 3235; no requests: 3253; neither: 3226): 93.6 % of the cycles are MFMA cycles.  The chip answers with
+//   a lower clock (DVFS give-back): - 7 % cycles are - 3.8 % time on the K loop.
+template <int NPROD, bool ASM = false>
+__global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
 #if defined(BX_STAMP) && BX_STAMP == 2   // timeline build (scripts/probe/bx_timeline.py): 8 words per workgroup
   const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
@@ -1037,7 +1018,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     __syncthreads();
   }
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WNW, wn = wave % WNW;
+  const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)ti * B2, col0 = (int64_t)tj * B2;
   int nt = (int)(p.K / BK);
@@ -1047,11 +1028,11 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     nt = nt - (int)kt0 < p.kt_split ? nt - (int)kt0 : p.kt_split;
   }
 
-  f32x16 acc[4][NJ];
+  f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -1075,18 +1056,18 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       __asm__ volatile("" ::: "memory");
       const int64_t rbase = row0 + wm * 128 + i * 32 + 4 * h + opaque;
       if (full_tile) {
-        float old[NJ][16];
+        float old[4][16];
         if (beta != 0.f) {
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            gptr cbase = Cout + rbase * ldc + (col0 + wn * (32 * NJ) + j * 32 + r);
+          for (int j = 0; j < 4; ++j) {
+            gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + r);
 #pragma unroll
             for (int e = 0; e < 16; ++e) old[j][e] = ld_l2(cbase + (int64_t)((e & 3) + 8 * (e >> 2)) * ldc);
           }
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          gptr cbase = Cout + rbase * ldc + (col0 + wn * (32 * NJ) + j * 32 + r);
+        for (int j = 0; j < 4; ++j) {
+          gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + r);
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             float v = alpha_ * acc[i][j][e];
@@ -1097,8 +1078,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int64_t col = col0 + wn * (32 * NJ) + j * 32 + r;
+        for (int j = 0; j < 4; ++j) {
+          const int64_t col = col0 + wn * 128 + j * 32 + r;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
@@ -1118,7 +1099,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   };
@@ -1142,8 +1123,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int64_t rb = row0 + wm * 128 + i * 32 + 4 * h + opaque, col = col0 + wn * (32 * NJ) + j * 32 + r;
+      for (int j = 0; j < 4; ++j) {
+        const int64_t rb = row0 + wm * 128 + i * 32 + 4 * h + opaque, col = col0 + wn * 128 + j * 32 + r;
         gptr cb = Cout + rb * ldc + col;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -1159,10 +1140,10 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   // ---- DMA sources: wave w fills blocks w and w + 4 of every piece of both operands (12 instructions per K tile),
   // each instruction 1 KB of consecutive global bytes (blocked piece layout).  Row blocks beyond the matrix read the
   // last block (their outputs are never stored).  The pointers advance by one k tile per request.
-  gcptr16 srcA[NU], srcB[NU];
+  gcptr16 srcA[2], srcB[2];
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int blk = wave + NW * u;
+  for (int u = 0; u < 2; ++u) {
+    const int blk = wave + 4 * u;
     int64_t ba = row0 / 32 + blk, bb = col0 / 32 + blk;   // 32-row block of the operand (clamped: never stored rows)
     ba = ba < p.nrbA ? ba : p.nrbA - 1;
     bb = bb < p.nrbB ? bb : p.nrbB - 1;
@@ -1178,30 +1159,30 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   auto dma16b = [&](gcptr16 src, unsigned lds_byte_addr) __attribute__((always_inline)) {
     __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_addr), "v"(src) : "memory");
   };
-  // part q of the 6 NU requests of one K tile: q = 0 .. 2 NU - 1 -> (block u = q / 2, operand q % 2), three pieces each
+  // part q of the 12 requests of one K tile: q = 0..3 -> (block u = q / 2, operand q % 2), three pieces each
   auto issue_part = [&](int st, int q) __attribute__((always_inline)) {
     const int u = q >> 1;
     if ((q & 1) == 0) {
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc)
-        dma16b(srcA[u] + pc * p.strideA, lds0 + (unsigned)(st * BX_STAGE + pc * BX_PIECE + NW * u * 1024));
+        dma16b(srcA[u] + pc * p.strideA, lds0 + (unsigned)(st * BX_STAGE + pc * BX_PIECE + 4 * u * 1024));
       srcA[u] += stepA;
     } else {
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc)
-        dma16b(srcB[u] + pc * p.strideB, lds0 + (unsigned)(st * BX_STAGE + BX_OPER + pc * BX_PIECE + NW * u * 1024));
+        dma16b(srcB[u] + pc * p.strideB, lds0 + (unsigned)(st * BX_STAGE + BX_OPER + pc * BX_PIECE + 4 * u * 1024));
       srcB[u] += stepB;
     }
   };
   auto issue = [&](int st) __attribute__((always_inline)) {  // the next not yet requested K tile into stage st
 #pragma unroll
-    for (int q = 0; q < 2 * NU; ++q) issue_part(st, q);
+    for (int q = 0; q < 4; ++q) issue_part(st, q);
   };
   // ---- one K tile of 16: 16 output tiles x NPROD bf16 MFMAs per wave; the smallest partial products go in first.
   // The B pieces of the wave's four column tiles stay in registers for the tile (48), the A pieces stream per row tile.
-  const unsigned fofsA = (unsigned)((wm * 4) * 1024 + h * 512 + r * 16), fofsB = (unsigned)((wn * NJ) * 1024 + h * 512 + r * 16);
+  const unsigned fofsA = (unsigned)((wm * 4) * 1024 + h * 512 + r * 16), fofsB = (unsigned)((wn * 4) * 1024 + h * 512 + r * 16);
   struct FragB {
-    bf16x8 v[3][NJ];
+    bf16x8 v[3][4];
   };
   struct FragA {
     bf16x8 v[3];
@@ -1212,7 +1193,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) f.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sB + pc * BX_PIECE + fofsB + j * 1024);
+      for (int j = 0; j < 4; ++j) f.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sB + pc * BX_PIECE + fofsB + j * 1024);
     return f;
   };
   auto load_a = [&](int st, int i) __attribute__((always_inline)) -> FragA {
@@ -1225,7 +1206,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   auto mfma_row = [&](auto iconst, const FragA &fa, const FragB &fb, auto &&between) __attribute__((always_inline)) {
     constexpr int i = decltype(iconst)::value;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < 4; ++j) {
       between(j);
 #if defined(BX_EXP) && BX_EXP == 5   // timing only (wrong numbers): the same flops on v_mfma_f32_16x16x32_bf16 -- the 32 x 32 block as
       // four 16 x 16 tiles, three instructions (two partial products fused along k) per tile and K tile
@@ -1328,17 +1309,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       // and 3 234.1 / 259.4 against 238.3 / 263.6 on that box.  The requests then have rows 0 and 1 of the next tile (48 MFMAs,
       // ~0.9 us) + what is left of row 3 to land before the mid-tile wait.
       const bool req = t + 2 < t1;
-#if defined(BX_STAGGER)   // experiment (round 6): the waves of a workgroup issue their requests in DIFFERENT rows, so that at most two of
-      // them load the CU's one address unit at a time.  1: odd waves row 2, even waves row 3;  2: waves 0, 1 row 2, waves 2, 3 row 3
-      const int wsel = __builtin_amdgcn_readfirstlane(BX_STAGGER == 1 ? (wave & 1) : (wave < 2));
-      mfma_row(J2{}, fa2, fb, [&](int j) __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (req && wsel) issue_part(st2, j);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-#else
       mfma_row(J2{}, fa2, fb, nothing);
-#endif
       // first fragments of tile t + 1: the B pieces of column tile j behind the MFMAs of column tile j - 1 of row 3
       {
         const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
@@ -1346,11 +1317,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
           __builtin_amdgcn_sched_barrier(0);
-#if defined(BX_STAGGER)
-          if (req && !wsel) issue_part(st2, j);
-#else
           if (req) issue_part(st2, j);
-#endif
           __builtin_amdgcn_sched_barrier(0);
         });
       }
@@ -1361,38 +1328,27 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     while (true) {
       const int tc = next_flush < t1 ? next_flush : t1;
       if constexpr (ASM && NPROD == 6) {
-        // every tile of the asm block requests tile t + 2: it runs up to the last two tiles of the pass, on an even number of
-        // tiles (the chain ends of this loop stay where they are)
-        int na = ((tc < t1 - 2 ? tc : t1 - 2) - t) & ~1;
+        // every tile of the asm block requests tile t + 2: it runs up to the last two tiles of the pass (the chain ends of this
+        // loop stay where they are)
+        // (a whole number of the block's trips AND of this loop's two-tile trips)
+        int na = (tc < t1 - 2 ? tc : t1 - 2) - t;
+        na -= na % (2 * BX_KLOOP_UNROLL);
         if (na > 0) {
           const unsigned fa_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx + fofsA;
           const unsigned fb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx + BX_OPER + fofsB;
           const int64_t strideA_b = 2 * p.strideA, strideB_b = 2 * p.strideB, stepA_b = 2 * stepA, stepB_b = 2 * stepB;
           __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the fragment sets of the C++ loop are not carried into the block)
-          if constexpr (NW == 4) {
-            __asm__ volatile(BX_KLOOP_TEXT
-                             : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
-                               "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),
-                               "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])
-                             : "v"(fa_lds), "v"(fb_lds), "v"(srcA[0]), "v"(srcA[NU - 1]), "v"(srcB[0]), "v"(srcB[NU - 1]), "s"(strideA_b),
-                               "s"(strideB_b), "s"(stepA_b), "s"(stepB_b), "s"(lds0), "s"(st), "s"(na), "s"(0)
-                             : BX_KLOOP_CLOB);
-          } else {
-            const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);   // waves 0-3 / 4-7: one of each per SIMD
-            __asm__ volatile(BX_KLOOP8_TEXT
-                             : "+a"(acc[0][0]), "+a"(acc[0][NJ - 1]), "+a"(acc[1][0]), "+a"(acc[1][NJ - 1]), "+a"(acc[2][0]), "+a"(acc[2][NJ - 1]),
-                               "+a"(acc[3][0]), "+a"(acc[3][NJ - 1])
-                             : "v"(fa_lds), "v"(fb_lds), "v"(srcA[0]), "v"(srcB[0]), "s"(strideA_b), "s"(strideB_b), "s"(stepA_b), "s"(stepB_b),
-                               "s"(lds0), "s"(st), "s"(na), "s"(grp)
-                             : BX_KLOOP8_ASM_CLOBBERS);
-          }
+          __asm__ volatile(BX_KLOOP_TEXT
+                           : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
+                             "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),
+                             "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])
+                           : "v"(fa_lds), "v"(fb_lds), "v"(srcA[0]), "v"(srcA[1]), "v"(srcB[0]), "v"(srcB[1]), "s"(strideA_b), "s"(strideB_b),
+                             "s"(stepA_b), "s"(stepB_b), "s"(lds0), "s"(st), "s"(na), "s"(0)
+                           : BX_KLOOP_CLOB);
           // the block leaves the request pointers na tiles further and the stage of the new tile t: redo both here (cheap,
           // and the operands above stay plain inputs -- 16 read-write accumulator operands already count twice)
-#pragma unroll
-          for (int u = 0; u < NU; ++u) {
-            srcA[u] += (int64_t)na * stepA;
-            srcB[u] += (int64_t)na * stepB;
-          }
+          srcA[0] += (int64_t)na * stepA; srcA[1] += (int64_t)na * stepA;
+          srcB[0] += (int64_t)na * stepB; srcB[1] += (int64_t)na * stepB;
           st = (st + na) % 3;
           t += na;
           fbX = load_b(st);
@@ -1443,34 +1399,26 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   // column-wise: lane r stores element (row r, col c) to C[col0 + c][row0 + r], 128 contiguous bytes per mirror row.
   auto flush_final = [&](bool first, bool mirror) __attribute__((always_inline)) {
     const float beta = first ? beta_ : 1.f;
-    // LDS of the dead stages.  Four waves: a ring of RING = 4 buffers of 8 KB per wave in the stages, the 32 x 32 patch behind
-    // them (16 KB).  Eight waves: patch (4 KB) + RING = 2 buffers per wave = 20 KB, 160 KB in all.
-    constexpr int RING = NW == 8 ? 2 : 4;
-    constexpr int NPAIR = 2 * NJ;           // pairs of accumulator tiles per wave
-    constexpr unsigned WREG = NW == 8 ? 20480u : 32768u;
-    float *ts = NW == 8 ? reinterpret_cast<float *>(smem_bx + wave * WREG) : reinterpret_cast<float *>(smem_bx + BX_PATCH_OFFSET) + wave * 1024;
-    const unsigned ring0 = NW == 8 ? 4096u : 0u;
+    float *ts = reinterpret_cast<float *>(smem_bx + BX_PATCH_OFFSET) + wave * 1024;
     const int rr = lane >> 3, c4 = lane & 7;
     int opaque = 0;
     __asm__ volatile("" : "+v"(opaque));
-    gptr cwave = Cout + (row0 + wm * 128 + rr + opaque) * ldc + (col0 + wn * (32 * NJ) + 4 * c4);
+    gptr cwave = Cout + (row0 + wm * 128 + rr + opaque) * ldc + (col0 + wn * 128 + 4 * c4);
     const bool pre = beta != 0.f;
-    const unsigned oldb = __builtin_amdgcn_readfirstlane(lds0 - (unsigned)(wave * 1024) + (unsigned)wave * WREG + ring0);   // this wave's ring
-    const unsigned char *oldp = smem_bx + wave * WREG + ring0 + lane * 16;
-    auto issue_pair = [&](int k) __attribute__((always_inline)) {   // old values of tiles 2 k, 2 k + 1 into buffer k % RING
+    const unsigned oldb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * (32768 - 1024)));   // this wave's 4 x 8 KB of the stages
+    const unsigned char *oldp = smem_bx + wave * 32768 + lane * 16;
+    auto issue_pair = [&](int k) __attribute__((always_inline)) {   // old values of tiles 2 k, 2 k + 1 into buffer k & 3
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int u = 2 * k + t;
-          dma16b((gcptr16)(const void __attribute__((address_space(1))) *)(cwave + (int64_t)((u / NJ) * 32 + 8 * it) * ldc + (u % NJ) * 32),
-                 oldb + (unsigned)((k % RING) * 8192 + t * 4096 + it * 1024));
+          dma16b((gcptr16)(const void __attribute__((address_space(1))) *)(cwave + (int64_t)((u >> 2) * 32 + 8 * it) * ldc + (u & 3) * 32),
+                 oldb + (unsigned)((k & 3) * 8192 + t * 4096 + it * 1024));
         }
     };
     auto wait_vm = [](int n) __attribute__((always_inline)) {
       switch (n) {
-        case 0: __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 8: __asm__ volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 16: __asm__ volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
         case 24: __asm__ volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
         case 32: __asm__ volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
@@ -1482,26 +1430,16 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     if (pre) {
       // earlier chains of this tile may have been added into C by L2 atomics: the DMA must not be served from a stale L1 line
       if (!first) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-      for (int k = 0; k < RING - 1; ++k) issue_pair(k);
+      issue_pair(0); issue_pair(1); issue_pair(2);
     }
 #pragma unroll
-    for (int k = 0; k < NPAIR; ++k) {
+    for (int k = 0; k < 8; ++k) {
       if (pre) {
         // operations issued after the requests of pair k: the later requests (8 each) and the stores of the pairs in
-        // between (8 per pair, + 32 mirror stores); vmcnt counts in issue order.  Pair k < RING - 1 went out up front (behind it:
-        // the rest of the prologue, then per finished pair its stores and one more request group); pair k >= RING - 1 went out
-        // behind the stores of pair k - RING + 1.
+        // between (8 per pair, + 32 mirror stores); vmcnt counts in issue order
         const int S = mirror ? 40 : 8;
-        int after;
-        if (k < RING - 1) {
-          after = 8 * (RING - 2 - k) + k * S;
-          for (int q = 0; q < k; ++q) after += (RING - 1 + q < NPAIR) ? 8 : 0;
-        } else {
-          after = (RING - 2) * S;
-          for (int q = k + 1; q <= k + RING - 2; ++q) after += q < NPAIR ? 8 : 0;
-        }
-        wait_vm(after < 8 ? 0 : after < 16 ? 8 : after < 24 ? 16 : after < 32 ? 24 : after < 56 ? 32 : after < 63 ? 56 : 63);
+        const int after = k == 0 ? 16 : k == 1 ? 16 + S : k < 6 ? 16 + 2 * S : k == 6 ? 8 + 2 * S : 2 * S;
+        wait_vm(after < 24 ? 16 : after < 32 ? 24 : after < 56 ? 32 : after < 63 ? 56 : 63);
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -1510,7 +1448,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-          ts[row * 32 + (r ^ ((row & 7) << 2))] = acc[u / NJ][u % NJ][e];
+          ts[row * 32 + (r ^ ((row & 7) << 2))] = acc[u >> 2][u & 3][e];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -1518,13 +1456,13 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
           float *tp = ts + (8 * it + rr) * 32 + 4 * (c4 ^ (rr & 7));
           f32x4 v = *reinterpret_cast<const f32x4 *>(tp);
           v = alpha_ * v;
-          if (pre) v += beta * *reinterpret_cast<const f32x4 *>(oldp + (k % RING) * 8192 + t * 4096 + it * 1024);
-          *(gptr4w)(cwave + (int64_t)((u / NJ) * 32 + 8 * it) * ldc + (u % NJ) * 32) = v;
+          if (pre) v += beta * *reinterpret_cast<const f32x4 *>(oldp + (k & 3) * 8192 + t * 4096 + it * 1024);
+          *(gptr4w)(cwave + (int64_t)((u >> 2) * 32 + 8 * it) * ldc + (u & 3) * 32) = v;
           if (mirror) *reinterpret_cast<f32x4 *>(tp) = v;
         }
         if (mirror) {   // transposed copy of tile u = (i, j)
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          gptr mbase = (gptr)p.C + (col0 + wn * (32 * NJ) + (u % NJ) * 32 + h) * p.ldc + (row0 + wm * 128 + (u / NJ) * 32 + r);
+          gptr mbase = (gptr)p.C + (col0 + wn * 128 + (u & 3) * 32 + h) * p.ldc + (row0 + wm * 128 + (u >> 2) * 32 + r);
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int col = 2 * q + h;
@@ -1532,9 +1470,9 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
           }
         }
       }
-      if (pre && k + RING - 1 < NPAIR) {
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads of buffer (k + RING - 1) % RING == (k - 1) % RING are done
-        issue_pair(k + RING - 1);
+      if (pre && k + 3 < 8) {
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads of buffer (k + 3) & 3 == (k - 1) & 3 are done
+        issue_pair(k + 3);
       }
     }
   };
@@ -1559,12 +1497,12 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int j = 0; j < 4; ++j) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int e = 0; e < 16; ++e) ts[r * 33 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[i][j][e];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int64_t mrow0 = col0 + wn * (32 * NJ) + j * 32;
+        const int64_t mrow0 = col0 + wn * 128 + j * 32;
         const int64_t mcol = row0 + wm * 128 + i * 32 + r;
 #pragma unroll
         for (int rr = 0; rr < 32; rr += 2) {
@@ -2368,25 +2306,20 @@ struct BxStrictScope {
 };
 
 #ifndef BX_ASM_DEFAULT
-#define BX_ASM_DEFAULT 0
+#define BX_ASM_DEFAULT 1
 #endif
-// VIVIT_BX_ASM = 0: the C++ K loop (the reference implementation); 4 (or 1): the hand-scheduled loop on the same four waves of
-// 128 x 128 (gemm256_bx_kernel<6, true, 4>); 8: eight waves of 128 x 64, two per SIMD (gemm256_bx_kernel<6, true, 8>)
-static int bx_asm_mode() {
-  static int mode = -1;
-  if (mode < 0) {
+// VIVIT_BX_ASM=1 / 0: the hand-scheduled K loop (gemm256_bx_kernel<6, true>) or the C++ loop (the reference implementation)
+static bool bx_asm_enabled() {
+  static int on = -1;
+  if (on < 0) {
     const char *e = getenv("VIVIT_BX_ASM");
-    const int v = e ? atoi(e) : BX_ASM_DEFAULT;
-    mode = v == 8 ? 8 : v != 0 ? 4 : 0;
+    on = e ? (atoi(e) != 0) : BX_ASM_DEFAULT;
   }
-  return mode;
+  return on != 0;
 }
 static void bx_launch6(dim3 grid, const GemmBxArgs &q, hipStream_t stream) {
-  const int mode = bx_asm_mode();
-  if (mode == 8)
-    gemm256_bx_kernel<6, true, 8><<<grid, 512, GEMM256BX_LDS_BYTES, stream>>>(q);
-  else if (mode == 4)
-    gemm256_bx_kernel<6, true, 4><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
+  if (bx_asm_enabled())
+    gemm256_bx_kernel<6, true><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
   else
     gemm256_bx_kernel<6><<<grid, 256, GEMM256BX_LDS_BYTES, stream>>>(q);
 }
@@ -2403,9 +2336,8 @@ static bool gemm256_attrs() {
                             reinterpret_cast<const void *>(gemm256_kernel<LAY_M, LAY_M>)};
       for (const void *f : fns)
         if (!ensure_dynamic_lds(f, GEMM256_LDS_BYTES, attr_done)) return false;
-      const void *bx[5] = {reinterpret_cast<const void *>(gemm256_bx_kernel<3>), reinterpret_cast<const void *>(gemm256_bx_kernel<6>),
-                           reinterpret_cast<const void *>(gemm256_bx_kernel<9>), reinterpret_cast<const void *>(gemm256_bx_kernel<6, true, 4>),
-                           reinterpret_cast<const void *>(gemm256_bx_kernel<6, true, 8>)};
+      const void *bx[4] = {reinterpret_cast<const void *>(gemm256_bx_kernel<3>), reinterpret_cast<const void *>(gemm256_bx_kernel<6>),
+                           reinterpret_cast<const void *>(gemm256_bx_kernel<9>), reinterpret_cast<const void *>(gemm256_bx_kernel<6, true>)};
       for (const void *f : bx)
         if (!ensure_dynamic_lds(f, GEMM256BX_LDS_BYTES, attr_done)) return false;
       attr_done |= 1ull << (dev & 63);

@@ -1,1 +1,1 @@
-const char *vivit_hip_source_hash(void) { return "3d3f5573b26968bead646a9443d6df3e-262e1d34"; }
+const char *vivit_hip_source_hash(void) { return "6b57c65382a235c4bab3fd20043479bb-262e1d34"; }

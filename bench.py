@@ -973,7 +973,12 @@ def main():
             "value": value,
             "unit": "eigenpairs/s",
             "n_gpus": world_info["distinct_devices"],   # GPUs, not ranks: two gloo ranks on one card are ONE GPU (world.world_size says 2)
-            "world": world_info,
+            "world": dict(world_info, eigensolver=(
+                {"band_reduction": "sharded by block rows (vivit_amd.distributed.sy2sb_sharded_)", "collectives_per_solve": dict(vdist.LAST_SHARDED_COLLECTIVES),
+                 "note": "all_gather: one per panel on the critical path; broadcast: the next panel's block row, asynchronous; NOT measured on more "
+                         "than one GPU by the builder (no multi-GPU node): scaling is unmeasured"}
+                if vdist.LAST_SHARDED_COLLECTIVES and world > 1 else
+                {"band_reduction": "replicated" if world > 1 else "single GPU", "collectives_per_solve": {"all_gather": 1} if (world > 1 and vectors) else {}})),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

@@ -286,6 +286,20 @@ def _worker_sharded_band(rank, world, port, ret):
         tau1_solo = vd.sy2sb_sharded_(A1, solo)
         band = lambda X: torch.tril(X) - torch.tril(X, -65)   # noqa: E731
         ok[f"band{n}"] = bool((band(A) - band(A1)).abs().max() <= 2e-5 * scale) and bool((tau1 - tau1_solo).abs().max() <= 1e-5)
+        # one collective per panel on the critical path (the all-gather of P); the next block row travels beside it
+        nblk = -(-n // 64)
+        vd.sy2sb_sharded_(S.clone(), None if world == 1 else dist.group.WORLD)
+        ok[f"count{n}"] = vd.LAST_SHARDED_COLLECTIVES == {"all_gather": nblk - 1, "broadcast": nblk, "total": 2 * nblk - 1}
+    # the default policy: sharded from SHARDED_BAND_MIN_RANKS ranks and SHARDED_BAND_MIN_N rows on
+    vd.LAST_SHARDED_COLLECTIVES.clear()
+    S = torch.randn(200, 200, generator=torch.Generator().manual_seed(1))
+    S = (S + S.T) / 2
+    vd.symeig(S)                                                   # 200 < 8192: replicated reduction
+    ok["default_small_replicated"] = not vd.LAST_SHARDED_COLLECTIVES
+    vd.SHARDED_BAND_MIN_N, vd.SHARDED_BAND_MIN_RANKS = 192, world
+    w, _ = vd.symeig(S)
+    ok["default_sharded"] = vd.LAST_SHARDED_COLLECTIVES.get("all_gather") == 3 and bool(
+        (w.double() - torch.linalg.eigvalsh(S.double())).abs().max() <= 2e-5 * float(S.abs().max()) * 20)
     ret[rank] = ok
     dist.destroy_process_group()
 

@@ -119,13 +119,15 @@ def test_slide_refuses_unaligned_shapes():
     assert torch.isfinite(out).all()
 
 
-@pytest.mark.parametrize("waves,loaders", [(5, 0), (11, 0), (12, 0), (5, 2), (10, 2)])
-def test_slide_wave_configurations(tmp_path, waves, loaders):
+@pytest.mark.parametrize("waves,loaders,lockstep", [(5, 0, None), (11, 0, None), (12, 0, None), (5, 2, None), (10, 2, None), (10, 2, 0), (5, 2, 1), (8, 1, 64)])
+def test_slide_wave_configurations(tmp_path, waves, loaders, lockstep):
     """the self-load path of qs_apply_kernel (no loader waves: LOADERS=0, or more than ten compute waves --
     which the product only takes for > 160 rows per CU, i.e. nrows > 40 960 or a CU-masked partition) has hand-counted
     s_waitcnt vmcnt(4) waits that no test reached.  Child processes (the knobs are read once per process) force 5 / 11 / 12
     compute waves without loaders, and two loader configurations for comparison: against the fp64 sequential reflectors,
-    against the block-step kernels, orthonormality, bit-reproducibility."""
+    against the block-step kernels, orthonormality, bit-reproducibility.  Round 6: the loaders of an XCD keep in lock-step through
+    a progress board (VIVIT_Q2_LOCKSTEP = window in blocks, default 4): off, the tightest window and a loose one must give the
+    same results -- the throttle only delays image requests."""
     import json
     import os
     import subprocess
@@ -134,7 +136,8 @@ def test_slide_wave_configurations(tmp_path, waves, loaders):
     here = os.path.dirname(os.path.abspath(__file__))
     out = tmp_path / "q2.json"
     subprocess.run([sys.executable, os.path.join(here, "q2_slide_child.py"), str(out)], check=True, timeout=600,
-                   env=dict(os.environ, VIVIT_Q2_SLIDE_WAVES=str(waves), VIVIT_Q2_SLIDE_LOADERS=str(loaders)))
+                   env=dict(os.environ, VIVIT_Q2_SLIDE_WAVES=str(waves), VIVIT_Q2_SLIDE_LOADERS=str(loaders),
+                            **({} if lockstep is None else {"VIVIT_Q2_LOCKSTEP": str(lockstep)})))
     res = json.loads(out.read_text())
     for key, row in res["sequential"].items():
         assert row["block"] <= 3e-6 and row["slide"] <= 3e-6, (key, row)

@@ -1,1 +1,1 @@
-const char *vivit_hip_source_hash(void) { return "6b57c65382a235c4bab3fd20043479bb-262e1d34"; }
+const char *vivit_hip_source_hash(void) { return "d4400c529f912db1d03f276a7cb0dbb5-262e1d34"; }

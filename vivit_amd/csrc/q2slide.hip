@@ -347,6 +347,12 @@ struct QsArgs {
   int64_t ldz;
   int nrows, n, G0, K0, K1;
   int nload;   // loader waves behind the compute waves of a workgroup (0: the compute waves request the images themselves)
+  // per-XCD progress board (round 6, VIVIT_Q2_LOCKSTEP = window in blocks, 0 = off): [8 XCDs][64 ints] = {arrival counter, ..,
+  // [32 + slot]: the block a workgroup's loader is about to request + 1 (0: not started, INT_MAX: done)}.  A loader that is more
+  // than `window` blocks ahead of the slowest running workgroup of ITS XCD waits (bounded) before requesting: the 32 CUs of an
+  // XCD then pull a block image while it is still in their 4 MiB L2 instead of once per CU from the fabric.
+  int *board;
+  int window;
 };
 
 // six partial products, smallest first (A pieces ah/am/al, B pieces bh/bm/bl)
@@ -522,14 +528,55 @@ __global__ __launch_bounds__(64 * MAXW) void qs_apply_kernel(QsArgs a) {
         __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(d), "v"(lane16), "s"(src) : "memory");
       }
     };
+    // lock-step of an XCD's loaders (loader wave 0 of every workgroup; see QsArgs::board)
+    const bool pace = a.window > 0 && a.board != nullptr && lw == 0;
+    int *mine = nullptr, *peers = nullptr;
+    if (pace) {
+      int xcc;
+      __asm__ volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      int *xb = a.board + (xcc & 7) * 64;
+      int slot = 0;
+      if (lane == 0) slot = __hip_atomic_fetch_add(xb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 31;
+      slot = __builtin_amdgcn_readfirstlane(slot);
+      mine = xb + 32 + slot;
+      peers = xb + 32 + (lane & 31);
+    }
     if (nseq > 0) request(0);
     for (int64_t seq = 0; seq < nseq; ++seq) {
+      int slowest = 0x7fffffff;
+      if (pace) {
+        // publish "about to request block seq + 1" and look at the peers -- the load is in flight while this wave waits for
+        // its image and for the compute waves: nothing is added to the block's critical path
+        if (lane == 0) __hip_atomic_store(mine, (int)seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int v = __hip_atomic_load(peers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slowest = v == 0 ? 0x7fffffff : v;
+      }
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of image seq have landed
 #if !QS_NO_SYNC
       __builtin_amdgcn_s_barrier();                           // ... everybody's; and every wave is done with image seq - 1
 #endif
+      if (pace) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          const int other = __shfl_xor(slowest, o, 64);
+          slowest = other < slowest ? other : slowest;
+        }
+        // ahead of the slowest running workgroup of this XCD by more than the window: wait for it, at most ~16 us per block
+        // (a peer that is descheduled or stuck must not stop this slab: the throttle is best effort)
+        for (int tries = 0; tries < 16 && (int)seq + 2 - slowest > a.window; ++tries) {
+          __builtin_amdgcn_s_sleep(100);
+          const int v = __hip_atomic_load(peers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          slowest = v == 0 ? 0x7fffffff : v;
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            const int other = __shfl_xor(slowest, o, 64);
+            slowest = other < slowest ? other : slowest;
+          }
+        }
+      }
       if (seq + 1 < nseq) request(seq + 1);
     }
+    if (pace && lane == 0) __hip_atomic_store(mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
@@ -718,6 +765,13 @@ static int qs_chunk_passes(int G0, int K0, int Kend, size_t bytes) {
 }
 
 constexpr size_t QS_WS_TARGET = (size_t)2 << 30;   // images of ~2 GB per chunk of passes
+// default window of the loaders' lock-step (QsArgs::board).  Measured at n = 40 960 (scripts/r06_q2_lockstep_pmc.sh,
+// profiles/r06_q2_lockstep_pmc.log), window -> ms / FETCH_SIZE per two solves: off 1224.7 / 2.518e9 KiB; 2: 1200.6 / 1.201e9; 4: 1207.5 /
+// 1.232e9; 8: 1210.2 / 1.289e9; 16: 1204.5 / 1.369e9; 128: 1266 -- half of the kernel's fabric traffic was block images fetched once
+// per CU instead of once per XCD; the time follows only by 1.5-2 % (the kernel is bound by its MFMA chains and the L2 -> LDS stream).
+#ifndef QS_LOCKSTEP_DEFAULT
+#define QS_LOCKSTEP_DEFAULT 4
+#endif
 
 size_t q2_slide_workspace_bytes(int64_t n) {
   if (n < 3) return 0;
@@ -725,7 +779,7 @@ size_t q2_slide_workspace_bytes(int64_t n) {
   // all images, at most ~2 GB of them at a time, at least the first pass (the longest): 2 G0 + 2 blocks
   const size_t all = (size_t)qs_pass_offset(G0, 0, G0 / 2 + 1) * QS_IMG, one = (size_t)(2 * G0 + 2) * QS_IMG;
   const size_t cap = all < QS_WS_TARGET ? all : QS_WS_TARGET;
-  return (one > cap ? one : cap) + 2048;
+  return (one > cap ? one : cap) + 2048 + 4096;   // (+ the loaders' progress board)
 }
 
 static int qs_env(const char *name, int dflt) {
@@ -765,7 +819,11 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     }
   }
   unsigned char *img = reinterpret_cast<unsigned char *>(align_up(reinterpret_cast<uintptr_t>(ws), 1024));
-  const size_t img_bytes = ws_bytes - (size_t)(img - reinterpret_cast<unsigned char *>(ws));
+  // the last 2 KB (8 XCDs x 64 ints) of the workspace: the loaders' progress board, zeroed in front of every launch
+  int *board = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(ws) + ws_bytes - 2048) & ~(uintptr_t)255);
+  const size_t img_bytes = (size_t)(reinterpret_cast<unsigned char *>(board) - img);
+  static int window = -1;
+  if (window < 0) window = qs_env("VIVIT_Q2_LOCKSTEP", QS_LOCKSTEP_DEFAULT);
   const int G0 = (int)((n - 2) / 64);
   const int Kend = G0 / 2 + 1;   // passes K with gmax(K) = G0 - 2K >= 0
   // waves per workgroup (16 rows each): one slab per CU when the rows allow it, at most 12 waves (168 registers)
@@ -786,6 +844,8 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
   pa.R2 = R2; pa.ldr = ldr; pa.tau2 = tau2; pa.nk = sb2st_num_levels(n); pa.n = (int)n; pa.G0 = G0; pa.img = img;
   QsArgs aa;
   aa.img = img; aa.Zt = Zt; aa.ldz = ldz; aa.nrows = (int)nrows; aa.n = (int)n; aa.G0 = G0; aa.nload = nload;
+  aa.board = (window > 0 && nload > 0) ? board : nullptr;
+  aa.window = window;
   for (int K0 = 0; K0 < Kend;) {
     const int K1 = qs_chunk_passes(G0, K0, Kend, img_bytes);
     if (K1 == K0) return VIVIT_E_WORKSPACE;
@@ -793,6 +853,7 @@ int q2_slide_launch(float *Zt, int64_t ldz, int64_t nrows, int64_t n, const floa
     const dim3 pgrid((unsigned)(2 * (G0 - 2 * K0) + 2), (unsigned)(K1 - K0));
     qs_prepare_kernel<<<pgrid, 256, QS_PREP_LDS, stream>>>(pa);
     aa.K0 = K0; aa.K1 = K1;
+    if (aa.board && hipMemsetAsync(aa.board, 0, 2048, stream) != hipSuccess) return VIVIT_E_LAUNCH;
     if (nwt <= 8) qs_apply_kernel<8><<<nslab, 64 * nwt, QS_APPLY_LDS, stream>>>(aa);
     else qs_apply_kernel<12><<<nslab, 64 * nwt, QS_APPLY_LDS, stream>>>(aa);
     K0 = K1;

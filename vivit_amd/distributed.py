@@ -467,10 +467,28 @@ def backproject_sum(coef: torch.Tensor, V_local: torch.Tensor, acc: BatchSharded
     return out.view(K, *V_local.shape[2:])
 
 
-# Smallest n whose band reduction is sharded by default; None = never (the prototype issues its two collectives per panel from
-# Python: at R = 8 its projected time equals the replicated reduction's, and no multi-GPU node could measure it -- so it is
-# opt-in: ``symeig(..., sharded_reduction=True)`` or VIVIT_SHARDED_BAND_MIN_N=<n> in the environment).
-SHARDED_BAND_MIN_N = int(_os.environ["VIVIT_SHARDED_BAND_MIN_N"]) if _os.environ.get("VIVIT_SHARDED_BAND_MIN_N") else None
+# The band reduction is sharded by default when at least SHARDED_BAND_MIN_RANKS ranks hold a matrix of at least
+# SHARDED_BAND_MIN_N rows (VIVIT_SHARDED_BAND_MIN_N / VIVIT_SHARDED_BAND_MIN_RANKS; ``symeig(..., sharded_reduction=...)`` decides
+# per call).  Below that the replicated reduction wins: every panel costs one collective on the critical path and ~25 small
+# launches from Python, while the sharded passes over the trailing matrix only save (R - 1) / R of 0.55 s at n = 40 960.
+# NOT MEASURED on more than one GPU (no node): the thresholds follow the projection in DESIGN.md section 6.
+SHARDED_BAND_MIN_N = int(_os.environ.get("VIVIT_SHARDED_BAND_MIN_N", "8192"))
+SHARDED_BAND_MIN_RANKS = int(_os.environ.get("VIVIT_SHARDED_BAND_MIN_RANKS", "4"))
+# collectives issued by the last sy2sb_sharded_ call of this process: {"all_gather": on the critical path, one per panel;
+# "broadcast": the next panel's stale block row, asynchronous, off the critical path; "total"} -- bench.py reports it
+LAST_SHARDED_COLLECTIVES = {}
+
+
+def _bcast_async(t: torch.Tensor, src: int, group):
+    """Broadcast ``t`` from group rank ``src``; returns a handle whose ``wait()`` orders the current stream behind it (RCCL runs
+    it on its own stream: the caller keeps queueing work that does not need ``t``).  gloo + device tensors: staged, synchronous."""
+    if not _active(group):
+        return _Done()
+    if _staged(t, group) or dist.get_backend(group) == "gloo":
+        broadcast_(t, src, group)
+        return _Done()
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
+    return dist.broadcast(t, gsrc, group=group, async_op=True)
 
 
 def sy2sb_sharded_(A: torch.Tensor, group=None) -> torch.Tensor:
@@ -483,103 +501,111 @@ def sy2sb_sharded_(A: torch.Tensor, group=None) -> torch.Tensor:
     trailing matrix shrinks) and, the matrix being symmetric and stored in full, a rank's rows ARE its block columns.
     Panel ``p`` (the reference has no counterpart: ``Tensor.symeig`` is one LAPACK call, vivit/linalg/eigh.py:248-250):
 
-      1. the owner of row block ``p`` broadcasts it (``64 x (n - j0)`` floats: the diagonal block and, transposed, the
-         panel); every rank factors the panel itself (``vivit_sy2sb_panel_qr_f32``: same kernels, same data --
-         bit-identical ``V``, ``T`` everywhere, nothing else to exchange) and files band entries and reflectors;
-      2. ``P = A22 V``: every rank multiplies its own rows (``1/R`` of the streamed panel product), one all-gather
-         of ``mp x 64`` floats puts ``P`` together;
+      0. (off the critical path) the owner of row block ``p + 1`` broadcasts it AS IT IS NOW -- stale with respect to panel
+         ``p`` -- asynchronously; it lands while the steps below run;
+      1. every rank factors panel ``p`` itself from block row ``p`` (``vivit_sy2sb_panel_qr_f32``: same kernels, same data
+         -- bit-identical ``V``, ``T`` everywhere) and files band entries and reflectors;
+      2. ``P = A22 V``: every rank multiplies its own rows (``1/R`` of the streamed panel product); ONE all-gather of
+         ``mp / R x 64`` floats puts ``P`` together -- the panel's only collective on the critical path;
       3. ``W = X - V (T^T (V^T X)) / 2`` with ``X = P T`` -- four 64-wide products, replicated;
-      4. ``A22 -= V W^T + W V^T`` on the own rows only (``1/R`` of the rank-128 update), no communication.
+      4. ``A22 -= V W^T + W V^T`` on the own rows only (``1/R`` of the rank-128 update), no communication;
+      5. every rank applies the same update to the stale block row of step 0 (a 64 x mp x 128 product, replicated): that IS
+         block row ``p + 1`` as panel ``p + 1`` needs it -- round 5 broadcast it after step 4, a second collective per panel
+         on the critical path.
 
-    Two collectives per panel.  Replicated per rank: the panel QR (its launch chain is the part of the single-GPU band
-    reduction that does not shrink) and the small products; sharded: the two passes over the trailing matrix
-    (0.43 s + 0.34 s of 1.27 s at n = 40 960 on one GPU)."""
+    Row sets are whole 64-row blocks in rank-cyclic order, so "rank r's rows of the trailing matrix" is a strided view of a
+    block-padded buffer: no index tensors, ~25 launches per panel.  Replicated per rank: the panel QR and the 64-wide
+    products; sharded: the two passes over the trailing matrix (0.30 s + 0.26 s of 0.94 s at n = 40 960 on one GPU)."""
     NB = kernels.BAND_NB
     n = A.shape[0]
     R, q = world_size(group), rank_of(group)
     nblk = -(-n // NB)
     dev = A.device
-    my_blocks = list(range(q, nblk, R))
-    rows_idx = torch.cat([torch.arange(b * NB, min((b + 1) * NB, n), device=dev) for b in my_blocks]) if my_blocks else \
-        torch.empty(0, dtype=torch.long, device=dev)
-    Aloc = A.index_select(0, rows_idx).contiguous()            # [n_loc, n]: the own rows (= block columns)
-    tau1 = torch.zeros(n, dtype=torch.float32, device=dev)
+    f32 = torch.float32
+    count = {"all_gather": 0, "broadcast": 0}
+    # own rows, whole blocks: local block k holds global block q + k R (the last global block may be short: zero rows below it)
+    nloc = len(range(q, nblk, R))
+    Aloc = torch.zeros((nloc * NB, n), dtype=f32, device=dev)
+    for k, b in enumerate(range(q, nblk, R)):
+        rows = min((b + 1) * NB, n) - b * NB
+        Aloc[k * NB:k * NB + rows] = A[b * NB:b * NB + rows]
+    tau1 = torch.zeros(n, dtype=f32, device=dev)
+
+    def block_row(b, j0):
+        """Block row b from column j0 on, from its owner's rows (zero elsewhere): [rows of block b, n - j0]."""
+        rows = min((b + 1) * NB, n) - b * NB
+        t = torch.zeros((rows, n - j0), dtype=f32, device=dev)
+        if q == b % R:
+            t.copy_(Aloc[(b // R) * NB:(b // R) * NB + rows, j0:])
+        return t
+
+    Bt = block_row(0, 0)
+    broadcast_(Bt, 0, group)
+    count["broadcast"] += 1
     gi_last = None
     for p in range(nblk):
         j0, gi = p * NB, (p + 1) * NB
         mp = n - gi
         if mp <= 0:
             break
-        owner = p % R
-        # ---- 1. row block p from its owner: [D | panel^T]
-        Bt = torch.empty((NB, n - j0), dtype=torch.float32, device=dev)
-        if q == owner:
-            lb = p // R
-            Bt.copy_(Aloc[lb * NB:(lb + 1) * NB, j0:])
-        broadcast_(Bt, owner, group)
-        pan = Bt[:, NB:].t().contiguous()                         # [mp, 64]
+        nb_live = -(-mp // NB)                                     # blocks p + 1 .. nblk - 1
+        # ---- 0. the next block row, stale, on its way while this panel is worked on
+        stale = block_row(p + 1, gi)
+        handle = _bcast_async(stale, (p + 1) % R, group)
+        count["broadcast"] += 1
+        # ---- 1. panel QR (replicated) on block row p = [D | panel^T]
+        pan = Bt[:, NB:].t().contiguous()                          # [mp, 64]
         Vt, tau, betas, T = kernels.panel_qr_(pan)
-        A[j0:gi, j0:gi] = Bt[:, :NB]                              # diagonal block of the band
+        A[j0:gi, j0:gi] = Bt[:, :NB]                               # diagonal block of the band
         top = min(NB, mp)
         A[gi:gi + top, j0:gi] = torch.triu(pan[:top], 1) + torch.diag(betas)[:top]   # R: the sub-diagonal block of the band
-        A[j0:gi, gi:] = Vt                                        # reflector rows (dead upper triangle)
+        A[j0:gi, gi:] = Vt                                         # reflector rows (dead upper triangle)
         tau1[j0:gi] = tau
-        # ---- 2. P = A22 V on the own live rows, all-gather
-        lb0 = 0 if p < q else (p - q) // R + 1                    # own blocks with global index <= p are finished
-        live = Aloc[lb0 * NB:, gi:]                               # [nl, mp] view (row stride n)
+        # ---- 2. P = A22 V on the own live blocks, one all-gather
+        lb0 = 0 if p < q else (p - q) // R + 1                     # own blocks with global index <= p are finished
+        live = Aloc[lb0 * NB:, gi:]                                # [nl, mp] view (row stride n); nl a multiple of 64
         nl = live.shape[0]
-        nl_max = _max_live_rows(n, NB, R, p)
-        send = torch.zeros((nl_max, NB), dtype=torch.float32, device=dev)
+        kmax = -(-(nblk - 1 - p) // R)                             # most live blocks any rank has
+        send = torch.zeros((kmax * NB, NB), dtype=f32, device=dev)
         if nl > 0:
             kernels.gemm_nt(live, Vt, out=send[:nl])
-        gathered = all_gather_cat(send, group).view(R, nl_max, NB)
-        P = torch.empty((mp, NB), dtype=torch.float32, device=dev)
+        gathered = all_gather_cat(send, group).view(R, kmax, NB, NB)
+        count["all_gather"] += 1
+        Ppad = torch.zeros((nb_live, NB, NB), dtype=f32, device=dev)          # P by blocks p + 1 .., padded to whole blocks
         for r in range(R):
-            idx = _live_rows(n, NB, R, r, p, dev)
-            if idx.numel():
-                P.index_copy_(0, idx - gi, gathered[r, : idx.numel()])
+            first = (r - (p + 1)) % R                                          # rank r's first live block, relative to block p + 1
+            cnt = len(range(first, nb_live, R))
+            if cnt:
+                Ppad[first::R] = gathered[r, :cnt]
+        P = Ppad.view(nb_live * NB, NB)[:mp]
         # ---- 3. W (replicated, 64-wide)
         X = kernels.gemm_nn(P, T)
         S2 = kernels.gemm_nn(Vt, X)
         Y = kernels.gemm_tn(T, S2)
-        W = kernels.gemm_tn(Vt, Y, out=X, alpha=-0.5, beta=1.0)   # W = X - V Y / 2
+        W = kernels.gemm_tn(Vt, Y, out=X, alpha=-0.5, beta=1.0)    # W = X - V Y / 2
+        Rm = torch.cat([W, Vt.t()], 1).contiguous()                # [mp, 128] = [W | V]
+        VW = torch.zeros((nb_live * NB, 2 * NB), dtype=f32, device=dev)       # [V | W] by blocks, padded to whole blocks
+        VW[:mp, :NB] = Vt.t()
+        VW[:mp, NB:] = W
         # ---- 4. own rows of the trailing matrix
         if nl > 0:
-            loc = rows_idx[lb0 * NB:] - gi
-            Lm = torch.cat([Vt.t().index_select(0, loc), W.index_select(0, loc)], 1).contiguous()   # [nl, 128] = [V_l | W_l]
-            Rm = torch.cat([W, Vt.t()], 1).contiguous()                                              # [mp, 128] = [W | V]
+            first = (q - (p + 1)) % R
+            Lm = VW.view(nb_live, NB, 2 * NB)[first::R].reshape(-1, 2 * NB)   # [nl, 128] = [V_l | W_l]
             kernels.gemm_nt(Lm, Rm, out=live, alpha=-1.0, beta=1.0)
+        # ---- 5. block row p + 1 for the next panel: the stale copy + this panel's update, on every rank
+        handle.wait()
+        rows = stale.shape[0]
+        kernels.gemm_nt(VW[:rows].contiguous(), Rm, out=stale, alpha=-1.0, beta=1.0)
+        Bt = stale
         gi_last = gi
     # ---- what is left of the trailing matrix (at most one block): the last diagonal block of the band
     if gi_last is not None and gi_last < n:
-        b = gi_last // NB
-        owner = b % R
         m = n - gi_last
-        Dl = torch.empty((m, m), dtype=torch.float32, device=dev)
-        if q == owner:
-            lb = b // R
-            Dl.copy_(Aloc[lb * NB:lb * NB + m, gi_last:])
-        broadcast_(Dl, owner, group)
-        A[gi_last:, gi_last:] = Dl
+        A[gi_last:, gi_last:] = Bt[:m, :m]
+    count["total"] = count["all_gather"] + count["broadcast"]
+    LAST_SHARDED_COLLECTIVES.clear()
+    LAST_SHARDED_COLLECTIVES.update(count)
     return tau1
-
-
-def _live_rows(n: int, NB: int, R: int, r: int, p: int, device) -> torch.Tensor:
-    """Global indices of rank ``r``'s rows in blocks ``b > p`` (its share of the trailing matrix of panel ``p``)."""
-    nblk = -(-n // NB)
-    blocks = [b for b in range(r, nblk, R) if b > p]
-    if not blocks:
-        return torch.empty(0, dtype=torch.long, device=device)
-    return torch.cat([torch.arange(b * NB, min((b + 1) * NB, n), device=device) for b in blocks])
-
-
-def _max_live_rows(n: int, NB: int, R: int, p: int) -> int:
-    nblk = -(-n // NB)
-    best = 1
-    for r in range(R):
-        rows = sum(min((b + 1) * NB, n) - b * NB for b in range(r, nblk, R) if b > p)
-        best = max(best, rows)
-    return best
 
 
 def symeig(G: torch.Tensor, group=None, overwrite: bool = False, sharded_reduction: Optional[bool] = None):
@@ -589,9 +615,9 @@ def symeig(G: torch.Tensor, group=None, overwrite: bool = False, sharded_reducti
     Every rank must hold the same ``G`` (e.g. the result of :func:`sharded_gram`).  Returns
     ``(evals [n], evecs [n, n])`` like ``kernels.symeig(G, eigenvectors=True)``; ``evecs`` is the
     transposed view of the gathered row-major eigenvector matrix (``evecs[:, i]`` contiguous).
-    ``sharded_reduction``: shard the full -> band reduction too (:func:`sy2sb_sharded_`); default: off unless
-    ``SHARDED_BAND_MIN_N`` is set and ``n`` reaches it.  Bulge chasing and the tridiagonal solve stay replicated (L2-resident, launch-free:
-    nothing to shard)."""
+    ``sharded_reduction``: shard the full -> band reduction too (:func:`sy2sb_sharded_`); default: on for at least
+    ``SHARDED_BAND_MIN_RANKS`` (4) ranks and ``n >= SHARDED_BAND_MIN_N`` (8192).  Bulge chasing and the tridiagonal solve stay
+    replicated (L2-resident, launch-free: nothing to shard)."""
     world = world_size(group)
     if _alone(world):
         return kernels.symeig(G, eigenvectors=True, overwrite=overwrite)
@@ -600,7 +626,7 @@ def symeig(G: torch.Tensor, group=None, overwrite: bool = False, sharded_reducti
     per = -(-n // world)
     lo, hi = row_slices(n, world)[rank]
     if sharded_reduction is None:
-        sharded_reduction = SHARDED_BAND_MIN_N is not None and n >= SHARDED_BAND_MIN_N
+        sharded_reduction = world >= SHARDED_BAND_MIN_RANKS and n >= SHARDED_BAND_MIN_N
     if sharded_reduction and n > 2 * kernels.BAND_NB:
         A = G if overwrite else G.clone()
         scal = kernels.symeig_prepare_(A)

@@ -46,7 +46,9 @@ SYRK_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * 3695931059.375 + 2766
 # Round 4 (profiles/r04_pmc/pmc_syrk_*, final code: one 4096-column chain per launch, 98 launches of each kernel): 4.76 TB
 # fetched / 0.83 TB written -- the workgroups of an XCD start every chain together and share their operand panels again.
 # Round 5 (profiles/r05_pmc/pmc_syrk_*, final code: the same 98 + 98 launches): 4.78 TB fetched / 0.83 TB written.
-SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.3010e9 + 3.2240e7) + (7.1264e8 + 9.6339e7)) * 1024.0}
+# Round 6 (profiles/r06_pmc/pmc_syrk_*, final code: the asm K loop, the same 98 + 98 launches): FETCH_SIZE 2.3295e9 + 3.2237e7 KiB,
+# WRITE_SIZE 7.9816e8 + 9.6339e7 KiB = 4.84 TB fetched (with the wide-read correction) / 0.92 TB written.
+SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.3295e9 + 3.2237e7) + (7.9816e8 + 9.6339e7)) * 1024.0}
 # clock the chip holds under that kernel, measured OUTSIDE this process (the product library carries no stamps):
 # in-kernel s_memtime / s_memrealtime stamps of a diagnostic build (scripts/probe/bx_clock.py + libstamp.so, median over
 # the 12 880 workgroups of the last chunk launch after 6 s of back-to-back SYRKs on the bench's own factors;
@@ -58,9 +60,13 @@ SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.3010e9 + 3.2240
 # (before the request placement, same round: 4.2170e10 / 8 over 2.951 s = 1.786 GHz, 73.6 %)
 # and on the benchmark's OWN first-layer factor (scripts/pmc_syrk_full.py bench; profiles/r05_pmc/pmc_syrk_mfma_bench_*): GRBM_GUI_ACTIVE 4.0224e10 / 8
 # over 2.520 s = 1.996 GHz, SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 = 77.1 % of the cycles: 267.3 TFLOP/s = 0.771 x 1.996 / 2.4 = 0.641 of the ceiling
-SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors": 1.862, "in_kernel_stamps_randn": 1.725,
-                                                  "pmc_grbm_gui_active_randn": 1.782, "pmc_grbm_gui_active_bench_factors": 1.996, "nominal": 2.4,
-                                                  "mfma_pipe_busy_pmc": 0.775, "mfma_pipe_busy_pmc_bench_factors": 0.771}}
+# round 6 (profiles/r06_pmc/pmc_syrk_mfma_*, profiles/r06_pmc_summary.txt; final code = the hand-scheduled K loop): N(0,1) data: GRBM_GUI_ACTIVE
+# 3.7763e10 / 8 over 2.771 s = 1.703 GHz, SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs = 82.1 % of the cycles; the bench's own factor:
+# 3.7714e10 / 8 over 2.403 s = 1.962 GHz, 82.3 %: 280.3 TFLOP/s = 0.823 x 1.962 / 2.4 = 0.672 of the ceiling (round 5: 77.1 % at 1.996 GHz = 0.641).
+# The pipe is busier (77 -> 82 %) and the chip answers with a lower clock (DVFS give-back): - 7 % cycles of the K loop are - 3.8 % of its time.
+SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors_k_loop": 1.9, "in_kernel_stamps_randn_k_loop": 1.7,
+                                                  "pmc_grbm_gui_active_randn": 1.703, "pmc_grbm_gui_active_bench_factors": 1.962, "nominal": 2.4,
+                                                  "mfma_pipe_busy_pmc": 0.821, "mfma_pipe_busy_pmc_bench_factors": 0.823}}
 # What the SAME per-K-tile instruction mix reaches with every byte of data movement removed (operand pieces in LDS once; no
 # DMA, barrier, flush): scripts/probe/bx_bare_loop.hip, profiles/r05_bx_bare_loop.log -- fraction of the bf16 / 6 ceiling and the
 # clock the chip holds, by operand data.  The power limit, not the kernel, takes the rest of the nominal peak.
@@ -81,12 +87,14 @@ WORKLOADS = {
 
 # the committed rocprofv3 outputs behind roofline.traffic / clock_ghz / clock_note (separate --pmc passes + kernel trace of the same command)
 PMC_FILES = {
-    "traffic": ["profiles/r05_pmc/pmc_syrk_FETCH_SIZE_counter_collection.csv", "profiles/r05_pmc/pmc_syrk_WRITE_SIZE_counter_collection.csv",
-                "profiles/r05_pmc/pmc_syrk_FETCH_SIZE_kernel_trace.csv", "profiles/r05_pmc/pmc_syrk_WRITE_SIZE_kernel_trace.csv"],
-    "clock_and_pipe_busy_randn": ["profiles/r05_pmc/pmc_syrk_mfma_counter_collection.csv", "profiles/r05_pmc/pmc_syrk_mfma_kernel_trace.csv"],
-    "clock_and_pipe_busy_bench_factor": ["profiles/r05_pmc/pmc_syrk_mfma_bench_counter_collection.csv", "profiles/r05_pmc/pmc_syrk_mfma_bench_kernel_trace.csv"],
-    "command": "scripts/r05_measure.sh (rocprofv3 --pmc <counter> --kernel-trace -- python3 scripts/pmc_syrk_full.py [bench])",
-    "kernel_trace_of_the_bench": "profiles/r05_bench_n40960_v7_kernel_stats.csv",
+    "traffic": ["profiles/r06_pmc/pmc_syrk_FETCH_SIZE_counter_collection.csv", "profiles/r06_pmc/pmc_syrk_WRITE_SIZE_counter_collection.csv",
+                "profiles/r06_pmc/pmc_syrk_FETCH_SIZE_kernel_trace.csv", "profiles/r06_pmc/pmc_syrk_WRITE_SIZE_kernel_trace.csv"],
+    "clock_and_pipe_busy_randn": ["profiles/r06_pmc/pmc_syrk_mfma_counter_collection.csv", "profiles/r06_pmc/pmc_syrk_mfma_kernel_trace.csv"],
+    "clock_and_pipe_busy_bench_factor": ["profiles/r06_pmc/pmc_syrk_mfma_bench_counter_collection.csv", "profiles/r06_pmc/pmc_syrk_mfma_bench_kernel_trace.csv"],
+    "summary": "profiles/r06_pmc_summary.txt (scripts/r06_pmc_summary.py over the passes above)",
+    "command": "scripts/r06_measure.sh (rocprofv3 --pmc <counter> --kernel-trace -- python3 scripts/pmc_syrk_full.py [bench])",
+    "kernel_trace_of_the_bench": "profiles/r06_bench_n40960_kernel_stats.csv",
+    "in_kernel_cycles_per_k_tile": "profiles/r06_bx_attribution_product.log (scripts/probe/bx_timeline.py on -DBX_STAMP=2 builds)",
 }
 
 
@@ -337,7 +345,7 @@ def _tune_threads(dims=(784, 512, 10), C=10, gram_batch=256, eig_n=5120):
     return best, {"affinity": affinity, "cpu_count": os.cpu_count(), "probe": table}
 
 
-def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256, 512), eig_batches=(512, 1024, 2048), repeats=3):
+def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256, 512), eig_batches=(512, 1024, 1600), repeats=3):
     """The oracle (CPU restatement of the reference algorithm) timed on this host on a bounded sample, both flavours
     the reference has for this MLP, never mixed:
       materialised -- einsum Gram over every parameter with the full 2 n^2 P work (vivit/utils/gram.py:230-232,
@@ -349,7 +357,7 @@ def cpu_baseline(dims, C, full_n, full_P, batches=(128, 256, 512), eig_batches=(
     sample: 2 n^2 P flop), eigh/eigvalsh at the larger ``eig_batches`` (on the same MLP's Gram matrix, built with the
     factorised form) because LAPACK only approaches its n^3 regime there.  The exponent of each phase is a least-squares
     FIT over its three sizes (never steeper than the flop count; the fit's worst residual is reported) and extrapolates the
-    largest sample -- n = 5120 for the Gram, n = 20 480 = half the full size for eigh -- to the full n (stated in ``sample``).
+    largest sample -- n = 5120 for the Gram, n = 16 000 for eigh -- to the full n (stated in ``sample``).
     Thread count tuned first (``_tune_threads``)."""
     from oracle import vivit_oracle as oracle
 
@@ -505,7 +513,7 @@ def _watch_ranks(procs, poll_s=0.5, grace_s=20.0):
 
 
 PANEL_EXCHANGE_US = 2.04        # one-XCD barrier + exchange (profiles/r03_grid_barrier_probe.log, mode 2)
-PANEL_LOCAL_LAUNCHES = 15       # dependent small launches per panel besides the QR (profiles/r05_bench_n40960_v7_kernel_stats.csv)
+PANEL_LOCAL_LAUNCHES = 15       # dependent small launches per panel besides the QR (profiles/r06_bench_n40960_kernel_stats.csv)
 DEPENDENT_LAUNCH_US = 3.0       # empty dependent kernel boundary (scripts/probe/launch_rate.hip: 3.0-3.3 us)
 VALU_F64_PEAK_TF = 78.6         # fp64 vector peak (MI355X_MICROARCH.md: 256 CUs x 128 flop/clk x 2.4 GHz)
 
@@ -532,7 +540,7 @@ def _stage_rooflines(stage_ms, n, steps, vectors, row_frac=1.0, split=0):
         # A LATENCY model, not a throughput one: the panel QR is a chain of 64 column steps per panel, each ending in an exchange
         # between the 32 workgroups of one XCD (2.04 us measured for barrier + exchange on one XCD: profiles/r03_grid_barrier_probe.log,
         # mode 2); around it a panel costs PANEL_LOCAL_LAUNCHES dependent small launches (T factor, coefficient products on 64-wide
-        # operands, load / store of the panel; count from profiles/r05_bench_n40960_v7_kernel_stats.csv) at 3.0 us per dependent
+        # operands, load / store of the panel; count from profiles/r06_bench_n40960_kernel_stats.csv) at 3.0 us per dependent
         # kernel boundary (scripts/probe/launch_rate.hip).  No look-ahead can shorten the chain: in a TWO-sided reduction panel
         # p + 1's columns need W_p, i.e. the complete streaming product A22 V_p (stage 9) of panel p.
         2: ("latency", (n / nb - 1) * (nb * PANEL_EXCHANGE_US + PANEL_LOCAL_LAUNCHES * DEPENDENT_LAUNCH_US) * 1e-6, "s"),
@@ -600,7 +608,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the parity check after the timed loop")
     ap.add_argument("--no-secondary", action="store_true", help="skip the values-only / top-10 secondary lines")
     ap.add_argument("--cpu-batches", default="128,256,512", help="batch sizes of the CPU baseline's einsum-Gram sample")
-    ap.add_argument("--cpu-eig-batches", default="512,1024,2048", help="batch sizes of the CPU baseline's eigh sample (n = 10 x batch)")
+    ap.add_argument("--cpu-eig-batches", default="512,1024,1600", help="batch sizes of the CPU baseline's eigh sample (n = 10 x batch; 2048 = "
+                    "half the full size costs 62 s for its one eigh and put the driver's run at 381 s; 1600: 31 s)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations (configs block)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="torch.distributed backend of a multi-rank run (default nccl = RCCL over xGMI; gloo: functional "
@@ -930,7 +939,7 @@ def main():
                 # split) per fp32 multiply-add, so the pipe's roofline for ALGORITHMIC fp32 flops is its peak / split
                 peak = MFMA_BF16_PEAK_TF / split
                 roofline = {
-                    "kernel": f"gemm256_bx_kernel<{split}> (Gram SYRK: fp32 operands split exactly into 3 bf16 pieces, {split} of 9 "
+                    "kernel": f"gemm256_bx_kernel<{split}, asm K loop> (Gram SYRK: fp32 operands split exactly into 3 bf16 pieces, {split} of 9 "
                               f"partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation) + bx_split_kernel",
                     "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "peak_note": f"dense bf16 MFMA peak {MFMA_BF16_PEAK_TF} TFLOP/s / {split} partial products per fp32 product; "
@@ -939,13 +948,13 @@ def main():
                     "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
                     "traffic": SYRK_BX_TRAFFIC_BYTES_PMC.get((args.workload, world)) if split == 6 else None,
                     "traffic_note": "bytes of the first-layer weight's SYRK (98.6 % of the Gram flops: 98 split + 98 product launches of "
-                                    "4096 columns) on N(0,1) data, separate rocprofv3 --pmc passes of the final code (profiles/r05_pmc/pmc_syrk_*: "
-                                    "FETCH_SIZE 2.3010e9 + 3.2240e7 KiB, WRITE_SIZE 7.1264e8 + 9.6339e7 KiB), FETCH_SIZE includes Infinity-Cache hits",
+                                    "4096 columns) on N(0,1) data, separate rocprofv3 --pmc passes of the final code (profiles/r06_pmc/pmc_syrk_*: "
+                                    "FETCH_SIZE 2.3295e9 + 3.2237e7 KiB, WRITE_SIZE 7.9816e8 + 9.6339e7 KiB), FETCH_SIZE includes Infinity-Cache hits",
                     "clock_ghz": SYRK_BX_CLOCK_GHZ.get((args.workload, world)) if split == 6 else None,
-                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.775) x (clock / 2.4 GHz); NOT "
-                                  "measured in this run: in-kernel stamps of a diagnostic build on the bench's own factors and on N(0,1) data "
-                                  "(profiles/r03_pmc/v3_bx_clock_*.txt, round-3 box), GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of a PMC pass over the 98 "
-                                  "launches of the first-layer SYRK on N(0,1) data and on the bench's own factor (profiles/r05_pmc/pmc_syrk_mfma_*, round-5 boxes)",
+                    "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.82) x (clock / 2.4 GHz); NOT "
+                                  "measured in this run: in-kernel stamps of a diagnostic build around the K loop (profiles/r06_bx_attribution_product.log), "
+                                  "GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of a PMC pass over the 98 launches of the first-layer SYRK on N(0,1) data and on "
+                                  "the bench's own factor (files: pmc_files; summary: profiles/r06_pmc_summary.txt)",
                     "pmc_files": PMC_FILES if split == 6 else None,
                     "bare_loop_ceiling": BX_BARE_LOOP_CEILING if split == 6 else None,
                     "frac_of_bare_loop_on_like_data": (achieved / BX_BARE_LOOP_CEILING["half_zeros_like_the_bench_factors"]["tflops_fp32_equiv"])

@@ -185,7 +185,7 @@ def run_configs(device, reps=3, which=("1", "3", "4", "5"), progress=lambda m: N
                 return comp, [comp.get_extension()], [{"params": list(layer.parameters()), "criterion": top_k(10)} for layer in layers]
 
             tag = "Gram side (the reference's path)" if side == "gram" else "side='auto' (parameter side where P < n)"
-            r3 = max(2, reps - 1) if side == "gram" else reps   # (2-3 s per pass on the Gram side: two timed passes behind the warm-up)
+            r3 = 1 if side == "gram" else reps   # (2-3 s per pass on the Gram side: one timed pass behind the warm-up)
             out.append(pb.line(f"3: eigvalsh, 5 blocks, {tag}", eigvalsh, 5 * n, r3, note))
             out.append(pb.line(f"3: eigh top-10 per block, {tag}", eigh10, 50, r3, note))
 

@@ -1735,7 +1735,9 @@ __global__ __launch_bounds__(256, 1) void gemm64_bx_kernel(GemmArgs p, const uin
 
   // DMA sources: wave w moves bytes [1536 w, 1536 w + 1536) of the A pieces (one full and one half-wave request) and
   // blocks w, w+4, w+8, w+12 of the B tile
+#if defined(G64_VADDR)
   gcptr srcA = (gcptr)(reinterpret_cast<const char *>(apieces) + (kbeg / BK) * 6144 + wave * 1536 + lane * 16);
+#endif
   gcptr srcB[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -1744,6 +1746,32 @@ __global__ __launch_bounds__(256, 1) void gemm64_bx_kernel(GemmArgs p, const uin
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem3;
   const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave * 1536)),
                  ldsB = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(G64X_TA * 4 + wave * 1024));
+#if !defined(G64_VADDR)
+  // Round 6: the requests take a wave-uniform base in scalar registers + ONE 32-bit offset per lane and stream instead of a
+  // 64-bit pointer per lane (global_load_lds_dwordx4 v, s[..]): in the 256-tile kernel's K loop that is what a request's cost
+  // to the SIMD hangs on (~25 cycles against ~3, gemm256_bx_kernel).  A lane's offset from the first row of the tile is
+  // below 256 rows x ldb x 4 bytes; it does not change along K.  (-DG64_VADDR: the per-lane pointers of rounds 4-5.)  Same-box
+  // A/B on N(0,1) data (scripts/probe/g64_ab.sh, profiles/r06_g64_ab.log): m = 40 960: 1820-1886 against 1884-1898 us;
+  // m = 20 480: 470-484 against 509-515 us.
+  gcptr baseA = (gcptr)(reinterpret_cast<const char *>(apieces) + (kbeg / BK) * 6144) + __builtin_amdgcn_readfirstlane(wave * (1536 / 4));
+  gcptr baseB = (gcptr)p.B + (BLAY == LAY_K ? (col0 < p.N ? col0 : 0) * p.ldb + kbeg : kbeg * p.ldb + (col0 < p.N ? col0 : 0));
+  const unsigned voffA = (unsigned)lane * 16u;
+  unsigned voffB[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) voffB[u] = (unsigned)((const char *)srcB[u] - (const char *)baseB);
+  auto dma16s = [](gcptr base, unsigned voff, unsigned lds_byte_addr) __attribute__((always_inline)) {
+    __asm__ volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff), "s"(base) : "memory");
+  };
+  auto issue = [&](int st) __attribute__((always_inline)) {   // 6 requests per wave
+    const unsigned so = (unsigned)(st * G64X_STG * 4);
+    dma16s(baseA, voffA, ldsA + so);
+    if (lane < 32) dma16s(baseA + 256, voffA, ldsA + so + 1024);   // (+256 floats = 1 KB; counted by vmcnt whatever the exec mask)
+    baseA += 6144 / 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dma16s(baseB, voffB[u], ldsB + so + (unsigned)(4 * u * 1024));
+    baseB += stepB;
+  };
+#else
   auto issue = [&](int st) __attribute__((always_inline)) {   // 6 requests per wave
     const unsigned so = (unsigned)(st * G64X_STG * 4);
     dma16(srcA, ldsA + so);
@@ -1755,6 +1783,7 @@ __global__ __launch_bounds__(256, 1) void gemm64_bx_kernel(GemmArgs p, const uin
       srcB[u] += stepB;
     }
   };
+#endif
 
   struct P3 { bf16x8 h, m, l; };
   P3 pa[2][2], pb[2][2];   // [tile parity][row / column tile]

@@ -1,1 +1,1 @@
-const char *vivit_hip_source_hash(void) { return "d4400c529f912db1d03f276a7cb0dbb5-262e1d34"; }
+const char *vivit_hip_source_hash(void) { return "c333aef5ad12b4e912e11758e1657df8-262e1d34"; }

@@ -1268,10 +1268,15 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   const bool mirrored = p.syrk == 1 && ti != tj;   // the mirror store wants the final values in the accumulators
   {
     const int t1 = nt;
+    // (tile 1 is requested behind tile 0 BEFORE the wait for tile 0: its latency runs beside tile 0's instead of behind the barrier)
     issue(0);
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (1 < t1) {
+      issue(1);
+      __asm__ volatile("s_waitcnt vmcnt(12)" ::: "memory");   // all but the 12 requests of tile 1: tile 0 has landed
+    } else {
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __asm__ volatile("s_barrier" ::: "memory");
-    if (1 < t1) issue(1);
 #if defined(BX_STAMP) && BX_STAMP == 2
     const unsigned long long stamp_loop0 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0 && g_bx_stamp && p.syrk == 2 && blockIdx.x < g_bx_stamp_cap) g_bx_stamp[8 * blockIdx.x + 3] = stamp_loop0;

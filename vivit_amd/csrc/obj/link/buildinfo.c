@@ -1,1 +1,1 @@
-const char *vivit_hip_source_hash(void) { return "c333aef5ad12b4e912e11758e1657df8-262e1d34"; }
+const char *vivit_hip_source_hash(void) { return "b06f502518d47d12563a8bb25cd1662d-262e1d34"; }

@@ -2,6 +2,7 @@
 """Generator of the hand-scheduled K loop of gemm256_bx_kernel<6, ASM, NW> (vivit_amd/csrc/gemm_f32.hip) as inline-asm blocks.
 
     python scripts/gen_bx_kloop.py            # writes vivit_amd/csrc/bx_kloop_asm.inc (committed: the build never runs this)
+    python scripts/gen_bx_kloop.py --variants # + csrc/bx_kloop_asm_variants.inc: the experiment / attribution blocks (git-ignored)
 
 VERDICT r03-r05 asked for the loop body in assembly: fixed register map, the global -> LDS requests of a K tile placed by
 hand between the MFMAs.  A block runs `ntiles` K tiles (16 k each) of the pipeline the C++ loop runs (gemm_f32.hip,
@@ -351,15 +352,24 @@ def variants():
 
 
 def main():
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vivit_amd", "csrc", "bx_kloop_asm.inc")
-    text = HEADER
+    """The product's block -> csrc/bx_kloop_asm.inc (committed); with --variants also the experiment / attribution blocks ->
+    csrc/bx_kloop_asm_variants.inc (git-ignored; included by gemm_f32.hip only under -DBX_KLOOP_TEXT_OVERRIDE=...,
+    scripts/probe/bx_asm_variants.sh)."""
+    import sys
+
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "vivit_amd", "csrc")
+    texts = {"bx_kloop_asm.inc": HEADER, "bx_kloop_asm_variants.inc": HEADER}
     for name, kw in variants().items():
         lines, G = gen(**kw)
-        text += render(lines, G, name, saddr=kw.get("addr") == "saddr", unroll=kw.get("unroll", 1))
-        print(name, len(lines), "lines,", G.noperands, "operands")
-    with open(out, "w") as f:
-        f.write(text)
-    print("wrote", os.path.normpath(out))
+        target = "bx_kloop_asm.inc" if name == "BX_KLOOP_ASM" else "bx_kloop_asm_variants.inc"
+        texts[target] += render(lines, G, name, saddr=kw.get("addr") == "saddr", unroll=kw.get("unroll", 1))
+        print(name, len(lines), "lines,", G.noperands, "operands ->", target)
+    for fname, text in texts.items():
+        if fname.endswith("variants.inc") and "--variants" not in sys.argv:
+            continue
+        with open(os.path.join(base, fname), "w") as f:
+            f.write(text)
+        print("wrote", os.path.normpath(os.path.join(base, fname)))
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@
 # default, in-kernel stamps for scripts/probe/bx_timeline.py (-DBX_STAMP=2).  "P" = the product's block.
 #   scripts/probe/bx_asm_variants.sh P E1 E2 T1 ...        (NOSTAMP=1: without the stamps, for whole-product timings)
 cd "$(dirname "$0")/../.."
+python scripts/gen_bx_kloop.py --variants > /dev/null   # the experiment blocks (csrc/bx_kloop_asm_variants.inc, git-ignored)
 stamp="-DBX_STAMP=2"; [ -n "$NOSTAMP" ] && stamp=""
 for v in "$@"; do
   if [ "$v" = P ]; then sel=""; else sel="-DBX_KLOOP_TEXT_OVERRIDE=BX_KLOOP_ASM_${v}_TEXT -DBX_KLOOP_CLOB_OVERRIDE=BX_KLOOP_ASM_${v}_CLOBBERS -DBX_KLOOP_UNROLL_OVERRIDE=BX_KLOOP_ASM_${v}_UNROLL"; fi

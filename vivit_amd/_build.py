@@ -47,11 +47,13 @@ def _digest(paths, extra=()):
 
 
 def _headers():
-    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "vivit_hip.h")]
+    # (csrc/bx_kloop_asm.inc: the generated asm K loop; the experiment blocks of bx_kloop_asm_variants.inc are not part of the product)
+    return (sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(CSRC, "bx_kloop_asm.inc")]
+            + [os.path.join(HERE, "..", "include", "vivit_hip.h")])
 
 
 def source_hash():
-    """Content hash (32 hex digits) of everything the library is compiled from: csrc/*.hip, csrc/*.h and
+    """Content hash (32 hex digits) of everything the library is compiled from: csrc/*.hip, csrc/*.h, csrc/bx_kloop_asm.inc and
     include/vivit_hip.h.  None when the sources are not beside the package (a binary-only install)."""
     hips = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     if not hips or not os.path.exists(os.path.join(HERE, "..", "include", "vivit_hip.h")):

@@ -962,7 +962,8 @@ __device__ unsigned int g_bx_stamp_cap = 0;
 #endif
 
 #include "bx_kloop_asm.inc"
-#if defined(BX_KLOOP_TEXT_OVERRIDE)     // attribution / experiment builds: any block of bx_kloop_asm.inc by name
+#if defined(BX_KLOOP_TEXT_OVERRIDE)     // attribution / experiment builds: a block of bx_kloop_asm_variants.inc by name
+#include "bx_kloop_asm_variants.inc"    // (python scripts/gen_bx_kloop.py --variants; not part of the product)
 #define BX_KLOOP_TEXT BX_KLOOP_TEXT_OVERRIDE
 #define BX_KLOOP_CLOB BX_KLOOP_CLOB_OVERRIDE
 #define BX_KLOOP_UNROLL BX_KLOOP_UNROLL_OVERRIDE

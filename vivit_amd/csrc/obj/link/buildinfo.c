@@ -1,1 +1,1 @@
-const char *vivit_hip_source_hash(void) { return "b06f502518d47d12563a8bb25cd1662d-262e1d34"; }
+const char *vivit_hip_source_hash(void) { return "271c69d25bb5d4e83ec99dc0964fa7d6-262e1d34"; }

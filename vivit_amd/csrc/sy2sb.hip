@@ -596,30 +596,36 @@ static bool skinny64_launch(const float *Coef, int64_t ldcoef, const float *B, i
 // Coef[64][128] = [ -1/2 T^T G T | T^T ]  (G = P^T-side Gram block Pt Vt^T): with the k-major rows [Vt; Pt] of the stack,
 // Wt = Coef [Vt; Pt] = T^T Pt - 1/2 (T^T G T) Vt  -- the panel's W in ONE pass, X = P T never materialised.  One workgroup.
 __global__ __launch_bounds__(256) void w_coef_kernel(const float *__restrict__ T, const float *__restrict__ G, float *__restrict__ Coef) {
+  // Round 6: both 64^3 products on the fp32 matrix pipe (v_mfma_f32_32x32x2f32: an exact fp32 fma chain in k order), one 32 x 32
+  // quadrant of the result per wave -- the scalar LDS loops took 24.4 us per panel (every multiply-add behind an LDS round
+  // trip), this form 5.7 us (scripts/probe/ktrace_sy2sb.sh).
   __shared__ float sT[SNB][SNB + 1], sG[SNB][SNB + 1], sU[SNB][SNB + 1];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, qi = (wave >> 1) * 32, qj = (wave & 1) * 32;
   for (int idx = tid; idx < SNB * SNB; idx += 256) {
     sT[idx / SNB][idx % SNB] = T[idx];
     sG[idx / SNB][idx % SNB] = G[idx];
   }
   __syncthreads();
-  // U = T^T G:  U[a][b] = sum_k T[k][a] G[k][b]
-  for (int idx = tid; idx < SNB * SNB; idx += 256) {
-    const int a = idx / SNB, b = idx % SNB;
-    float acc = 0.f;
+  // U = T^T G:  U[a][b] = sum_k T[k][a] G[k][b]      (A operand: lane (r, h) holds A[qi + r][2 s + h] = T[2 s + h][qi + r])
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll 8
-    for (int k = 0; k < SNB; ++k) acc = fmaf(sT[k][a], sG[k][b], acc);
-    sU[a][b] = acc;
-  }
+  for (int s2 = 0; s2 < SNB / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sT[2 * s2 + h][qi + r], sG[2 * s2 + h][qj + r], acc, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sU[qi + (e & 3) + 8 * (e >> 2) + 4 * h][qj + r] = acc[e];
   __syncthreads();
   // Y = U T:  Y[a][b] = sum_k U[a][k] T[k][b]
-  for (int idx = tid; idx < SNB * SNB; idx += 256) {
-    const int a = idx / SNB, b = idx % SNB;
-    float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll 8
-    for (int k = 0; k < SNB; ++k) acc = fmaf(sU[a][k], sT[k][b], acc);
-    Coef[a * 2 * SNB + b] = -0.5f * acc;
-    Coef[a * 2 * SNB + SNB + b] = sT[b][a];
+  for (int s2 = 0; s2 < SNB / 2; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sU[qi + r][2 * s2 + h], sT[2 * s2 + h][qj + r], acc, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int a_ = qi + (e & 3) + 8 * (e >> 2) + 4 * h, b_ = qj + r;
+    Coef[a_ * 2 * SNB + b_] = -0.5f * acc[e];
+    Coef[a_ * 2 * SNB + SNB + b_] = sT[b_][a_];
   }
 }
 
@@ -635,9 +641,9 @@ __global__ __launch_bounds__(256) void sb_panel_store_kernel(float *__restrict__
 }
 
 // T (nb x nb upper triangular, forward/columnwise larft) from S = V^T V and tau; nb = SNB.
-// Two diagonal half blocks by column-parallel back substitution (device_utils.h:tfactor_column: the longest column is 496
-// dependent multiply-adds instead of 2016), then the coupling block T12 = -T11 S12 T22 as two 32^3 products over 256 threads:
-// 43 -> ~16 us per panel.
+// Two diagonal half blocks by column-parallel back substitution (the longest column is 496 multiply-adds instead of 2016), then
+// the coupling block T12 = -T11 S12 T22 as two 32^3 products over 256 threads: 43 -> 34 us per panel (round 3); with the column of
+// the back substitution in registers instead of LDS (round 6): see below.
 __global__ __launch_bounds__(256) void larft_kernel(const float *__restrict__ S, int64_t lds_, const float *__restrict__ tau, int nb,
                                                     int nvalid, float *__restrict__ T) {
   constexpr int H = SNB / 2, LD = SNB + 1;
@@ -649,23 +655,54 @@ __global__ __launch_bounds__(256) void larft_kernel(const float *__restrict__ S,
   }
   if (tid < SNB) taus[tid] = (tid < nvalid && tid < nb) ? tau[tid] : 0.f;
   __syncthreads();
-  if (tid < H) tfactor_column(Ss, taus, Ts, LD, H, tid);                                        // T11
-  else if (tid < SNB) tfactor_column(Ss + H * LD + H, taus + H, Ts + H * LD + H, LD, H, tid - H);   // T22
-  __syncthreads();
-  for (int idx = tid; idx < H * H; idx += 256) {   // X = S12 T22
-    const int i = idx / H, j = idx % H;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k <= j; ++k) acc = fmaf(Ss[i * LD + H + k], Ts[(H + k) * LD + H + j], acc);
-    Xs[i * (H + 1) + j] = acc;
+  if (tid < SNB) {
+    // Column j of a diagonal half block by back substitution with the column IN REGISTERS (round 6; the same recurrence and
+    // summation order as device_utils.h:tfactor_column, whose column lives in LDS: every multiply-add there waits for an LDS
+    // round trip behind the store of the previous row -- 496 dependent round trips for the longest column, 25 of the kernel's
+    // 34 us).  t[c] = 0 for c > j (T is upper triangular), so the sums need no bounds; S[i][c] is the same address for all
+    // threads of a half block: a broadcast read.
+    const int half = tid / H, j = tid % H;
+    const float *Sb = Ss + half * (H * LD + H), *tb = taus + half * H;
+    float t[H];
+#pragma unroll
+    for (int c = 0; c < H; ++c) t[c] = 0.f;
+#pragma unroll
+    for (int i = H - 1; i >= 0; --i) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = i + 1; c < H; ++c) acc += Sb[i * LD + c] * t[c];
+      t[i] = i == j ? tb[j] : (i < j ? -tb[i] * acc : 0.f);
+    }
+    float *Tb = Ts + half * (H * LD + H);
+#pragma unroll
+    for (int i = 0; i < H; ++i) Tb[i * LD + j] = t[i];
   }
   __syncthreads();
-  for (int idx = tid; idx < H * H; idx += 256) {   // T12 = -T11 X
-    const int i = idx / H, j = idx % H;
-    float acc = 0.f;
+  // the coupling block T12 = -T11 (S12 T22): two 32^3 products on the fp32 matrix pipe by wave 0 (an exact fma chain in k order;
+  // the structural zeros of the triangular factors add exact zeros) -- the scalar LDS loops were 4 of the kernel's 14 us.
+  // Kernel trace at n = 20 480 (scripts/probe/ktrace_sy2sb.sh): larft_kernel 33.9 -> 14.2 (column in registers) -> 10.2 us per panel
+  if (tid < 64) {
+    const int r = tid & 31, h = tid >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll 8
-    for (int k = i; k < H; ++k) acc = fmaf(Ts[i * LD + k], Xs[k * (H + 1) + j], acc);
-    Ts[i * LD + H + j] = -acc;
+    for (int s2 = 0; s2 < H / 2; ++s2)   // X = S12 T22
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ss[r * LD + H + 2 * s2 + h], Ts[(H + 2 * s2 + h) * LD + H + r], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Xs[((e & 3) + 8 * (e >> 2) + 4 * h) * (H + 1) + r] = acc[e];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int r = tid & 31, h = tid >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll 8
+    for (int s2 = 0; s2 < H / 2; ++s2)   // T12 = -T11 X
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ts[r * LD + 2 * s2 + h], Xs[(2 * s2 + h) * (H + 1) + r], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Ts[((e & 3) + 8 * (e >> 2) + 4 * h) * LD + H + r] = -acc[e];
   }
   __syncthreads();
   for (int idx = tid; idx < SNB * SNB; idx += 256) T[idx] = Ts[(idx / SNB) * LD + (idx % SNB)];

@@ -150,12 +150,12 @@ class Emitter:
 
 
 def loop_body(e, G, req_gaps, label, setprio=False, nop_m0=True, ds_per_gap=3, row0_colmajor=False, barrier="full", dma=True, addr="vaddr",
-              unroll=1):
+              unroll=1, mfma16=False):
     """`unroll` tiles per trip: the stage registers take their roles by renaming (no rotation moves), ntiles % unroll == 0."""
     e.raw(f"{label}:")
     regs = [S_CUR, S_NXT, S_NN]
     for k in range(unroll):
-        one_tile(e, G, req_gaps, regs[k % 3], regs[(k + 1) % 3], regs[(k + 2) % 3], setprio, nop_m0, ds_per_gap, row0_colmajor, barrier, dma, addr)
+        one_tile(e, G, req_gaps, regs[k % 3], regs[(k + 1) % 3], regs[(k + 2) % 3], setprio, nop_m0, ds_per_gap, row0_colmajor, barrier, dma, addr, mfma16)
     if unroll % 3 != 0:   # rotate the stages: (cur, nxt, nn) <- (nxt, nn, cur), `unroll` times
         e.raw(f"s_mov_b32 {S_TMP}, {regs[0]}")
         if unroll % 3 == 1:
@@ -171,7 +171,7 @@ def loop_body(e, G, req_gaps, label, setprio=False, nop_m0=True, ds_per_gap=3, r
     e.raw(f"s_cbranch_scc1 {label}")
 
 
-def one_tile(e, G, req_gaps, S_CUR, S_NXT, S_NN, setprio, nop_m0, ds_per_gap, row0_colmajor, barrier, dma, addr):
+def one_tile(e, G, req_gaps, S_CUR, S_NXT, S_NN, setprio, nop_m0, ds_per_gap, row0_colmajor, barrier, dma, addr, mfma16=False):
     """One K tile: the MFMA stream with its fillers; `req_gaps[r]` = the MFMA slot BEFORE which request r is issued.
     `ds_per_gap`: at most this many ds_read_b128 per MFMA gap (MI355X_MICROARCH.md, LDS: a third read per gap by every wave
     saturates the LDS array and stretches the gap to 48 cycles); `row0_colmajor`: row 0 column by column like row 3, so that the
@@ -252,6 +252,14 @@ def one_tile(e, G, req_gaps, S_CUR, S_NXT, S_NN, setprio, nop_m0, ds_per_gap, ro
         e.need([f"{names_a[i]}{pa}", f"B{j}{pb}"])
         if setprio and g in (0, 2 * R):
             e.raw("s_setprio 1")
+        if mfma16:
+            # TIMING ONLY (wrong results): the same flops as two v_mfma_f32_16x16x32_bf16 on the same operand registers, accumulators
+            # taken as fixed 4-register groups of the 256 AGPRs -- what the other MFMA shape does to cycles and clock
+            # (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.14 x the FLOP/s of the 32x32x16 shape in power-limited loops)
+            for half in range(2):
+                a4 = 4 * ((2 * g + half) % 64)
+                e.raw(f"v_mfma_f32_16x16x32_bf16 a[{a4}:{a4 + 3}], {G.va(0 if i in (0, 2) else 1, pa)}, {G.vb(j, pb)}, a[{a4}:{a4 + 3}]")
+            continue
         e.raw(f"v_mfma_f32_32x32x16_bf16 {G.acc(i, j)}, {G.va(0 if i in (0, 2) else 1, pa)}, {G.vb(j, pb)}, {G.acc(i, j)}")
     emit_fillers(G.nmfma)
     want = [f"N0{pc}" for pc in range(3)] + [f"NB{j}{pc}" for j in range(G.nj) for pc in range(3)]
@@ -348,6 +356,8 @@ def variants():
         "BX_KLOOP_ASM_T1": dict(best, req_gaps=spread, unroll=3, barrier="none"),
         "BX_KLOOP_ASM_T2": dict(best, req_gaps=spread, unroll=3, dma=False),
         "BX_KLOOP_ASM_T3": dict(best, req_gaps=spread, unroll=3, dma=False, barrier="none"),
+        "BX_KLOOP_ASM_T4": dict(best, req_gaps=spread, unroll=3, mfma16=True),
+        "BX_KLOOP_ASM_T5": dict(best, req_gaps=spread, unroll=3, mfma16=True, dma=False, barrier="none"),
     }
 
 

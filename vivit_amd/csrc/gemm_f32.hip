@@ -792,6 +792,9 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
 // commits on the product itself.  Six bf16 MFMAs replace eight fp32 MFMAs per 16 k: 2.67x the matrix-pipe rate for the
 // same accumulation arithmetic (fp32 accumulators, the same two-level flush into C, tile map and epilogues of
 // gemm256_kernel).  Operands are K-contiguous (LAY_K) on both sides: the Gram SYRK and the NT products.
+// (The six-product kernel issues them as THREE v_mfma_f32_16x16x32_bf16 per 16 x 16 tile -- lo hi + hi lo, mid mid + mid hi,
+// hi mid + hi hi, each instruction summing two partial products over the same 16 k --: same pipe rate, same exactness argument,
+// a higher clock under the power limit; see gemm256_bx_kernel.)
 //
 // Two kernels: bx_split_kernel writes the three pieces of a column chunk of an operand as bf16 matrices (HBM-bound:
 // 4 B read + 6 B written per element, 1-2 % of the product's time); gemm256_bx_kernel is then a pure bf16 GEMM on the
@@ -961,36 +964,66 @@ __device__ unsigned long long *g_bx_stamp = nullptr;
 __device__ unsigned int g_bx_stamp_cap = 0;
 #endif
 
+#ifndef BX_SHAPE16
+#define BX_SHAPE16 1   // 0: the six-product kernel on v_mfma_f32_32x32x16_bf16 as in rounds 2-5 (same-box comparisons)
+#endif
 #include "bx_kloop_asm.inc"
-#if defined(BX_KLOOP_TEXT_OVERRIDE)     // attribution / experiment builds: a block of bx_kloop_asm_variants.inc by name
-#include "bx_kloop_asm_variants.inc"    // (python scripts/gen_bx_kloop.py --variants; not part of the product)
-#define BX_KLOOP_TEXT BX_KLOOP_TEXT_OVERRIDE
-#define BX_KLOOP_CLOB BX_KLOOP_CLOB_OVERRIDE
-#define BX_KLOOP_UNROLL BX_KLOOP_UNROLL_OVERRIDE
+// (both forms are parsed in every build: the text of a discarded `if constexpr` branch is still checked against its operand list)
+#define BX_KLOOP_TEXT16 BX_KLOOP_ASM_TEXT
+#define BX_KLOOP_CLOB16 BX_KLOOP_ASM_CLOBBERS
+#define BX_KLOOP_TEXT32 BX_KLOOP_ASM32_TEXT
+#define BX_KLOOP_CLOB32 BX_KLOOP_ASM32_CLOBBERS
+#define BX_KLOOP_UNROLL 3
+static_assert(BX_KLOOP_ASM_UNROLL == BX_KLOOP_UNROLL && BX_KLOOP_ASM32_UNROLL == BX_KLOOP_UNROLL, "tiles per trip of the asm blocks");
+#if defined(BX_KLOOP_TEXT_OVERRIDE)     // attribution / experiment builds: a block of bx_kloop_asm_variants.inc by name, of the
+#include "bx_kloop_asm_variants.inc"    // form BX_SHAPE16 selects (python scripts/gen_bx_kloop.py --variants; not part of the product)
+static_assert(BX_KLOOP_UNROLL_OVERRIDE == BX_KLOOP_UNROLL, "tiles per trip of the asm blocks");
+#if BX_SHAPE16
+#undef BX_KLOOP_TEXT16
+#undef BX_KLOOP_CLOB16
+#define BX_KLOOP_TEXT16 BX_KLOOP_TEXT_OVERRIDE
+#define BX_KLOOP_CLOB16 BX_KLOOP_CLOB_OVERRIDE
 #else
-#define BX_KLOOP_TEXT BX_KLOOP_ASM_TEXT
-#define BX_KLOOP_CLOB BX_KLOOP_ASM_CLOBBERS
-#define BX_KLOOP_UNROLL BX_KLOOP_ASM_UNROLL
+#undef BX_KLOOP_TEXT32
+#undef BX_KLOOP_CLOB32
+#define BX_KLOOP_TEXT32 BX_KLOOP_TEXT_OVERRIDE
+#define BX_KLOOP_CLOB32 BX_KLOOP_CLOB_OVERRIDE
+#endif
 #endif
 
 // ASM (default since round 6): the steady part of the K loop runs as ONE hand-scheduled inline-asm block (bx_kloop_asm.inc,
 // generated by scripts/gen_bx_kloop.py: fixed register map, every memory instruction placed between the MFMAs by hand);
 // prologue, the last tiles of a pass, the chain flushes and the epilogues stay the C++ below, which is also the reference
-// implementation (ASM = false, VIVIT_BX_ASM=0).  Same partial products in the same order per accumulator: bit-identical
-// results (tests/test_bx_asm_gpu.py).  What the block does differently, and what each point is worth in core cycles per K tile
-// (3072 of them are the 96 MFMAs; in-kernel stamps, profiles/r06_bx_attribution*.log; the C++ loop: 3525):
+// implementation (ASM = false, VIVIT_BX_ASM=0).  Same instructions in the same order per accumulator: bit-identical
+// results (tests/test_bx_asm_gpu.py).
+//
+// MFMA shape (second half of round 6).  The six-product kernel computes on v_mfma_f32_16x16x32_bf16, two partial products fused
+// along the instruction's K = 32 (see "S16" at the fragment loads): the same flops as six v_mfma_f32_32x32x16_bf16 per 32 x 32
+// block, in twice as many instructions of half the length.  It needs MORE core cycles per K tile (3072 of them are MFMA cycles
+// either way; in-kernel stamps, profiles/r06_bx16_timeline*.log: 3440-3470 against 3250-3280, 40 fragment reads instead of 27)
+// -- and runs faster, because the kernel is power-limited and the chip holds a higher clock on this shape (2.0-2.1 against 1.8 GHz
+// on half-zero data, 1.8 against 1.7 on N(0,1); MI355X_MICROARCH.md, DVFS give-back item 7): the headline-shaped SYRK takes
+// 875 / 780 ms (N(0,1) / half zeros) against 921 / 819 ms on the same box (profiles/r06_syrk_ab_s16.log).  -DBX_SHAPE16=0 builds
+// the 32 x 32 x 16 form (its own asm block, BX_KLOOP_ASM32) for such comparisons.
+//
+// What the blocks do differently from the compiler's schedule, in core cycles per K tile (32 x 32 x 16 form, where they were
+// measured one by one; profiles/r06_bx_attribution*.log; the C++ loop: 3525):
 //   * the twelve global -> LDS requests take a scalar base + ONE 32-bit lane offset instead of twelve 64-bit per-lane
 //     pointers (global_load_lds_dwordx4 v, s[..]): the requests cost ~30 cycles per tile instead of ~290 -- it is the address
 //     registers of a request, not its issue slot, that hold up the SIMD (eight waves, two per SIMD, did not hide it: same 3500);
-//   * never more than two ds_read_b128 per MFMA gap (a third one by every wave saturates the LDS array for that gap: ~100);
-//   * one request per gap over rows 2 + 3, never beside fragment reads (all in row 3: + 190);
-//   * row 0 column by column, so that the last column's B fragments, read at the end of the previous tile, are first needed
-//     18 MFMAs later; three tiles per trip with the stage registers renamed instead of rotated (- 45).
-//   Now 3283 (no barrier: 3235; no requests: 3253; neither: 3226): 93.6 % of the cycles are MFMA cycles.  The chip answers with
-//   a lower clock (DVFS give-back): - 7 % cycles are - 3.8 % time on the K loop.
+//   * never more than two ds_read_b128 per 32-cycle MFMA gap (a third one by every wave saturates the LDS array for that gap: ~100)
+//     -- one per 16-cycle gap in the 16 x 16 x 32 form;
+//   * one request per gap over the second half of the tile, never beside fragment reads (all in the last row: + 190; one per gap
+//     right behind the barrier, 16 x 16 x 32 form: + 370);
+//   * an accumulator comes back every 8th instruction at the earliest (16 x 16 x 32 form: every 2nd costs ~ 25);
+//   * three tiles per trip with the stage registers renamed instead of rotated (- 45); M0 written one gap ahead of its request
+//     instead of s_nop in front of it (- 30).
+//   32 x 32 x 16 form: 3283 (no barrier: 3235; no requests: 3253; neither: 3226).  16 x 16 x 32 form: 3440 (no barrier: 3400; no
+//   requests: 3380; neither: 3350).  Fewer cycles come back as time only in part (DVFS give-back): - 7 % cycles were - 3.8 % time.
 template <int NPROD, bool ASM = false>
 __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
+  constexpr bool S16 = NPROD == 6 && BX_SHAPE16 != 0;   // the MFMA shape (accumulator layout below)
 #if defined(BX_STAMP) && BX_STAMP == 2   // timeline build (scripts/probe/bx_timeline.py): 8 words per workgroup
   const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1021,6 +1054,16 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
+  // Accumulator layout.  The six-product kernel computes on v_mfma_f32_16x16x32_bf16 (S16): the 32 x 32 block acc[i][j] is four
+  // 16 x 16 tiles (tr, tc) in registers 4 (2 tr + tc) .. + 3, lane l holding rows 4 (l / 16) .. + 3 of column l % 16 of each; the
+  // other kernels on v_mfma_f32_32x32x16_bf16 (register e = rows (e & 3) + 8 (e >> 2) + 4 (l / 32) of column l % 32).
+  const int r16 = lane & 15, kb = lane >> 4;
+  // element e of a block: (row, column) = (lrow + erc(e), lcol + ecc(e)), a lane part and a part that is a constant per register
+  const int lrow = S16 ? 4 * kb : 4 * h, lcol = S16 ? r16 : r;
+  auto erc = [](int e) __attribute__((always_inline)) -> int { return S16 ? 16 * (e >> 3) + (e & 3) : (e & 3) + 8 * (e >> 2); };
+  auto ecc = [](int e) __attribute__((always_inline)) -> int { return S16 ? 16 * ((e >> 2) & 1) : 0; };
+  auto erow = [&](int e) __attribute__((always_inline)) -> int { return lrow + erc(e); };
+  auto ecol = [&](int e) __attribute__((always_inline)) -> int { return lcol + ecc(e); };
   const int64_t row0 = (int64_t)ti * B2, col0 = (int64_t)tj * B2;
   int nt = (int)(p.K / BK);
   int64_t kt0 = 0;
@@ -1029,13 +1072,21 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     nt = nt - (int)kt0 < p.kt_split ? nt - (int)kt0 : p.kt_split;
   }
 
-  f32x16 acc[4][4];
+  // (S16: see the accumulator layout above -- the 32 x 32 block is four separate 4-register accumulators)
+  constexpr int NQ = S16 ? 4 : 1, QW = 16 / NQ;
+  typedef typename std::conditional<S16, f32x4, f32x16>::type AccV;
+  AccV acc[4][4][NQ];
+  auto aget = [&](int i, int j, int e) __attribute__((always_inline)) -> float { return acc[i][j][e / QW][e % QW]; };
+  auto aset = [&](int i, int j, int e, float v) __attribute__((always_inline)) { acc[i][j][e / QW][e % QW] = v; };
+  auto clear_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 16; ++e) aset(i, j, e, 0.f);
+  };
+  clear_acc();
 
   gptr Cout = p.kt_split > 0 ? (gptr)p.slab + (int64_t)blockIdx.y * p.M * p.N : (gptr)p.C;
   const int64_t ldc = p.kt_split > 0 ? p.N : p.ldc;
@@ -1055,54 +1106,45 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       // one row of four 32 x 32 tiles at a time: 64 loads in flight, then 64 stores (tile by tile - 16 loads, wait,
       // 16 stores - the read-modify-write cost ~40 us per 256 x 256 tile: half of a K = 512 update's time)
       __asm__ volatile("" ::: "memory");
-      const int64_t rbase = row0 + wm * 128 + i * 32 + 4 * h + opaque;
+      const int64_t rbase = row0 + wm * 128 + i * 32 + lrow + opaque;
       if (full_tile) {
         float old[4][16];
         if (beta != 0.f) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + r);
+            gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + lcol);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) old[j][e] = ld_l2(cbase + (int64_t)((e & 3) + 8 * (e >> 2)) * ldc);
+            for (int e = 0; e < 16; ++e) old[j][e] = ld_l2(cbase + (int64_t)erc(e) * ldc + ecc(e));
           }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + r);
+          gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + lcol);
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            float v = alpha_ * acc[i][j][e];
+            float v = alpha_ * aget(i, j, e);
             if (beta != 0.f) v += beta * old[j][e];
-            cbase[(int64_t)((e & 3) + 8 * (e >> 2)) * ldc] = v;
-            acc[i][j][e] = v;
+            cbase[(int64_t)erc(e) * ldc + ecc(e)] = v;
+            aset(i, j, e, v);
           }
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int64_t col = col0 + wn * 128 + j * 32 + r;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
-            float v = alpha_ * acc[i][j][e];
+            const int64_t row = rbase + erc(e), col = col0 + wn * 128 + j * 32 + ecol(e);
+            float v = alpha_ * aget(i, j, e);
             if (row < p.M && col < p.N) {
               gptr c = Cout + row * ldc + col;
               if (beta != 0.f) v += beta * ld_l2(c);
               *c = v;
             }
-            acc[i][j][e] = v;
+            aset(i, j, e, v);
           }
         }
       }
     }
-  };
-  auto clear_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   };
 
   typedef f32x4 __attribute__((address_space(1))) *gptr4w;
@@ -1125,14 +1167,14 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t rb = row0 + wm * 128 + i * 32 + 4 * h + opaque, col = col0 + wn * 128 + j * 32 + r;
-        gptr cb = Cout + rb * ldc + col;
+        const int64_t rb = row0 + wm * 128 + i * 32 + lrow + opaque, cb0 = col0 + wn * 128 + j * 32 + lcol;
+        gptr cb = Cout + rb * ldc + cb0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int dr = (e & 3) + 8 * (e >> 2);
-          if (full_tile || (rb + dr < p.M && col < p.N)) {
-            if (store) cb[(int64_t)dr * ldc] = alpha_ * acc[i][j][e];
-            else __builtin_amdgcn_global_atomic_fadd_f32(cb + (int64_t)dr * ldc, alpha_ * acc[i][j][e]);
+          const int dr = erc(e), dc = ecc(e);
+          if (full_tile || (rb + dr < p.M && cb0 + dc < p.N)) {
+            if (store) cb[(int64_t)dr * ldc + dc] = alpha_ * aget(i, j, e);
+            else __builtin_amdgcn_global_atomic_fadd_f32(cb + (int64_t)dr * ldc + dc, alpha_ * aget(i, j, e));
           }
         }
       }
@@ -1181,27 +1223,58 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   };
   // ---- one K tile of 16: 16 output tiles x NPROD bf16 MFMAs per wave; the smallest partial products go in first.
   // The B pieces of the wave's four column tiles stay in registers for the tile (48), the A pieces stream per row tile.
-  const unsigned fofsA = (unsigned)((wm * 4) * 1024 + h * 512 + r * 16), fofsB = (unsigned)((wn * 4) * 1024 + h * 512 + r * 16);
+  // S16: one v_mfma_f32_16x16x32_bf16 adds TWO partial products -- its K = 32 is the tile's 16 k twice, first with one pair of
+  // pieces and then with another.  Lane l supplies row (column) l % 16 and k block l / 16 of the instruction's 32: blocks 0, 1 are
+  // the two 8-k halves of the first piece, blocks 2, 3 those of the second, so a fragment is still ONE ds_read_b128 with the piece
+  // picked per lane.  Three instructions per 16 x 16 tile and K tile, smallest terms first:
+  //   [a2 | a0] x [b0 | b2]  ->  lo hi + hi lo        [a1 | a1] x [b1 | b0]  ->  mid mid + mid hi        [a0 | a0] x [b1 | b0]  ->  hi mid + hi hi
+  // i.e. three A fragments per 16 rows and two B fragments per 16 columns (the B fragments of the wave's 128 columns stay in
+  // registers for the tile: 64).  40 fragment reads per wave and K tile against 28 for the 32 x 32 x 16 shape, 192 instructions of
+  // 8 passes against 96 of 16 -- same flops, but the chip holds a ~12 % higher clock on this shape (profiles/r06_bx_mfma16_timing.log).
+  const unsigned fofsA = S16 ? (unsigned)((wm * 4) * 1024 + (kb & 1) * 512 + r16 * 16) : (unsigned)((wm * 4) * 1024 + h * 512 + r * 16);
+  const unsigned fofsB = S16 ? (unsigned)((wn * 4) * 1024 + (kb & 1) * 512 + r16 * 16) : (unsigned)((wn * 4) * 1024 + h * 512 + r * 16);
+  constexpr int NCA = 3, NCB = S16 ? 2 : 3, NSUB = S16 ? 2 : 1;   // fragments per 32-row block: NCA (NCB) combinations x NSUB halves
+  // byte offset of combination c of A (d of B) inside a stage: the piece this lane reads
+  unsigned cofsA[NCA], cofsB[NCB];
+  if (S16) {
+    cofsA[0] = (unsigned)((kb >> 1 ? 0 : 2) * BX_PIECE) + fofsA;   // [a2 | a0]
+    cofsA[1] = (unsigned)(1 * BX_PIECE) + fofsA;                   // [a1 | a1]
+    cofsA[2] = fofsA;                                              // [a0 | a0]
+    cofsB[0] = (unsigned)(BX_OPER + (kb >> 1 ? 2 : 0) * BX_PIECE) + fofsB;   // [b0 | b2]
+    cofsB[1] = (unsigned)(BX_OPER + (kb >> 1 ? 0 : 1) * BX_PIECE) + fofsB;   // [b1 | b0]
+  } else {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      cofsA[pc] = (unsigned)(pc * BX_PIECE) + fofsA;
+      if (pc < NCB) cofsB[pc] = (unsigned)(BX_OPER + pc * BX_PIECE) + fofsB;
+    }
+  }
   struct FragB {
-    bf16x8 v[3][4];
+    bf16x8 v[NCB][4 * NSUB];
   };
   struct FragA {
-    bf16x8 v[3];
+    bf16x8 v[NCA][NSUB];
+  };
+  auto load_b_col = [&](int st, int j, FragB &f) __attribute__((always_inline)) {   // the fragments of 32-column block j
+    const unsigned char *sS = smem_bx + st * BX_STAGE;
+#pragma unroll
+    for (int d = 0; d < NCB; ++d)
+#pragma unroll
+      for (int tc = 0; tc < NSUB; ++tc) f.v[d][NSUB * j + tc] = *reinterpret_cast<const bf16x8 *>(sS + cofsB[d] + j * 1024 + tc * 256);
   };
   auto load_b = [&](int st) __attribute__((always_inline)) -> FragB {
-    const unsigned char *sB = smem_bx + st * BX_STAGE + BX_OPER;
     FragB f;
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) f.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sB + pc * BX_PIECE + fofsB + j * 1024);
+    for (int j = 0; j < 4; ++j) load_b_col(st, j, f);
     return f;
   };
-  auto load_a = [&](int st, int i) __attribute__((always_inline)) -> FragA {
-    const unsigned char *sA = smem_bx + st * BX_STAGE;
+  auto load_a = [&](int st, int i) __attribute__((always_inline)) -> FragA {   // the fragments of 32-row block i
+    const unsigned char *sS = smem_bx + st * BX_STAGE;
     FragA f;
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) f.v[pc] = *reinterpret_cast<const bf16x8 *>(sA + pc * BX_PIECE + fofsA + i * 1024);
+    for (int c = 0; c < NCA; ++c)
+#pragma unroll
+      for (int tr = 0; tr < NSUB; ++tr) f.v[c][tr] = *reinterpret_cast<const bf16x8 *>(sS + cofsA[c] + i * 1024 + tr * 256);
     return f;
   };
   auto mfma_row = [&](auto iconst, const FragA &fa, const FragB &fb, auto &&between) __attribute__((always_inline)) {
@@ -1209,45 +1282,29 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       between(j);
-#if defined(BX_EXP) && BX_EXP == 5   // timing only (wrong numbers): the same flops on v_mfma_f32_16x16x32_bf16 -- the 32 x 32 block as
-      // four 16 x 16 tiles, three instructions (two partial products fused along k) per tile and K tile
-      if (NPROD == 6) {
-        f32x16 c0 = acc[i][j];
-        f32x4 q[4];
+      if constexpr (S16) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) q[t] = __builtin_shufflevector(c0, c0, 4 * 0, 4 * 0 + 1, 4 * 0 + 2, 4 * 0 + 3);
-        q[0] = __builtin_shufflevector(c0, c0, 0, 1, 2, 3);
-        q[1] = __builtin_shufflevector(c0, c0, 4, 5, 6, 7);
-        q[2] = __builtin_shufflevector(c0, c0, 8, 9, 10, 11);
-        q[3] = __builtin_shufflevector(c0, c0, 12, 13, 14, 15);
-#pragma unroll
-        for (int pr = 0; pr < 3; ++pr)
+        for (int m = 0; m < 3; ++m)   // (the four tiles in turn: consecutive instructions never share an accumulator)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            q[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v[pr], fb.v[(pr + t) % 3][j], q[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c0[4 * t + e] = q[t][e];
-        acc[i][j] = c0;
-        continue;
+            acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v[m][t >> 1], fb.v[m == 0 ? 0 : 1][2 * j + (t & 1)], acc[i][j][t], 0, 0, 0);
+      } else {
+        f32x16 c = acc[i][j][0];
+        if (NPROD >= 9) {
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2][0], fb.v[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2][0], fb.v[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1][0], fb.v[2][j], c, 0, 0, 0);
+        }
+        if (NPROD >= 6) {
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2][0], fb.v[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0][0], fb.v[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1][0], fb.v[1][j], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1][0], fb.v[0][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0][0], fb.v[1][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0][0], fb.v[0][j], c, 0, 0, 0);
+        acc[i][j][0] = c;
       }
-#endif
-      f32x16 c = acc[i][j];
-      if (NPROD >= 9) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2], fb.v[2][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2], fb.v[1][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1], fb.v[2][j], c, 0, 0, 0);
-      }
-      if (NPROD >= 6) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[2], fb.v[0][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0], fb.v[2][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1], fb.v[1][j], c, 0, 0, 0);
-      }
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[1], fb.v[0][j], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0], fb.v[1][j], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v[0], fb.v[0][j], c, 0, 0, 0);
-      acc[i][j] = c;
     }
   };
   using J0 = std::integral_constant<int, 0>;
@@ -1318,10 +1375,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       mfma_row(J2{}, fa2, fb, nothing);
       // first fragments of tile t + 1: the B pieces of column tile j behind the MFMAs of column tile j - 1 of row 3
       {
-        const unsigned char *sBn = smem_bx + stn * BX_STAGE + BX_OPER;
         mfma_row(J3{}, fa3, fb, [&](int j) __attribute__((always_inline)) {
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) fbn.v[pc][j] = *reinterpret_cast<const bf16x8 *>(sBn + pc * BX_PIECE + fofsB + j * 1024);
+          load_b_col(stn, j, fbn);
           __builtin_amdgcn_sched_barrier(0);
           if (req) issue_part(st2, j);
           __builtin_amdgcn_sched_barrier(0);
@@ -1340,17 +1395,27 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
         int na = (tc < t1 - 2 ? tc : t1 - 2) - t;
         na -= na % (2 * BX_KLOOP_UNROLL);
         if (na > 0) {
-          const unsigned fa_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx + fofsA;
-          const unsigned fb_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx + BX_OPER + fofsB;
+          const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem_bx;
           const int64_t strideA_b = 2 * p.strideA, strideB_b = 2 * p.strideB, stepA_b = 2 * stepA, stepB_b = 2 * stepB;
           __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the fragment sets of the C++ loop are not carried into the block)
-          __asm__ volatile(BX_KLOOP_TEXT
-                           : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]),
-                             "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]),
-                             "+a"(acc[3][0]), "+a"(acc[3][1]), "+a"(acc[3][2]), "+a"(acc[3][3])
-                           : "v"(fa_lds), "v"(fb_lds), "v"(srcA[0]), "v"(srcA[1]), "v"(srcB[0]), "v"(srcB[1]), "s"(strideA_b), "s"(strideB_b),
-                             "s"(stepA_b), "s"(stepB_b), "s"(lds0), "s"(st), "s"(na), "s"(0)
-                           : BX_KLOOP_CLOB);
+          if constexpr (S16) {
+            // the block names its accumulators: acc[i][j][q] is pinned to a[16 (4 i + j) + 4 q .. + 3]
+            __asm__ volatile(BX_KLOOP_TEXT16
+                             : BX_KLOOP_ASM_ACC(acc)
+                             : "v"(lds_base + cofsA[0]), "v"(lds_base + cofsA[1]), "v"(lds_base + cofsA[2]), "v"(lds_base + cofsB[0]),
+                               "v"(lds_base + cofsB[1]), "v"(srcA[0]), "v"(srcA[1]), "v"(srcB[0]), "v"(srcB[1]), "s"(strideA_b), "s"(strideB_b),
+                               "s"(stepA_b), "s"(stepB_b), "s"(lds0), "s"(st), "s"(na), "s"(0)
+                             : BX_KLOOP_CLOB16);
+          } else {
+            const unsigned fa_lds = lds_base + fofsA, fb_lds = lds_base + BX_OPER + fofsB;
+            __asm__ volatile(BX_KLOOP_TEXT32
+                             : "+a"(acc[0][0][0]), "+a"(acc[0][1][0]), "+a"(acc[0][2][0]), "+a"(acc[0][3][0]), "+a"(acc[1][0][0]), "+a"(acc[1][1][0]),
+                               "+a"(acc[1][2][0]), "+a"(acc[1][3][0]), "+a"(acc[2][0][0]), "+a"(acc[2][1][0]), "+a"(acc[2][2][0]), "+a"(acc[2][3][0]),
+                               "+a"(acc[3][0][0]), "+a"(acc[3][1][0]), "+a"(acc[3][2][0]), "+a"(acc[3][3][0])
+                             : "v"(fa_lds), "v"(fb_lds), "v"(srcA[0]), "v"(srcA[1]), "v"(srcB[0]), "v"(srcB[1]), "s"(strideA_b), "s"(strideB_b),
+                               "s"(stepA_b), "s"(stepB_b), "s"(lds0), "s"(st), "s"(na), "s"(0)
+                             : BX_KLOOP_CLOB32);
+          }
           // the block leaves the request pointers na tiles further and the stage of the new tile t: redo both here (cheap,
           // and the operands above stay plain inputs -- 16 read-write accumulator operands already count twice)
           srcA[0] += (int64_t)na * stepA; srcA[1] += (int64_t)na * stepA;
@@ -1453,8 +1518,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-          ts[row * 32 + (r ^ ((row & 7) << 2))] = acc[u >> 2][u & 3][e];
+          const int row = erow(e);
+          ts[row * 32 + (ecol(e) ^ ((row & 7) << 2))] = aget(u >> 2, u & 3, e);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -1506,7 +1571,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       for (int j = 0; j < 4; ++j) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int e = 0; e < 16; ++e) ts[r * 33 + (e & 3) + 8 * (e >> 2) + 4 * h] = acc[i][j][e];
+        for (int e = 0; e < 16; ++e) ts[ecol(e) * 33 + erow(e)] = aget(i, j, e);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int64_t mrow0 = col0 + wn * 128 + j * 32;
         const int64_t mcol = row0 + wm * 128 + i * 32 + r;

@@ -433,7 +433,7 @@ def next_b_order(pairs):
     return [(ct, 0) for ct in range(8)] + [(ct, 1) for ct in range(8)]
 
 
-def one_tile16(e, G, req_gaps, S_CUR, S_NXT, S_NN, nop_m0=True, barrier="full", dma=True, barrier_gap=96, split_req=True, pairs=False, m0_early=False):
+def one_tile16(e, G, req_gaps, S_CUR, S_NXT, S_NN, nop_m0=True, barrier="full", dma=True, barrier_gap=96, split_req=True, pairs=False, m0_early=False, merge_waits=0, transposed=False):
     reqs = G.requests()
     assert len(req_gaps) == len(reqs)
     for c in range(3):
@@ -516,8 +516,15 @@ def one_tile16(e, G, req_gaps, S_CUR, S_NXT, S_NN, nop_m0=True, barrier="full", 
     for g, (rt, ct, m) in enumerate(stream):
         emit_fillers(g)
         d = 0 if m == 0 else 1
-        e.need([f"A{rt}{m}", f"B{ct}{d}"])
-        e.raw(f"v_mfma_f32_16x16x32_bf16 {G.acc(rt, ct)}, {G.va(rt & 1, m)}, {G.vb(ct, d)}, {G.acc(rt, ct)}")
+        want_now = [f"A{rt}{m}", f"B{ct}{d}"]
+        if merge_waits and m == 0 and ct == 0:
+            want_now += [f"A{rt}1", f"A{rt}2"]       # one wait for the row tile's three A fragments (read 24 MFMAs ago)
+        if merge_waits >= 2 and rt == 0 and ct % merge_waits == 0:
+            want_now += [f"B{c2}{d}" for c2 in range(ct, min(ct + merge_waits, 8))]
+        e.need(want_now)
+        # (B fragment first: the instruction computes the transposed tile -- a lane's four values are consecutive in a row of C)
+        first, second = (G.vb(ct, d), G.va(rt & 1, m)) if transposed else (G.va(rt & 1, m), G.vb(ct, d))
+        e.raw(f"v_mfma_f32_16x16x32_bf16 {G.acc(rt, ct)}, {first}, {second}, {G.acc(rt, ct)}")
     emit_fillers(N)
     emit_fillers(N + 1)
     want = [f"N0{c}" for c in range(3)] + [f"NB{ct}{d}" for ct, d in next_b_order(pairs)]
@@ -620,7 +627,11 @@ def variants():
         "BX_KLOOP_ASM_F1": (gen16, dict(req_gaps=early)),                       # requests right behind the barrier
         "BX_KLOOP_ASM_F2": (gen16, dict(split_req=False)),
         "BX_KLOOP_ASM_F3": (gen16, dict(barrier_gap=72, req_gaps=[76, 80, 84, 88, 92, 100, 104, 108, 112, 116, 124, 128])),
-        "BX_KLOOP_ASM_F4": (gen16, dict(pairs=True)),                           # row tiles 0 and 7 column pair by column pair
+        "BX_KLOOP_ASM_F4": (gen16, dict(pairs=True)),
+        "BX_KLOOP_ASM_F6": (gen16, dict(m0_early=True, merge_waits=1)),         # one lgkm wait per row tile for its A fragments
+        "BX_KLOOP_ASM_F7": (gen16, dict(m0_early=True, merge_waits=2)),         # + the B fragments of row tile 0 two at a time
+        "BX_KLOOP_ASM_F8": (gen16, dict(m0_early=True, merge_waits=4)),         # + four at a time
+        "BX_KLOOP_ASM_F9": (gen16, dict(m0_early=True, transposed=True)),       # B fragment first (-DBX_S16_TRANSPOSED=1): the transposed tile                           # row tiles 0 and 7 column pair by column pair
         "BX_KLOOP_ASM_F5": (gen16, dict(m0_early=False)),                       # M0 written right in front of its request (+ s_nop)
         # ---- TIMING ONLY (wrong results)
         "BX_KLOOP_ASM_U1": (gen16, dict(barrier="none")),

@@ -22,6 +22,17 @@ for kind in ("randn", "half zeros"):
         t0 = time.perf_counter(); kernels.gram_syrk(A, out=G); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     t = sorted(ts)[1]
     res.append(f"{kind}: {t*1e3:.1f} ms = {n*(n+1)*p/t/1e12:.1f} TF")
+# a rank-1024 update C -= V W^T of a 20480 x 20480 block (the band reduction's trailing update / Q1's shape: one 64-tile chain + flush)
+del A, G
+m, k = 20480, 1024
+V = torch.randn(m, k, device=dev); W = torch.randn(m, k, device=dev); C = torch.randn(m, m, device=dev)
+kernels.gemm_nt(V, W, out=C, alpha=-1.0, beta=1.0); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    kernels.gemm_nt(V, W, out=C, alpha=-1.0, beta=1.0)
+torch.cuda.synchronize()
+t = (time.perf_counter() - t0) / 10
+res.append(f"rank-1024 update of 20480^2: {t*1e3:.2f} ms = {2*m*m*k/t/1e12:.1f} TF")
 print(os.environ.get("VIVIT_HIP_LIB"), " | ".join(res), flush=True)
 PY
 }

@@ -964,6 +964,15 @@ __device__ unsigned long long *g_bx_stamp = nullptr;
 __device__ unsigned int g_bx_stamp_cap = 0;
 #endif
 
+#ifndef BX_S16_TRANSPOSED
+#define BX_S16_TRANSPOSED 0   // 1: B fragment first (a lane holds four consecutive columns of a row; needs the asm block BX_KLOOP_ASM_F9)
+#endif
+#ifndef BX_FLUSH_ROWS
+#define BX_FLUSH_ROWS 1   // rows of 32 x 32 blocks whose old values are in flight together in the register flush (2: the same time; 4: spills, + 4 %)
+#endif
+#ifndef BX_SWZ_MASK
+#define BX_SWZ_MASK 7   // rows of the flush patch are rotated by (row & mask) float4 units (experiments: 3)
+#endif
 #ifndef BX_SHAPE16
 #define BX_SHAPE16 1   // 0: the six-product kernel on v_mfma_f32_32x32x16_bf16 as in rounds 2-5 (same-box comparisons)
 #endif
@@ -1055,13 +1064,20 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   // Accumulator layout.  The six-product kernel computes on v_mfma_f32_16x16x32_bf16 (S16): the 32 x 32 block acc[i][j] is four
-  // 16 x 16 tiles (tr, tc) in registers 4 (2 tr + tc) .. + 3, lane l holding rows 4 (l / 16) .. + 3 of column l % 16 of each; the
-  // other kernels on v_mfma_f32_32x32x16_bf16 (register e = rows (e & 3) + 8 (e >> 2) + 4 (l / 32) of column l % 32).
+  // 16 x 16 tiles (tr, tc) in registers 4 (2 tr + tc) .. + 3, lane l holding rows 4 (l / 16) .. + 3 of column l % 16 of each.
+  // (S16T, -DBX_S16_TRANSPOSED=1: with the B fragment as the instruction's first operand a lane holds row l % 16 and the four
+  // CONSECUTIVE columns 4 (l / 16) .. + 3 instead -- bit-identical sums, one 16-byte access per tile in the flush and a mirrored
+  // store that is coalesced as it stands; measured SLOWER on the same box, profiles/r06_syrk_ab_transposed.log: headline-shaped
+  // SYRK 875 / 783 against 866 / 772 ms, rank-1024 update of 20480^2 4.18 against 3.94 ms.)
+  // The other kernels on v_mfma_f32_32x32x16_bf16 (register e = rows (e & 3) + 8 (e >> 2) + 4 (l / 32) of column l % 32).
   const int r16 = lane & 15, kb = lane >> 4;
   // element e of a block: (row, column) = (lrow + erc(e), lcol + ecc(e)), a lane part and a part that is a constant per register
-  const int lrow = S16 ? 4 * kb : 4 * h, lcol = S16 ? r16 : r;
-  auto erc = [](int e) __attribute__((always_inline)) -> int { return S16 ? 16 * (e >> 3) + (e & 3) : (e & 3) + 8 * (e >> 2); };
-  auto ecc = [](int e) __attribute__((always_inline)) -> int { return S16 ? 16 * ((e >> 2) & 1) : 0; };
+  constexpr bool S16T = S16 && BX_S16_TRANSPOSED != 0;
+  const int lrow = S16T ? r16 : S16 ? 4 * kb : 4 * h, lcol = S16T ? 4 * kb : S16 ? r16 : r;
+  auto erc = [](int e) __attribute__((always_inline)) -> int {
+    return S16T ? 16 * (e >> 3) : S16 ? 16 * (e >> 3) + (e & 3) : (e & 3) + 8 * (e >> 2);
+  };
+  auto ecc = [](int e) __attribute__((always_inline)) -> int { return S16T ? 16 * ((e >> 2) & 1) + (e & 3) : S16 ? 16 * ((e >> 2) & 1) : 0; };
   auto erow = [&](int e) __attribute__((always_inline)) -> int { return lrow + erc(e); };
   auto ecol = [&](int e) __attribute__((always_inline)) -> int { return lcol + ecc(e); };
   const int64_t row0 = (int64_t)ti * B2, col0 = (int64_t)tj * B2;
@@ -1097,58 +1113,97 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   auto ld_l2 = [](gptr q) __attribute__((always_inline)) -> float {
     return __hip_atomic_load((const float *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
+  typedef f32x4 __attribute__((address_space(1))) *gptr4w;
+  const bool c_vec = (reinterpret_cast<uintptr_t>(Cout) & 15) == 0 && (ldc & 3) == 0 && (col0 & 3) == 0;
   auto flush_to_c = [&](bool first) __attribute__((always_inline)) {
     const float beta = first ? beta_ : 1.f;
     int opaque = 0;
     __asm__ volatile("" : "+v"(opaque));  // keeps the 256 output addresses out of LICM's reach (see gemm256_kernel)
+    // BX_FLUSH_ROWS rows of four 32 x 32 blocks at a time: 64 loads per row in flight, then as many stores (block by block - 16
+    // loads, wait, 16 stores - the read-modify-write cost ~40 us per 256 x 256 tile: half of a K = 512 update's time)
+    constexpr int NR = BX_FLUSH_ROWS;
+    // (the 16-byte loads of the vector path are plain loads: earlier chains of this tile went into C by L2 atomics, which the L1
+    // does not see -- drop its lines first)
+    if (S16T && !first) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // one row of four 32 x 32 tiles at a time: 64 loads in flight, then 64 stores (tile by tile - 16 loads, wait,
-      // 16 stores - the read-modify-write cost ~40 us per 256 x 256 tile: half of a K = 512 update's time)
+    for (int i0 = 0; i0 < 4; i0 += NR) {
       __asm__ volatile("" ::: "memory");
-      const int64_t rbase = row0 + wm * 128 + i * 32 + lrow + opaque;
-      if (full_tile) {
-        float old[4][16];
+      const int64_t rbase0 = row0 + wm * 128 + i0 * 32 + lrow + opaque;
+      if (S16T && full_tile && c_vec) {
+        // a lane's four values of a 16 x 16 tile are consecutive in its row of C: one 16-byte load and store per tile
+        f32x4 old[NR][4][4];
         if (beta != 0.f) {
 #pragma unroll
+          for (int ii = 0; ii < NR; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              gptr cbase = Cout + (rbase0 + ii * 32) * ldc + (col0 + wn * 128 + j * 32 + lcol);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) old[ii][j][q] = *(gptr4w)(cbase + (int64_t)erc(4 * q) * ldc + ecc(4 * q));
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < NR; ++ii)
+#pragma unroll
           for (int j = 0; j < 4; ++j) {
-            gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + lcol);
+            gptr cbase = Cout + (rbase0 + ii * 32) * ldc + (col0 + wn * 128 + j * 32 + lcol);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) old[j][e] = ld_l2(cbase + (int64_t)erc(e) * ldc + ecc(e));
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v;
+#pragma unroll
+              for (int e4 = 0; e4 < 4; ++e4) v[e4] = alpha_ * aget(i0 + ii, j, 4 * q + e4);
+              if (beta != 0.f) v += beta * old[ii][j][q];
+              *(gptr4w)(cbase + (int64_t)erc(4 * q) * ldc + ecc(4 * q)) = v;
+#pragma unroll
+              for (int e4 = 0; e4 < 4; ++e4) aset(i0 + ii, j, 4 * q + e4, v[e4]);
+            }
           }
+      } else if (full_tile) {
+        float old[NR][4][16];
+        if (beta != 0.f) {
+#pragma unroll
+          for (int ii = 0; ii < NR; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              gptr cbase = Cout + (rbase0 + ii * 32) * ldc + (col0 + wn * 128 + j * 32 + lcol);
+#pragma unroll
+              for (int e = 0; e < 16; ++e) old[ii][j][e] = ld_l2(cbase + (int64_t)erc(e) * ldc + ecc(e));
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          gptr cbase = Cout + rbase * ldc + (col0 + wn * 128 + j * 32 + lcol);
+        for (int ii = 0; ii < NR; ++ii)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float v = alpha_ * aget(i, j, e);
-            if (beta != 0.f) v += beta * old[j][e];
-            cbase[(int64_t)erc(e) * ldc + ecc(e)] = v;
-            aset(i, j, e, v);
+          for (int j = 0; j < 4; ++j) {
+            gptr cbase = Cout + (rbase0 + ii * 32) * ldc + (col0 + wn * 128 + j * 32 + lcol);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              float v = alpha_ * aget(i0 + ii, j, e);
+              if (beta != 0.f) v += beta * old[ii][j][e];
+              cbase[(int64_t)erc(e) * ldc + ecc(e)] = v;
+              aset(i0 + ii, j, e, v);
+            }
           }
-        }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int ii = 0; ii < NR; ++ii)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int64_t row = rbase + erc(e), col = col0 + wn * 128 + j * 32 + ecol(e);
-            float v = alpha_ * aget(i, j, e);
-            if (row < p.M && col < p.N) {
-              gptr c = Cout + row * ldc + col;
-              if (beta != 0.f) v += beta * ld_l2(c);
-              *c = v;
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int64_t row = rbase0 + ii * 32 + erc(e), col = col0 + wn * 128 + j * 32 + ecol(e);
+              float v = alpha_ * aget(i0 + ii, j, e);
+              if (row < p.M && col < p.N) {
+                gptr c = Cout + row * ldc + col;
+                if (beta != 0.f) v += beta * ld_l2(c);
+                *c = v;
+              }
+              aset(i0 + ii, j, e, v);
             }
-            aset(i, j, e, v);
           }
-        }
       }
     }
   };
 
-  typedef f32x4 __attribute__((address_space(1))) *gptr4w;
-  const bool c_vec = (reinterpret_cast<uintptr_t>(Cout) & 15) == 0 && (ldc & 3) == 0;
   // The flush INSIDE the K loop (end of an accumulation chain): C += alpha * acc with no-return fp32 atomics executed in
   // the L2 (global_atomic_add_f32: a correctly rounded fp32 add, exactly the VALU add of the other flushes), or a plain
   // store when this is the tile's first flush and beta = 0 (the host passes only beta = 0 or 1 and scales C beforehand
@@ -1287,7 +1342,8 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
         for (int m = 0; m < 3; ++m)   // (the four tiles in turn: consecutive instructions never share an accumulator)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
-            acc[i][j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v[m][t >> 1], fb.v[m == 0 ? 0 : 1][2 * j + (t & 1)], acc[i][j][t], 0, 0, 0);
+            acc[i][j][t] = S16T ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb.v[m == 0 ? 0 : 1][2 * j + (t & 1)], fa.v[m][t >> 1], acc[i][j][t], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v[m][t >> 1], fb.v[m == 0 ? 0 : 1][2 * j + (t & 1)], acc[i][j][t], 0, 0, 0);
       } else {
         f32x16 c = acc[i][j][0];
         if (NPROD >= 9) {
@@ -1519,12 +1575,15 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = erow(e);
-          ts[row * 32 + (ecol(e) ^ ((row & 7) << 2))] = aget(u >> 2, u & 3, e);
+#if defined(BX_FLUSH_EXP) && BX_FLUSH_EXP == 1   // timing only: no patch writes
+          if (p.alpha == 12345.678f)
+#endif
+          ts[row * 32 + (ecol(e) ^ ((row & BX_SWZ_MASK) << 2))] = aget(u >> 2, u & 3, e);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          float *tp = ts + (8 * it + rr) * 32 + 4 * (c4 ^ (rr & 7));
+          float *tp = ts + (8 * it + rr) * 32 + 4 * (c4 ^ (rr & BX_SWZ_MASK));
           f32x4 v = *reinterpret_cast<const f32x4 *>(tp);
           v = alpha_ * v;
           if (pre) v += beta * *reinterpret_cast<const f32x4 *>(oldp + (k & 3) * 8192 + t * 4096 + it * 1024);
@@ -1537,7 +1596,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const int col = 2 * q + h;
-            mbase[(int64_t)(2 * q) * p.ldc] = ts[r * 32 + (col ^ ((r & 7) << 2))];
+            mbase[(int64_t)(2 * q) * p.ldc] = ts[r * 32 + (col ^ ((r & BX_SWZ_MASK) << 2))];
           }
         }
       }
@@ -1547,10 +1606,17 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
       }
     }
   };
-#if defined(BX_OLD_FINAL)   // experiment: the register read-modify-write for every last flush
-  const bool fast_tile = false;
-#else
+  // Which last flush: since the asm K loop the register read-modify-write (flush_to_c) wins -- inside flush_final hipcc reloads
+  // spilled lane constants from scratch and waits for them with vmcnt(0), which also waits for every old-value request in flight
+  // (same box, headline-shaped SYRK on N(0,1) / half-zero data and a rank-1024 update of 20480^2, profiles/r06_syrk_ab_flush.log:
+  // flush_final 893 / 801 ms, 4.47 ms; flush_to_c 867 / 773 ms, 3.97 ms; flush_final for mirrored tiles only 916 / 807 ms, 5.04 ms).
+  // -DBX_FINAL_DMA=1 / 2 builds the LDS-DMA flush for every full tile / for mirrored tiles only.
+#if defined(BX_FINAL_DMA) && BX_FINAL_DMA == 2
+  const bool fast_tile = full_tile && c_vec && mirrored;
+#elif defined(BX_FINAL_DMA) && BX_FINAL_DMA == 1
   const bool fast_tile = full_tile && c_vec;
+#else
+  const bool fast_tile = false;
 #endif
 #if defined(BX_EXP) && BX_EXP == 1   // timing only: no final flush
   if (p.alpha == 12345.678f)
@@ -1562,7 +1628,21 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   else
     flush_mid(false);
 
-  if (mirrored && !fast_tile) {
+  if (S16T && mirrored && !fast_tile) {
+    // the transposed image: for a fixed register the lanes of a row group hold 16 consecutive ROWS of one column of the tile,
+    // i.e. 64 consecutive bytes of the image's row -- stored as they are
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t mcol = row0 + wm * 128 + i * 32 + lrow, mrow0 = col0 + wn * 128 + j * 32 + lcol;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t mr = mrow0 + ecc(e), mc = mcol + erc(e);
+          if (mr < p.N && mc < p.M) *((gptr)p.C + mr * p.ldc + mc) = aget(i, j, e);
+        }
+      }
+  } else if (mirrored && !fast_tile) {
     __syncthreads();
     float *ts = reinterpret_cast<float *>(smem_bx) + wave * (32 * 33);
 #pragma unroll

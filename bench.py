@@ -48,7 +48,9 @@ SYRK_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * 3695931059.375 + 2766
 # Round 5 (profiles/r05_pmc/pmc_syrk_*, final code: the same 98 + 98 launches): 4.78 TB fetched / 0.83 TB written.
 # Round 6 (profiles/r06_pmc/pmc_syrk_*, final code: the asm K loop, the same 98 + 98 launches): FETCH_SIZE 2.3295e9 + 3.2237e7 KiB,
 # WRITE_SIZE 7.9816e8 + 9.6339e7 KiB = 4.84 TB fetched (with the wide-read correction) / 0.92 TB written.
-SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.3295e9 + 3.2237e7) + (7.9816e8 + 9.6339e7)) * 1024.0}
+# Round 6, second half (profiles/r06_pmc_s16/pmc_syrk_*, final code: 16x16x32 MFMAs, register flush, the same 98 + 98 launches): FETCH_SIZE
+# 2.4568e9 + 3.2238e7 KiB, WRITE_SIZE 6.3943e8 + 9.6339e7 KiB = 5.10 TB fetched (with the wide-read correction) / 0.75 TB written.
+SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.4568e9 + 3.2238e7) + (6.3943e8 + 9.6339e7)) * 1024.0}
 # clock the chip holds under that kernel, measured OUTSIDE this process (the product library carries no stamps):
 # in-kernel s_memtime / s_memrealtime stamps of a diagnostic build (scripts/probe/bx_clock.py + libstamp.so, median over
 # the 12 880 workgroups of the last chunk launch after 6 s of back-to-back SYRKs on the bench's own factors;
@@ -64,16 +66,26 @@ SYRK_BX_TRAFFIC_BYTES_PMC = {("mlp784-512-10_b4096", 1): (2 * (2.3295e9 + 3.2237
 # 3.7763e10 / 8 over 2.771 s = 1.703 GHz, SQ_VALU_MFMA_BUSY_CYCLES 3.9707e12 over 1024 SIMDs = 82.1 % of the cycles; the bench's own factor:
 # 3.7714e10 / 8 over 2.403 s = 1.962 GHz, 82.3 %: 280.3 TFLOP/s = 0.823 x 1.962 / 2.4 = 0.672 of the ceiling (round 5: 77.1 % at 1.996 GHz = 0.641).
 # The pipe is busier (77 -> 82 %) and the chip answers with a lower clock (DVFS give-back): - 7 % cycles of the K loop are - 3.8 % of its time.
-SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_real_factors_k_loop": 1.9, "in_kernel_stamps_randn_k_loop": 1.7,
-                                                  "pmc_grbm_gui_active_randn": 1.703, "pmc_grbm_gui_active_bench_factors": 1.962, "nominal": 2.4,
-                                                  "mfma_pipe_busy_pmc": 0.821, "mfma_pipe_busy_pmc_bench_factors": 0.823}}
+# round 6, second half (profiles/r06_pmc_s16/pmc_syrk_mfma_*, profiles/r06_pmc_s16_summary.txt; final code = v_mfma_f32_16x16x32_bf16 with two partial
+# products fused per instruction + the register flush): N(0,1) data: GRBM_GUI_ACTIVE 3.7401e10 / 8 over 2.621 s = 1.784 GHz, 82.9 % of the cycles;
+# the bench's own factor: 3.7744e10 / 8 over 2.268 s = 2.080 GHz, 82.2 %: 297.0 TFLOP/s = 0.822 x 2.080 / 2.4 = 0.712 of the ceiling.  Same busy
+# fraction as the 32x32x16 form above (the K loop needs 5 % MORE cycles, the flush fewer), but the chip holds a 5-6 % higher clock on this shape.
+SYRK_BX_CLOCK_GHZ = {("mlp784-512-10_b4096", 1): {"in_kernel_stamps_half_zero_k_loop": 2.1, "in_kernel_stamps_randn_k_loop": 1.8,
+                                                  "pmc_grbm_gui_active_randn": 1.784, "pmc_grbm_gui_active_bench_factors": 2.080, "nominal": 2.4,
+                                                  "mfma_pipe_busy_pmc": 0.829, "mfma_pipe_busy_pmc_bench_factors": 0.822}}
 # What the SAME per-K-tile instruction mix reaches with every byte of data movement removed (operand pieces in LDS once; no
 # DMA, barrier, flush): scripts/probe/bx_bare_loop.hip, profiles/r05_bx_bare_loop.log -- fraction of the bf16 / 6 ceiling and the
 # clock the chip holds, by operand data.  The power limit, not the kernel, takes the rest of the nominal peak.
-BX_BARE_LOOP_CEILING = {"randn": {"frac": 0.708, "tflops_fp32_equiv": 296.8, "clock_ghz": 1.778},
-                        "half_zeros_like_the_bench_factors": {"frac": 0.787, "tflops_fp32_equiv": 330.0, "clock_ghz": 1.969},
-                        "zeros": {"frac": 0.976, "tflops_fp32_equiv": 409.3, "clock_ghz": 2.383},
-                        "source": "scripts/probe/bx_bare_loop.hip on one MI355X, 3 s per data kind, all 256 CUs (profiles/r05_bx_bare_loop.log)"}
+# That probe is the 32x32x16 instruction mix.  For the product's 16x16x32 mix the same question is answered by the product's own asm block
+# built without requests and without the barrier (timing-only variant U3 of scripts/gen_bx_kloop.py, in-kernel stamps,
+# profiles/r06_bx16_timeline.log): 3351 core cycles per K tile at 2.4 GHz on half-zero data = 2 * 256^2 * 16 flop / 1.396 us x 256 CUs.
+BX_BARE_LOOP_CEILING = {"mfma_32x32x16_mix": {"randn": {"frac": 0.708, "tflops_fp32_equiv": 296.8, "clock_ghz": 1.778},
+                                              "half_zeros_like_the_bench_factors": {"frac": 0.787, "tflops_fp32_equiv": 330.0, "clock_ghz": 1.969},
+                                              "zeros": {"frac": 0.976, "tflops_fp32_equiv": 409.3, "clock_ghz": 2.383}},
+                        "half_zeros_like_the_bench_factors": {"frac": 0.917, "tflops_fp32_equiv": 384.6, "clock_ghz": 2.4, "cycles_per_k_tile": 3351},
+                        "source": "the product's 16x16x32 K loop without requests and barrier (variant U3, profiles/r06_bx16_timeline.log); 32x32x16 mix: "
+                                  "scripts/probe/bx_bare_loop.hip on one MI355X, 3 s per data kind, all 256 CUs (profiles/r05_bx_bare_loop.log, "
+                                  "profiles/r06_bx_bare_loop_s16_v1.log)"}
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
 MFMA_BF16_PEAK_TF = 2516.6  # dense bf16 MFMA peak (256 CU x 4 SIMD x 1024 flop/cycle x 2.4 GHz; same guide)
 
@@ -87,14 +99,15 @@ WORKLOADS = {
 
 # the committed rocprofv3 outputs behind roofline.traffic / clock_ghz / clock_note (separate --pmc passes + kernel trace of the same command)
 PMC_FILES = {
-    "traffic": ["profiles/r06_pmc/pmc_syrk_FETCH_SIZE_counter_collection.csv", "profiles/r06_pmc/pmc_syrk_WRITE_SIZE_counter_collection.csv",
-                "profiles/r06_pmc/pmc_syrk_FETCH_SIZE_kernel_trace.csv", "profiles/r06_pmc/pmc_syrk_WRITE_SIZE_kernel_trace.csv"],
-    "clock_and_pipe_busy_randn": ["profiles/r06_pmc/pmc_syrk_mfma_counter_collection.csv", "profiles/r06_pmc/pmc_syrk_mfma_kernel_trace.csv"],
-    "clock_and_pipe_busy_bench_factor": ["profiles/r06_pmc/pmc_syrk_mfma_bench_counter_collection.csv", "profiles/r06_pmc/pmc_syrk_mfma_bench_kernel_trace.csv"],
-    "summary": "profiles/r06_pmc_summary.txt (scripts/r06_pmc_summary.py over the passes above)",
+    "traffic": ["profiles/r06_pmc_s16/pmc_syrk_FETCH_SIZE_counter_collection.csv", "profiles/r06_pmc_s16/pmc_syrk_WRITE_SIZE_counter_collection.csv",
+                "profiles/r06_pmc_s16/pmc_syrk_FETCH_SIZE_kernel_trace.csv", "profiles/r06_pmc_s16/pmc_syrk_WRITE_SIZE_kernel_trace.csv"],
+    "clock_and_pipe_busy_randn": ["profiles/r06_pmc_s16/pmc_syrk_mfma_counter_collection.csv", "profiles/r06_pmc_s16/pmc_syrk_mfma_kernel_trace.csv"],
+    "clock_and_pipe_busy_bench_factor": ["profiles/r06_pmc_s16/pmc_syrk_mfma_bench_counter_collection.csv",
+                                         "profiles/r06_pmc_s16/pmc_syrk_mfma_bench_kernel_trace.csv"],
+    "summary": "profiles/r06_pmc_s16_summary.txt (scripts/r06_pmc_summary.py over the passes above)",
     "command": "scripts/r06_measure.sh (rocprofv3 --pmc <counter> --kernel-trace -- python3 scripts/pmc_syrk_full.py [bench])",
-    "kernel_trace_of_the_bench": "profiles/r06_bench_n40960_kernel_stats.csv",
-    "in_kernel_cycles_per_k_tile": "profiles/r06_bx_attribution_product.log (scripts/probe/bx_timeline.py on -DBX_STAMP=2 builds)",
+    "kernel_trace_of_the_bench": "profiles/r06_bench_n40960_s16_kernel_stats.csv",
+    "in_kernel_cycles_per_k_tile": "profiles/r06_bx16_timeline.log (scripts/probe/bx_timeline.py on -DBX_STAMP=2 builds)",
 }
 
 
@@ -940,7 +953,8 @@ def main():
                 peak = MFMA_BF16_PEAK_TF / split
                 roofline = {
                     "kernel": f"gemm256_bx_kernel<{split}, asm K loop> (Gram SYRK: fp32 operands split exactly into 3 bf16 pieces, {split} of 9 "
-                              f"partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulation) + bx_split_kernel",
+                              f"partial products on {'v_mfma_f32_16x16x32_bf16, two fused per instruction' if split == 6 else 'v_mfma_f32_32x32x16_bf16'}, "
+                              f"fp32 accumulation) + bx_split_kernel",
                     "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                     "peak_note": f"dense bf16 MFMA peak {MFMA_BF16_PEAK_TF} TFLOP/s / {split} partial products per fp32 product; "
                                  f"achieved = algorithmic fp32 flops n(n+1)P per second",
@@ -948,13 +962,13 @@ def main():
                     "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TF,
                     "traffic": SYRK_BX_TRAFFIC_BYTES_PMC.get((args.workload, world)) if split == 6 else None,
                     "traffic_note": "bytes of the first-layer weight's SYRK (98.6 % of the Gram flops: 98 split + 98 product launches of "
-                                    "4096 columns) on N(0,1) data, separate rocprofv3 --pmc passes of the final code (profiles/r06_pmc/pmc_syrk_*: "
-                                    "FETCH_SIZE 2.3295e9 + 3.2237e7 KiB, WRITE_SIZE 7.9816e8 + 9.6339e7 KiB), FETCH_SIZE includes Infinity-Cache hits",
+                                    "4096 columns) on N(0,1) data, separate rocprofv3 --pmc passes of the final code (profiles/r06_pmc_s16/pmc_syrk_*: "
+                                    "FETCH_SIZE 2.4568e9 + 3.2238e7 KiB, WRITE_SIZE 6.3943e8 + 9.6339e7 KiB), FETCH_SIZE includes Infinity-Cache hits",
                     "clock_ghz": SYRK_BX_CLOCK_GHZ.get((args.workload, world)) if split == 6 else None,
                     "clock_note": "the chip lowers its clock under the bf16 MFMA load: frac = (matrix-pipe busy 0.82) x (clock / 2.4 GHz); NOT "
-                                  "measured in this run: in-kernel stamps of a diagnostic build around the K loop (profiles/r06_bx_attribution_product.log), "
+                                  "measured in this run: in-kernel stamps of a diagnostic build around the K loop (profiles/r06_bx16_timeline.log), "
                                   "GRBM_GUI_ACTIVE / SQ_VALU_MFMA_BUSY_CYCLES of a PMC pass over the 98 launches of the first-layer SYRK on N(0,1) data and on "
-                                  "the bench's own factor (files: pmc_files; summary: profiles/r06_pmc_summary.txt)",
+                                  "the bench's own factor (files: pmc_files; summary: profiles/r06_pmc_s16_summary.txt)",
                     "pmc_files": PMC_FILES if split == 6 else None,
                     "bare_loop_ceiling": BX_BARE_LOOP_CEILING if split == 6 else None,
                     "frac_of_bare_loop_on_like_data": (achieved / BX_BARE_LOOP_CEILING["half_zeros_like_the_bench_factors"]["tflops_fp32_equiv"])

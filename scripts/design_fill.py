@@ -1,5 +1,5 @@
 """DESIGN.md = scripts/design_template.md with the numbers of one bench.py JSON line filled in (phase table, measured block,
-config table).   usage: python scripts/design_fill.py profiles/r06_bench_n40960_final.json"""
+config table).   usage: python scripts/design_fill.py profiles/r06_bench_n40960_s16.json"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 bench = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
@@ -24,10 +24,10 @@ for r in bench["roofline_phases"]:
 t = t.replace("{{PHASE_TABLE}}", "\n".join(rows))
 ph = bench["phases"]
 t = t.replace("{{STEP_S}}", f"{bench['ms_per_step'] / 1e3:.3f}").replace("{{GRAM_S}}", f"{ph['gram_s']:.2f}").replace("{{EIG_S}}", f"{ph['symeig_s']:.2f}")
-t = t.replace("{{VALUE}}", f"{bench['value']:.0f}").replace("{{BOX}}", "one MI355X, 20 steps after 5 warm-up steps")
+t = t.replace("{{BENCH_FILE}}", os.path.basename(sys.argv[1])).replace("{{VALUE}}", f"{bench['value']:.0f}").replace("{{BOX}}", "one MI355X, 20 steps after 5 warm-up steps")
 rf, cb, v = bench["roofline"], bench["cpu_baseline"], bench["verified"]
 sp = bench["ms_per_step_spread"]
-blk = (f"Last run with the driver's flags (`python bench.py --steps 20 --warmup 5`, `profiles/r06_bench_n40960_final.json`): **{bench['value']:.0f} eigenpairs/s** "
+blk = (f"Last run with the driver's flags (`python bench.py --steps 20 --warmup 5`, `profiles/{os.path.basename(sys.argv[1])}`): **{bench['value']:.0f} eigenpairs/s** "
        f"({bench['ms_per_step']:.1f} ms per step; per-step min / median / max {sp['min']:.1f} / {sp['median']:.1f} / {sp['max']:.1f} ms); `roofline`: {rf['achieved']:.1f} TF of "
        f"fp32 work = **{rf['frac']:.3f}** of the bf16 / 6 ceiling (= {rf['vs_fp32_mfma_peak']:.2f} x the fp32 MFMA peak), traffic {rf['traffic'] / 1e12:.2f} TB per SYRK against "
        f"0.069 TB algorithmic (tile re-reads through L2 / MALL: not the limiter), clock under load {{CLOCK_TXT}}; `cpu_baseline` (oracle, {cb['cores']} threads of an "
@@ -43,7 +43,7 @@ for c in bench.get("configs", []):
     else:
         crow.append(f"| {c['config'].replace('|', '/')} | {c['backward_s'] * 1e3:.1f} ms | {c['factors_s'] * 1e3:.1f} ms | {c['total_s'] * 1e3:.1f} ms |")
 t = t.replace("{{CONFIG_TABLE}}", "\n".join(crow))
-t = t.replace("{CLOCK_TXT}", "1.96 GHz at 82.3 % matrix-pipe busy on the bench's own factor, 1.70 GHz at 82.1 % on N(0,1) data "
-              "(`profiles/r06_pmc_summary.txt`; round 5: 2.00 GHz at 77.1 %)")
+t = t.replace("{CLOCK_TXT}", "2.08 GHz at 82.2 % matrix-pipe busy on the bench's own factor, 1.78 GHz at 82.9 % on N(0,1) data "
+              "(`profiles/r06_pmc_s16_summary.txt`; the 32 x 32 x 16 form: 1.96 GHz at 82.3 %; round 5: 2.00 GHz at 77.1 %)")
 open(os.path.join(ROOT, 'DESIGN.md'), 'w').write(t)
 print(len(t.encode()), "bytes")

@@ -1621,6 +1621,14 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #if defined(BX_EXP) && BX_EXP == 1   // timing only: no final flush
   if (p.alpha == 12345.678f)
 #endif
+#if defined(BX_FINAL_ATOMIC) && BX_FINAL_ATOMIC
+  // experiment: C += alpha acc by no-return L2 atomics whenever the launch accumulates (beta = 1) and nothing needs the final values.
+  // Nothing is loaded or waited for -- and it is slower: the 1024 atomic instructions of a tile take 43 us to issue against 18 us for the
+  // read-modify-write (headline-shaped SYRK 865 / 759 against 843 / 744 ms, rank-1024 update 4.62 against 3.84 ms; profiles/r06_syrk_ab_atomic.log)
+  if (!mirrored && (!first_flush || beta_ == 1.f))
+    flush_mid(false);
+  else
+#endif
   if (!fast_tile)
     flush_to_c(first_flush);          // edge tiles / unaligned C; the mirror store below takes the values from the registers
   else if (mirrored || first_flush)

@@ -23,6 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # (n, K): 5120 rows = 210 lower 256-tiles -> chunked 256-tile launch; 1280 rows = 15 tiles -> split-K launch
 TILE_CASES = ["5120:2064", "5120:65552", "5120:401408", "5120:2064:mixed"]
 SPLITK_CASES = ["1280:65552", "1280:401408", "1280:65552:mixed"]
+NINE_CASES = ["5120:2064", "5120:65552", "5120:2064:mixed"]
 
 
 def _child(mode, cases, tmp_path):
@@ -42,6 +43,7 @@ def stats(tmp_path_factory):
         0: _child(0, TILE_CASES + SPLITK_CASES, tmp),   # fp32 MFMA kernels: the yardstick
         6: _child(6, TILE_CASES + SPLITK_CASES, tmp),   # default
         3: _child(3, TILE_CASES, tmp),                  # three partial products: must be caught
+        9: _child(9, NINE_CASES, tmp),                  # all nine partial products (32x32x16 MFMAs; optional mode)
     }
 
 
@@ -64,6 +66,18 @@ def test_default_path_is_fp32_class(stats, case):
     # relative error of the sums of squares on the diagonal (where truncation would show as a bias) below 2e-7
     assert bx["offdiag_rms"] <= 2.5e-6
     assert abs(bx["diag_mean"]) <= 2e-7 + 2.0 * abs(f32["diag_mean"])
+
+
+@pytest.mark.parametrize("case", NINE_CASES)
+def test_nine_partial_products_mode(stats, case):
+    """VIVIT_GEMM_SPLIT=9 (the three dropped partial products added; the kernel instance that stayed on 32x32x16 MFMAs when the default
+    moved to the fused 16x16x32 form): fp32-class by the same criterion and no worse than the default."""
+    f32, b9, b6 = stats[0][_key(case)], stats[9][_key(case)], stats[6][_key(case)]
+    print(case, "fp32 MFMA:", f32["offdiag_rms"], "bf16 x 9:", b9["offdiag_rms"], "bf16 x 6:", b6["offdiag_rms"])
+    assert b9["symmetric"] and b9["finite"] and b9["entries"] >= 500
+    for k in ("offdiag_rms", "mirror_rms", "diag_rms"):
+        assert b9[k] <= 2.0 * f32[k], (k, b9[k], f32[k])
+    assert b9["offdiag_rms"] <= 1.1 * b6["offdiag_rms"]
 
 
 @pytest.mark.parametrize("case", TILE_CASES)

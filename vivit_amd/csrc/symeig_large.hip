@@ -57,6 +57,29 @@ __global__ __launch_bounds__(KB) void bt_tfactor_kernel(const float *__restrict_
 // reflectors) so that the three products of the back-transformation have a long contraction / wide
 // output (the 256 x 256 tile kernel; Zt is streamed once per 1024 instead of once per 128 reflectors):
 //   H_1 H_2 = I - [Y1 Y2] [[T1, -T1 (Y1^T Y2) T2], [0, T2]] [Y1 Y2]^T        (applied recursively).
+// The merge tree T12 = -T1 (Y1^T Y2) T2 as TWO batched products per level (all pairs of a level are independent) instead of
+// two launches per pair: at 2048 reflectors 8 launches instead of 30 per super-block (Q1 at n = 40 960: 600 launches of 24 us).
+// The descriptors only depend on the buffers, so one tiny kernel writes them once per back-transformation:
+// per level (halves of size h, nb = KS / 2h pairs):  desc[at + q] : X_q = T1 S12,   desc[at + nb + q] : T12 = -X_q T2,   at += 2 nb.
+constexpr int BT_MAX_DESC = 2 * 32;   // 2 (nsub - 1) descriptors, nsub <= 32
+__global__ void bt_merge_desc_kernel(const float *S, float *T, float *X, int64_t KS, int64_t kb, GemmDesc *desc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int at = 0;
+  for (int64_t h = kb; h < KS; h *= 2) {
+    const int nb = (int)(KS / (2 * h));
+    for (int64_t o = 0, q = 0; o < KS; o += 2 * h, ++q) {
+      float *Xq = X + q * h * h;
+      GemmDesc d1, d2;
+      d1.A = T + o * (KS + 1); d1.B = S + o * KS + (o + h); d1.C = Xq;
+      d1.M = h; d1.N = h; d1.K = h; d1.lda = KS; d1.ldb = KS; d1.ldc = h;
+      d2.A = Xq; d2.B = T + (o + h) * (KS + 1); d2.C = T + o * KS + (o + h);
+      d2.M = h; d2.N = h; d2.K = h; d2.lda = h; d2.ldb = KS; d2.ldc = KS;
+      desc[at + q] = d1; desc[at + nb + q] = d2;
+    }
+    at += 2 * nb;
+  }
+}
+
 static int bt_nsub(int64_t n) {   // largest super-block (workspace sizing)
   static int forced = -2;
   if (forced == -2) { const char *e = getenv("VIVIT_BT_NSUB"); forced = e ? atoi(e) : -1; }
@@ -89,6 +112,7 @@ static size_t bt_workspace_bytes(int64_t n) {
   b += align_up(sizeof(float) * KS * n, 256);      // Yt
   b += align_up(sizeof(float) * n * KS, 256) * 2;  // W1, W2
   b += align_up(sizeof(float) * KS * KS, 256) * 3; // S, T, X
+  b += align_up(sizeof(GemmDesc) * BT_MAX_DESC, 256);   // merge-tree descriptors
   b += align_up(bt_gemm_ws_bytes(n), 256);
   return b + 512;
 }
@@ -108,6 +132,7 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
   float *S = (float *)take(sizeof(float) * KSmax * KSmax);
   float *T = (float *)take(sizeof(float) * KSmax * KSmax);
   float *X = (float *)take(sizeof(float) * KSmax * KSmax);
+  GemmDesc *mdesc = (GemmDesc *)take(sizeof(GemmDesc) * BT_MAX_DESC);
   const size_t gws_bytes = bt_gemm_ws_bytes(n);
   void *gws = take(gws_bytes);
   if (jmax < 0 || nrows <= 0) return VIVIT_OK;
@@ -121,6 +146,10 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
     }
   }
   int st;
+  if (nsub > 1) {
+    if (2 * (nsub - 1) > BT_MAX_DESC) return VIVIT_E_UNSUPPORTED;
+    bt_merge_desc_kernel<<<1, 64, 0, stream>>>(S, T, X, KS, (int64_t)KB, mdesc);
+  }
   for (int64_t a = (jmax / KS) * KS; a >= 0; a -= KS) {
     // reflector rows of the super-block (zero rows for indices beyond jmax), their Gram matrix, block T factors
     bt_extract_kernel<<<dim3((unsigned)cdiv(n, 256), (unsigned)KS), 256, 0, stream>>>(A, lda, ni, (int)a, Yt, shift, (int)jmax);
@@ -129,15 +158,18 @@ static int backtransform_launch(const float *A, int64_t n, int64_t lda, const fl
     if (nsub > 1 && hipMemsetAsync(T, 0, sizeof(float) * KS * KS, stream) != hipSuccess) return VIVIT_E_LAUNCH;
     // block T factors of the nsub diagonal blocks: one workgroup each, one launch
     bt_tfactor_kernel<<<nsub, KB, BT_TF_LDS, stream>>>(S, KS, tau, (int)jmax, (int)a, T, KS);
-    // merge tree: T12 = -T1 S12 T2 for halves of size h = KB, 2 KB, ...
-    for (int64_t h = KB; h < KS; h *= 2)
-      for (int64_t o = 0; o < KS; o += 2 * h) {
-        const float *T1 = T + o * (KS + 1), *T2 = T + (o + h) * (KS + 1), *S12 = S + o * KS + (o + h);
-        st = gemm_launch(LAY_K, LAY_M, T1, S12, X, h, h, h, KS, KS, h, 1.f, 0.f, false, gws, gws_bytes, stream);
+    // merge tree: T12 = -T1 S12 T2 for halves of size h = KB, 2 KB, ...: the pairs of a level as one batched launch per product
+    {
+      int at = 0;
+      for (int64_t h = KB; h < KS; h *= 2) {
+        const int batch = (int)(KS / (2 * h));
+        st = gemm_batched_launch(LAY_K, LAY_M, mdesc + at, batch, h, h, 1.f, 0.f, stream);
         if (st != VIVIT_OK) return st;
-        st = gemm_launch(LAY_K, LAY_M, X, T2, T + o * KS + (o + h), h, h, h, h, KS, KS, -1.f, 0.f, false, gws, gws_bytes, stream);
+        st = gemm_batched_launch(LAY_K, LAY_M, mdesc + at + batch, batch, h, h, -1.f, 0.f, stream);
         if (st != VIVIT_OK) return st;
+        at += 2 * batch;
       }
+    }
     const int64_t m = n - a;  // components a+shift .. n-1 carry the super-block's reflectors (the columns before
                               // are zero in Yt: starting at the aligned offset a keeps the operands 16-byte aligned)
     // W1[nrows x KS] = Zt[:, a:] * Yt[:, a:]^T

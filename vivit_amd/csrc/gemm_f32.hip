@@ -207,6 +207,37 @@ __device__ __forceinline__ bool map_tile(int syrk, int SBW, int tiles_m, int til
   return true;
 }
 
+// map_tile + the K split of the workgroup.  SBW >= 0: the split is blockIdx.y.  SBW < 0 (the split-K launches of SMALL outputs: one
+// partial super-block of v valid tiles): a COMPACT one-dimensional grid of 8 v ceil(nsplit / 8) workgroups, workgroup L -> tile
+// (L / 8) % v of split 8 (L / 8 / v) + L % 8.  Workgroups go to XCD L % 8, so ALL tiles of a split run on ONE XCD at about the same
+// time and share their operand panels in its L2 -- the padded grid (256 slots per split row, slots rotated over the XCDs) gave
+// every XCD tiles of many splits that share nothing, so the product ran at the HBM rate of 48 KB per K tile and workgroup, and its
+// 8 200 padding workgroups (each asking for a whole CU's LDS) queued for whatever CU was free: the config-1 Gram SYRK (n = 1280,
+// K = 401 408: 15 tiles x 34 splits) took 7.1 ms for 2.4 ms of tile time (profiles/r06_splitk_compact.log).
+__device__ __forceinline__ bool map_tile_z(int syrk, int SBW, int tiles_m, int tiles_n, int nsplit, int &ti, int &tj, int &zsplit) {
+  if (SBW >= 0) {
+    zsplit = (int)blockIdx.y;
+    return map_tile(syrk, SBW, tiles_m, tiles_n, ti, tj);
+  }
+  const int d = tiles_m < tiles_n ? tiles_m : tiles_n;
+  const int v = syrk ? d * (d + 1) / 2 : tiles_m * tiles_n;
+  const int L = (int)blockIdx.x, r = L >> 3;
+  const int idx = r % v;
+  zsplit = 8 * (r / v) + (L & 7);
+  if (zsplit >= nsplit) return false;
+  if (syrk) {
+    int a = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
+    while ((a + 1) * (a + 2) / 2 <= idx) ++a;
+    while (a * (a + 1) / 2 > idx) --a;
+    ti = a;
+    tj = idx - a * (a + 1) / 2;
+  } else {
+    ti = idx / tiles_n;
+    tj = idx % tiles_n;
+  }
+  return true;
+}
+
 // Number of valid tiles map_tile hands XCD `blockIdx.x & 7` in this workgroup's super-block (the members of its XCD
 // group: they share their operand panels through that XCD's L2), and the group's index.  Same geometry as map_tile.
 __device__ __forceinline__ int xcd_group(int syrk, int SBW, int tiles_m, int tiles_n, int &group) {
@@ -565,16 +596,16 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem2[];
   // stand-in for a bf16-pipe launch whose operand chunk is out of the split's range: runs only when the chunk is flagged
   if (p.gate && (*p.gate & p.gate_mask) == 0) return;
-  int ti, tj;
-  if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
+  int ti, tj, zsplit;
+  if (!map_tile_z(p.syrk, p.sbw, p.tiles_m, p.tiles_n, p.ksplit, ti, tj, zsplit)) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int64_t row0 = (int64_t)ti * B2, col0 = (int64_t)tj * B2;
-  // split-K (few tiles, deep K: Gram matrices of small batches): blockIdx.y owns [kbeg, kend) and writes a slab
-  const int64_t kbeg = (int64_t)blockIdx.y * p.kchunk;
+  // split-K (few tiles, deep K: Gram matrices of small batches): split zsplit owns [kbeg, kend) and writes a slab
+  const int64_t kbeg = (int64_t)zsplit * p.kchunk;
   const int64_t kend = (kbeg + p.kchunk < p.K) ? kbeg + p.kchunk : p.K;
   const int nt = (int)((kend - kbeg) / BK);  // K and kchunk are multiples of 16 (host)
   const bool partial = p.ksplit > 1;
@@ -590,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  gptr Cout = (gptr)(partial ? p.slab + (int64_t)blockIdx.y * p.M * p.N : p.C);
+  gptr Cout = (gptr)(partial ? p.slab + (int64_t)zsplit * p.M * p.N : p.C);
   const int64_t ldc = partial ? p.N : p.ldc;
   const float alpha_ = partial ? 1.f : p.alpha, beta_ = partial ? 0.f : p.beta;
   const bool full_tile = row0 + B2 <= p.M && col0 + B2 <= p.N;
@@ -1039,8 +1070,11 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
 #if !(defined(BX_EXP) && BX_EXP == 2)   // (experiment 2: timing without the gate check)
   if (p.gate && (*p.gate & p.gate_mask) != 0) return;  // the fp32 MFMA kernel takes this chunk
 #endif
-  int ti, tj;
-  if (!map_tile(p.syrk, p.sbw, p.tiles_m, p.tiles_n, ti, tj)) return;
+  int ti, tj, zsplit;
+  {
+    const int nt_all = (int)(p.K / BK);
+    if (!map_tile_z(p.syrk, p.sbw, p.tiles_m, p.tiles_n, p.kt_split > 0 ? (nt_all + p.kt_split - 1) / p.kt_split : 1, ti, tj, zsplit)) return;
+  }
 
   const int tid = threadIdx.x;
   if (p.sync) {
@@ -1084,7 +1118,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   int nt = (int)(p.K / BK);
   int64_t kt0 = 0;
   if (p.kt_split > 0) {
-    kt0 = (int64_t)blockIdx.y * p.kt_split;
+    kt0 = (int64_t)zsplit * p.kt_split;
     nt = nt - (int)kt0 < p.kt_split ? nt - (int)kt0 : p.kt_split;
   }
 
@@ -1104,7 +1138,7 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
   };
   clear_acc();
 
-  gptr Cout = p.kt_split > 0 ? (gptr)p.slab + (int64_t)blockIdx.y * p.M * p.N : (gptr)p.C;
+  gptr Cout = p.kt_split > 0 ? (gptr)p.slab + (int64_t)zsplit * p.M * p.N : (gptr)p.C;
   const int64_t ldc = p.kt_split > 0 ? p.N : p.ldc;
   const float alpha_ = p.kt_split > 0 ? 1.f : p.alpha, beta_ = p.kt_split > 0 ? 0.f : p.beta;
   const bool full_tile = row0 + B2 <= p.M && col0 + B2 <= p.N;
@@ -1487,7 +1521,9 @@ __global__ __launch_bounds__(256, 1) void gemm256_bx_kernel(GemmBxArgs p) {
         tile(fbY, faY, fbX, faX);
       }
       if (t + 2 > t1) break;  // at most one tile left: it joins this chain
-      flush_mid(first_flush && beta_ == 0.f);  // end of a chain; its memory operations drain behind the next tile's MFMAs
+      // end of a chain; its memory operations drain behind the next tile's MFMAs.  (As a register read-modify-write like the last
+      // flush: the same within 2 % on split-K Gram matrices and on a five-chain product, profiles/r06_splitk_compact.log.)
+      flush_mid(first_flush && beta_ == 0.f);
       first_flush = false;
       clear_acc();
       next_flush += flush_tiles;
@@ -2697,6 +2733,24 @@ static bool bx_splitk_shape(int64_t M, int64_t N, int64_t K, bool syrk, bool sam
   int64_t s = 512 / tiles;                             // ~2 rounds of one workgroup per CU
   if (s > nt / 64) s = nt / 64;                        // at least 64 k tiles per split
   if (s < 2) return false;
+  {
+    // Compact grid (map_tile_z: one super-block, every split's tiles on ONE XCD, splits dealt round-robin to the 8 XCDs): the
+    // number of splits is 8 g, and what counts is the busiest XCD -- ceil(tiles g / 32) rounds of ceil(nt / 8 g) K tiles on its 32
+    // CUs -- plus the slab the reduce has to read back.  (34 splits of 15 tiles gave two XCDs 75 workgroups and six 60: three
+    // rounds where the others needed two.)
+    const int sbw = syrk ? 16 : sb_width((int)tm, (int)tn), sbh = 256 / sbw;
+    const int64_t nsb = syrk ? cdiv(tm, sbh) * (cdiv(tm, sbh) + 1) / 2 : cdiv(tm, sbh) * cdiv(tn, sbw);
+    if (nsb == 1) {
+      double best = 0.0;
+      int64_t gbest = 0;
+      for (int64_t g = 1; g <= 16 && nt / (8 * g) >= 64; ++g) {
+        const double tile_us = 1.85, slab_us = 8.0 * (double)g * (double)M * (double)N * 8.0 / 5.0e6;
+        const double cost = (double)(cdiv(tiles * g, 32) * cdiv(nt, 8 * g)) * tile_us + slab_us;
+        if (gbest == 0 || cost < best * 0.97) { best = cost; gbest = g; }   // (fewer splits unless more are worth 3 %)
+      }
+      if (gbest > 0) s = 8 * gbest;
+    }
+  }
   const int64_t kts = cdiv(nt, s);
   s = cdiv(nt, kts);
   if (nsplit_out) *nsplit_out = (int)s;
@@ -2748,14 +2802,20 @@ static int bx_splitk_launch(int alay, int blay, const GemmArgs &p, bool syrk, vo
   q.sync = nullptr;
   const int64_t sbm = cdiv(q.tiles_m, sbh), sbn = cdiv(q.tiles_n, sbw);
   const int64_t nsb = syrk ? sbm * (sbm + 1) / 2 : sbm * sbn;
-  const dim3 grid((unsigned)(nsb * 256), (unsigned)nsplit);
+  dim3 grid((unsigned)(nsb * 256), (unsigned)nsplit);
+  if (nsb == 1) {   // one (partial) super-block: the compact grid of map_tile_z, all tiles of a split on one XCD
+    const int64_t d = q.tiles_m < q.tiles_n ? q.tiles_m : q.tiles_n;
+    const int64_t v = syrk ? d * (d + 1) / 2 : (int64_t)q.tiles_m * q.tiles_n;
+    grid = dim3((unsigned)(8 * v * cdiv(nsplit, 8)), 1);
+    q.sbw = -sbw;
+  }
   bx_launch6(grid, q, stream);
   int st = launch_status();
   if (st != VIVIT_OK) return st;
   {  // BX_GATE: the fp32 MFMA kernel with the same K split and slab; returns at once unless the operand is flagged
     GemmArgs f = p;
     f.ksplit = nsplit; f.kchunk = (int64_t)kts * BK; f.slab = slab;
-    f.tiles_m = q.tiles_m; f.tiles_n = q.tiles_n; f.syrk = q.syrk; f.sbw = sbw; f.desc = nullptr;
+    f.tiles_m = q.tiles_m; f.tiles_n = q.tiles_n; f.syrk = q.syrk; f.sbw = q.sbw; f.desc = nullptr;
     f.a_vec = f.b_vec = 1;
     f.gate = flag; f.gate_mask = q.gate_mask;
     if (alay == LAY_K && blay == LAY_K)
